@@ -1,0 +1,293 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (build container only).
+
+    python -m oracle.gen_golden            # from the repo root; needs /root/reference
+
+Every expected output below is computed by the reference's own classes
+(model_spatial_query.py imported via oracle/ref_import.py), with parameters and inputs from
+the build's deterministic PRNG (transeditor_amd/synth.py) so that the GPU box regenerates them
+bit-identically without any reference file.  The script also checks the oracle restatement
+(oracle/te_oracle.py) against the reference on every case and writes the max errors to
+tests/golden/REPORT.txt.  Fixtures are data only (inputs / expected outputs / small weights).
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import, te_oracle as O          # noqa: E402
+from transeditor_amd import synth                       # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+REPORT = []
+
+
+def rel_err(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def note(name, err):
+    REPORT.append(f'{name:58s} oracle-vs-reference max rel err {err:.3e}')
+    assert err < 2e-5, (name, err)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    sz = os.path.getsize(os.path.join(OUT, name + '.npz'))
+    REPORT.append(f'  wrote {name}.npz ({sz / 1024:.1f} KiB)')
+
+
+def sample16(t, key):
+    """16 fixed pseudo-random flat positions of a tensor (per-layer spot checks)."""
+    idx = (synth.normal((16,), 'sample.' + key, 7).abs() * 1e6).long() % t.numel()
+    return t.detach().reshape(-1)[idx]
+
+
+# ------------------------------------------------------------------------------- op fixtures
+
+UPFIRDN_CASES = [
+    # name, shape, taps (1-D => outer product) or '2d', gain, up, down, pad
+    ('blur_p11_g4', (2, 3, 9, 9), (1, 3, 3, 1), 4.0, 1, 1, (1, 1)),       # G upsample-conv blur, :262-268
+    ('blur_p22', (2, 3, 8, 8), (1, 3, 3, 1), 1.0, 1, 1, (2, 2)),          # D conv2 blur, :746-750
+    ('blur_p11', (2, 2, 10, 6), (1, 3, 3, 1), 1.0, 1, 1, (1, 1)),         # D skip blur
+    ('up2_p21_g4', (2, 3, 5, 7), (1, 3, 3, 1), 4.0, 2, 1, (2, 1)),        # ToRGB skip upsample, :95-113
+    ('down2_p11_g4', (2, 3, 10, 14), (1, 3, 3, 1), 4.0, 1, 2, (1, 1)),    # its adjoint (backward)
+    ('down2_p10', (1, 2, 9, 9), (1, 3, 3, 1), 1.0, 1, 2, (1, 0)),         # Downsample, :116-134
+    ('asym4x4', (1, 2, 6, 7), '2d4', 1.0, 1, 1, (2, 1)),                  # flip / true-convolution check
+    ('k3_up2', (1, 2, 4, 5), (1, 2, 1), 4.0, 2, 1, (1, 1)),               # 3-tap (mode 2/4 class)
+    ('k2_down2', (1, 2, 8, 8), (1, 1), 1.0, 1, 2, (0, 0)),                # 2-tap
+    ('crop_negpad', (1, 2, 8, 8), (1, 3, 3, 1), 1.0, 1, 1, (-1, 2)),      # negative pad = crop
+    ('generic_u3d2', (1, 2, 5, 6), '2d5', 1.0, 3, 2, (3, 2)),             # no reference kernel mode: generic
+]
+
+
+def gen_ops(M):
+    ref_up = ref_import.reference_upfirdn2d()
+    d = {}
+    for name, shape, taps, gain, up, down, pad in UPFIRDN_CASES:
+        if taps == '2d4':
+            k = synth.normal((4, 4), 'k.' + name)
+        elif taps == '2d5':
+            k = synth.normal((5, 5), 'k.' + name)
+        else:
+            k = O.fir_kernel(taps, gain)
+        x = synth.normal(shape, 'x.' + name).requires_grad_(True)
+        y = ref_up(x, k, up, down, pad)
+        wy = synth.normal(tuple(y.shape), 'wy.' + name)
+        gx, = torch.autograd.grad((y * wy).sum(), x)
+        yo = O.upfirdn2d(x, k, up, down, pad)
+        note('upfirdn2d.' + name, rel_err(yo, y))
+        d.update({f'{name}.x': x, f'{name}.k': k, f'{name}.y': y, f'{name}.wy': wy, f'{name}.gx': gx,
+                  f'{name}.cfg': np.array([up, down, pad[0], pad[1]])})
+    npz('upfirdn2d', **d)
+
+    d = {}
+    for name, shape in (('2d', (4, 8)), ('4d', (2, 5, 3, 3)), ('3d', (2, 6, 5))):
+        x = synth.normal(shape, 'flr.x.' + name).requires_grad_(True)
+        b = (0.5 * synth.normal((shape[1],), 'flr.b.' + name)).requires_grad_(True)
+        y = O.fused_leaky_relu(x, b)          # restated formula (no native twin in the reference)
+        wy = synth.normal(shape, 'flr.wy.' + name).requires_grad_(True)
+        gx, gb = torch.autograd.grad((y * wy).sum(), (x, b), create_graph=True)
+        u = synth.normal(shape, 'flr.u.' + name)
+        ub = synth.normal((shape[1],), 'flr.ub.' + name)
+        ggy, = torch.autograd.grad((gx * u).sum() + (gb * ub).sum(), wy)
+        d.update({f'{name}.x': x, f'{name}.b': b, f'{name}.y': y, f'{name}.wy': wy, f'{name}.gx': gx,
+                  f'{name}.gb': gb, f'{name}.u': u, f'{name}.ub': ub, f'{name}.ggy': ggy})
+    npz('fused_leaky_relu', **d)
+
+    # ModulatedConv2d (reference class), incl. first grads and a path-length style second-order term
+    d = {}
+    for name, (B, cin, cout, k, H, demod, upsmp) in {
+            'plain3': (3, 6, 5, 3, 7, True, False), 'up3': (2, 4, 6, 3, 5, True, True),
+            'rgb1': (2, 8, 3, 1, 6, False, False), 'plain3_wide': (2, 40, 36, 3, 12, True, False),
+            'up3_wide': (2, 36, 40, 3, 9, True, True)}.items():
+        m = M.ModulatedConv2d(cin, cout, k, 16, demodulate=demod, upsample=upsmp)
+        sd = m.state_dict()
+        for kk, t in sd.items():
+            if 'blur' not in kk:
+                t.copy_(synth.normal(tuple(t.shape), f'mc.{name}.{kk}') * (0.3 if 'bias' in kk else 1.0)
+                        + (1.0 if 'modulation.bias' in kk else 0.0))
+        x = synth.normal((B, cin, H, H), f'mc.{name}.x').requires_grad_(True)
+        s = synth.normal((B, 16), f'mc.{name}.s').requires_grad_(True)
+        y = m(x, s)
+        wy = synth.normal(tuple(y.shape), f'mc.{name}.wy')
+        params = [m.weight, m.modulation.weight, m.modulation.bias]
+        g = torch.autograd.grad((y * wy).sum(), [x, s] + params, create_graph=True)
+        pl = g[1].pow(2).sum()                       # second order through d/dstyle, as g_path_regularize does
+        g2 = torch.autograd.grad(pl, [x] + params, allow_unused=True)     # rgb1: no demod => mod_b unused
+        g2 = [torch.zeros_like(t) if gi is None else gi for gi, t in zip(g2, [x] + params)]
+        P = {kk: v for kk, v in m.state_dict().items()}
+        yo = O.modulated_conv2d(x, s, P['weight'], P['modulation.weight'], P['modulation.bias'], demod, upsmp)
+        note('modulated_conv2d.' + name, rel_err(yo, y))
+        d.update({f'{name}.x': x, f'{name}.s': s, f'{name}.y': y, f'{name}.wy': wy,
+                  f'{name}.weight': m.weight, f'{name}.mod_w': m.modulation.weight, f'{name}.mod_b': m.modulation.bias,
+                  f'{name}.gx': g[0], f'{name}.gs': g[1], f'{name}.gw': g[2], f'{name}.gmw': g[3], f'{name}.gmb': g[4],
+                  f'{name}.pl': pl, f'{name}.pl_gx': g2[0], f'{name}.pl_gw': g2[1], f'{name}.pl_gmw': g2[2],
+                  f'{name}.pl_gmb': g2[3], f'{name}.cfg': np.array([demod, upsmp])})
+    npz('modulated_conv2d', **d)
+
+    # AttentionBlock at 528 (block 0) and 512
+    d = {}
+    for name, (cin, cp) in {'b0_528': (528, 528), 'b_512': (512, 512)}.items():
+        m = M.AttentionBlock(cin, cp, 512, lr_mul=0.01)
+        for kk, t in m.state_dict().items():          # lr_mul=0.01 convention: weight ~ randn/lr_mul
+            t.copy_(synth.normal(tuple(t.shape), f'ab.{name}.{kk}') * (10.0 if 'bias' in kk else 100.0))
+        x = synth.normal((2, 16, cin), f'ab.{name}.x').requires_grad_(True)
+        p = synth.normal((2, 16, cp), f'ab.{name}.p').requires_grad_(True)
+        y, sim = m(x, p, return_similarity=True)
+        wy = synth.normal(tuple(y.shape), f'ab.{name}.wy')
+        gx, gp = torch.autograd.grad((y * wy).sum(), (x, p))
+        P = {'b.' + kk: v for kk, v in m.state_dict().items()}
+        yo, simo = O.attention_block(P, 'b', x, p, 0.01)
+        note('attention_block.' + name, max(rel_err(yo, y), rel_err(simo, sim)))
+        d.update({f'{name}.x': x, f'{name}.p': p, f'{name}.y': y, f'{name}.sim': sim, f'{name}.wy': wy,
+                  f'{name}.gx': gx, f'{name}.gp': gp})
+    npz('attention_block', **d)
+
+
+# ------------------------------------------------------------------------------- full generator
+
+def build_ref_generator(M, size, seed):
+    token = 2 * (int(math.log2(size)) - 1)                      # train_spatial_query.py:432
+    g = M.Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1)   # CLI default dim=1 (:415)
+    synth.fill_state_dict(g.state_dict(), seed)
+    return g
+
+
+def gen_generator(M):
+    # BASELINE config 1: 64x64, batch 4, n_trans 8
+    g = build_ref_generator(M, 64, seed=0)
+    P = {k: v.detach() for k, v in g.state_dict().items()}
+    z, p = synth.latents(4, 1000)
+    z.requires_grad_(True)
+    p.requires_grad_(True)
+    img, latent, _ = g(z, p, return_latents=True)
+    wimg = synth.normal(tuple(img.shape), 'wimg.64')
+    loss = (img * wimg).sum() / img.numel()
+    names = [n for n, _ in g.named_parameters()]
+    grads = torch.autograd.grad(loss, [z, p] + list(g.parameters()), allow_unused=True)
+    gnorm = np.array([0.0 if t is None else float(t.double().norm()) for t in grads[2:]])
+    taps = {}
+    img_o, lat_o, _ = O.generator_forward(P, z, p, 64, taps=taps)
+    note('generator64.image', rel_err(img_o, img))
+    note('generator64.latent', rel_err(lat_o, latent))
+    stylecode, spatialcode = g(z, p, return_mapped_codes=True)
+    lat2, spc2, st_o, sp_o, sims = O.generator_latent(P, z, p)
+    note('generator64.mapped_z', rel_err(st_o, stylecode))
+    note('generator64.mapped_p', rel_err(sp_o, spatialcode))
+    go = torch.autograd.grad((img_o * wimg).sum() / img.numel(), [z, p])
+    note('generator64.grad_z', rel_err(go[0], grads[0]))
+    note('generator64.grad_p', rel_err(go[1], grads[1]))
+    layer_stats = {}
+    for k, t in taps.items():            # oracle == reference to 1e-6 (asserted above); stats for per-layer checks
+        layer_stats[f'layer.{k}.stats'] = torch.stack([t.mean(), t.abs().max()])
+        layer_stats[f'layer.{k}.samples'] = sample16(t, k)
+    npz('generator64_b4', image=img, latent=latent, stylecode=stylecode, spatialcode=spatialcode,
+        wimg_key='wimg.64', gz=grads[0], gp=grads[1], grad_norms=gnorm, grad_names=np.array(names),
+        sim_last=sims[-1], **layer_stats,
+        g_adjust_w=grads[2 + names.index('adjust_style.weight')],
+        g_rgb1_bias=grads[2 + names.index('to_rgb1.bias')],
+        g_conv1_act_bias=grads[2 + names.index('conv1.activate.bias')],
+        g_last_act_bias=grads[2 + names.index('convs.7.activate.bias')])
+
+    # forward-flag surface (test_spatial_query.py:90-103,128-137,168-177,205-214) on the same model
+    with torch.no_grad():
+        zz, pp = synth.latents(2, 1001)
+        d = {}
+        d['mapped_p'] = g(zz, pp, return_only_mapped_p=True)
+        d['mapped_z'] = g(zz, pp, return_only_mapped_z=True)
+        d['style_latent'] = g(zz, pp, return_only_style_latent=True)
+        mz, mp = d['mapped_z'], d['mapped_p']
+        d['img_nomap'] = g(mz, mp, use_style_mapping=False, use_spatial_mapping=False)[0]
+        d['img_default'] = g(zz, pp)[0]
+        lat = d['style_latent']
+        d['img_from_latent'] = g(lat, pp, input_is_latent=True)[0]
+        i2, l2 = g(zz, pp, return_style=True)
+        d['ret_style_latent'] = l2
+        i3, sp3 = g(zz, pp, return_p_latent=True)
+        d['ret_p_latent'] = sp3
+        # NB: trans_interact=False on a model built with no_trans=False raises UnboundLocalError in the
+        # reference (model_spatial_query.py:686 reads `x` that :675 never assigned) - not a usable mode.
+    npz('generator64_flags', **d)
+    del g
+
+    # small sizes (deep-pyramid plumbing) + path-length regulariser on 32x32
+    for size, B in ((8, 2), (32, 2)):
+        g = build_ref_generator(M, size, seed=size)
+        P = {k: v.detach() for k, v in g.state_dict().items()}
+        z, p = synth.latents(B, 2000 + size)
+        img, latent, _ = g(z, p, return_latents=True)
+        img_o, lat_o, _ = O.generator_forward(P, z, p, size)
+        note(f'generator{size}.image', rel_err(img_o, img))
+        d = {'image': img, 'latent': latent}
+        if size == 32:
+            noise = synth.normal(tuple(img.shape), 'pl.noise') / math.sqrt(size * size)
+            grad, = torch.autograd.grad((img * noise).sum(), latent, create_graph=True)
+            lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
+            mean = 0.0 + 0.01 * (lengths.mean() - 0.0)
+            pen = (lengths - mean).pow(2).mean()
+            names = [n for n, _ in g.named_parameters()]
+            gs = torch.autograd.grad(pen, list(g.parameters()), allow_unused=True)
+            d.update(path_lengths=lengths, path_penalty=pen,
+                     pl_grad_norms=np.array([0.0 if t is None else float(t.double().norm()) for t in gs]),
+                     pl_grad_names=np.array(names))
+            # oracle double backward vs reference
+            Pg = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in P.items()}
+            io, lo, _ = O.generator_forward(Pg, z, p, size)
+            peno, _, leno = O.g_path_regularize(io, lo, 0.0, noise)
+            note('generator32.path_lengths', rel_err(leno, lengths))
+            keys = [k for k in names]
+            gso = torch.autograd.grad(peno, [Pg[k] for k in keys], allow_unused=True)
+            e = max(abs(float(a.double().norm()) - b) / (b + 1e-12)
+                    for a, b in zip(gso, d['pl_grad_norms']) if a is not None and b > 1e-8)
+            note('generator32.path_penalty_param_grads(norms)', e)
+        npz(f'generator{size}_b{B}', **d)
+        del g
+
+
+def gen_discriminator(M):
+    dmod = M.Discriminator(64)
+    synth.fill_state_dict(dmod.state_dict(), 5)
+    P = {k: v.detach() for k, v in dmod.state_dict().items()}
+    img = synth.normal((4, 3, 64, 64), 'd.img').clamp(-1, 1).requires_grad_(True)
+    fake = synth.normal((4, 3, 64, 64), 'd.fake').clamp(-1, 1)
+    pred = dmod(img)
+    fpred = dmod(fake)
+    gr, = torch.autograd.grad(pred.sum(), img, create_graph=True)
+    r1 = gr.pow(2).reshape(4, -1).sum(1).mean()
+    names = [n for n, _ in dmod.named_parameters()]
+    gs = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * pred[0], list(dmod.parameters()), allow_unused=True, retain_graph=True)
+    dl = F.softplus(-pred).mean() + F.softplus(fpred).mean()
+    gl = F.softplus(-fpred).mean()
+    po = O.discriminator_forward(P, img, 64)
+    note('discriminator64.pred', rel_err(po, pred))
+    note('discriminator64.r1', abs(float(O.d_r1_loss(po, img)) - float(r1)) / float(r1))
+    npz('discriminator64_b4', pred=pred, fake_pred=fpred, r1=r1, d_loss=dl, g_loss=gl,
+        r1_grad_norms=np.array([0.0 if t is None else float(t.double().norm()) for t in gs]),
+        r1_grad_names=np.array(names))
+
+
+def main():
+    assert ref_import.available(), 'needs /root/reference (build container only)'
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    M = ref_import.import_reference()
+    gen_ops(M)
+    gen_generator(M)
+    gen_discriminator(M)
+    with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:
+        f.write('golden fixtures generated by oracle/gen_golden.py from the imported reference\n')
+        f.write(f'torch {torch.__version__}, numpy {np.__version__}\n')
+        f.write('\n'.join(REPORT) + '\n')
+    print('\n'.join(REPORT))
+
+
+if __name__ == '__main__':
+    main()
