@@ -1,0 +1,142 @@
+/*
+ * te_hip.h — C ABI of libte_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * TransEditor generator hot path.
+ *
+ * Conventions (SURVEY §8b "What a C-ABI replacement must export"):
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; the CALLER owns every
+ *     buffer (the Python host allocates through the torch caching allocator);
+ *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
+ *     no synchronisation, no global mutable state; safe to call from several host threads;
+ *   - return 0 on success, a negative TE_ERR_* for argument validation failures, or a positive
+ *     hipError_t if the launch failed; nothing throws across the ABI.  te_last_error_string()
+ *     describes the calling thread's most recent failure.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * BillyXYB/TransEditor repository root).
+ */
+#ifndef TE_HIP_H
+#define TE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TE_ABI_VERSION 1
+
+#define TE_ERR_NULL -1      /* required pointer is NULL              */
+#define TE_ERR_SHAPE -2     /* non-positive / inconsistent dimension */
+#define TE_ERR_UNSUPPORTED -3
+#define TE_ERR_WORKSPACE -4 /* workspace too small                   */
+
+typedef void* te_stream_t;
+
+int te_version(void);
+const char* te_last_error_string(void);
+/* name of the code-object architecture this library was built for ("gfx950") */
+const char* te_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  fused bias + activation.  Replaces pybind `fused.fused_bias_act(input, bias, refer, act,
+ * grad, alpha, scale)` — utils/op/fused_bias_act.cpp:11-21, kernel fused_bias_act_kernel.cu:18-49.
+ *   x' = x + b[(i / step_b) % size_b]     (b may be NULL = no bias; integer index math bit-exact)
+ *   act*10+grad: 10/11 linear, 12 -> 0, 30 lrelu(x'), 31 x' * (ref>0 ? 1 : alpha), 32 -> 0
+ *   out = y * scale.   `ref` may be NULL (treated as 0).  In-place (out == x) is allowed.
+ */
+int te_bias_act_f32(float* out, const float* x, const float* b, const float* ref, int act, int grad,
+                    float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
+                    te_stream_t stream);
+
+/* Backward of the fused lrelu in ONE pass — replaces FusedLeakyReLUFunctionBackward.forward,
+ * utils/op/fused_act.py:18-38 (kernel call + grad_input.sum(dim)):
+ *   gi[n,c,i] = g[n,c,i] * (ref[n,c,i] > 0 ? 1 : alpha) * scale ;  gb[c] = sum_{n,i} gi[n,c,i]
+ * Layout [outer][C][inner].  gb (may be NULL) must be zero-filled by the caller (partial sums
+ * are combined with atomics).  */
+int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const float* ref, float alpha, float scale,
+                        int64_t outer, int64_t C, int64_t inner, te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  upfirdn2d.  Replaces pybind `upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel, up_x,
+ * up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)` — utils/op/upfirdn2d.cpp:12-23, kernel
+ * upfirdn2d_kernel.cu:52-137.  Output dims follow upfirdn2d.py:101-102:
+ *   out_h = (in_h*up_y + pad_y0 + pad_y1 - kh) / down_y + 1 (same for w); caller allocates
+ *   out[major, out_h, out_w, minor].  True convolution (taps flipped), zero fill outside the
+ *   input.  Unlike the reference (6 template modes, garbage otherwise) every (up, down, k) works.
+ * Optional fused epilogue (b != NULL or act != 0), minor must be 1: channel = major_index % size_b,
+ *   out = act(out + b[channel]) * scale with act 0 = linear, 3 = lrelu(alpha).
+ */
+int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, int in_h, int in_w,
+                     int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                     int pad_x1, int pad_y0, int pad_y1, const float* b, int64_t size_b, int act,
+                     float alpha, float scale, te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F1  modulated convolution family (reference: ModulatedConv2d.forward, model_spatial_query.py:
+ * 296-337, which the reference runs as stock grouped F.conv2d / F.conv_transpose2d with B
+ * materialised weight copies).  Here ONE shared weight tensor is used and the per-sample style
+ * modulation / demodulation are row/column scalings fused into the kernel:
+ *     out[b,m,:,:] = act( osc[b,m] * conv(isc[b,k] * in[b,k,:,:], W)[m] + bias[m] )
+ *
+ * Weights are consumed in a packed layout  Wp[tap][Kp][Mp]  (Kp = K rounded up to 8, Mp = M
+ * rounded up to 128, zero padded) produced by te_conv_pack_weights_f32.
+ */
+
+/* kind of convolution executed by te_conv_f32 */
+#define TE_CONV_3X3 0    /* 3x3, stride 1, pad 1           in [B,K,H,W]       -> out [B,M,H,W]        */
+#define TE_CONV_T2 1     /* 3x3 transposed, stride 2, pad 0 in [B,K,H,W]       -> out [B,M,2H+1,2W+1]  */
+#define TE_CONV_S2 2     /* 3x3, stride 2, pad 0           in [B,K,2H+1,2W+1] -> out [B,M,H,W]        */
+#define TE_CONV_1X1 3    /* 1x1                            in [B,K,H,W]       -> out [B,M,H,W]        */
+
+/* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
+ * ModulatedConv2d.weight[0]) */
+#define TE_PACK_FWD 0    /* M = Co, K = Ci, taps as stored         (forward 3x3 / 1x1 / T2, and S2) */
+#define TE_PACK_DGRAD 1  /* M = Ci, K = Co, taps flipped           (data gradient of 3x3 / 1x1)     */
+#define TE_PACK_SWAP 2   /* M = Ci, K = Co, taps as stored         (S2 as data gradient of T2)       */
+
+int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
+int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
+                             int ksize, te_stream_t stream);
+
+/* `H`,`W` are ALWAYS the low-resolution size (the H,W of the table above).  isc [B,K], osc [B,M],
+ * bias [M] may be NULL.  act: 0 linear, 3 lrelu(0.2)*sqrt(2) (applied after osc and bias). */
+int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
+                const float* bias, int act, int kind, int B, int K, int M, int H, int W,
+                te_stream_t stream);
+
+/* Weight-gradient correlation, per sample and per pixel chunk ("slabs"), NO modulation applied:
+ *   slab[b][s][co][ci][tap] = sum_{pixels of chunk s} g[b,co,p (+) tap] * x[b,ci,p]
+ * kind TE_CONV_3X3 / TE_CONV_1X1: g [B,Co,H,W], x [B,Ci,H,W];
+ * kind TE_CONV_T2: g [B,Co,2H+1,2W+1], x [B,Ci,H,W]  (weight gradient of the transposed conv).
+ * te_wgrad_slab_count returns S (chunks per sample) for the given problem; the caller allocates
+ * slabs[B][S][Co][Ci][taps] and reduces them with te_wgrad_reduce_f32. */
+int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W);
+int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H,
+                 int W, int S, te_stream_t stream);
+
+/* Combine slabs (SURVEY §7 step 6 "reductions for ds, dd"):
+ *   gw[co,ci,t]  = wscale * sum_{b,s} osc[b,co]*isc[b,ci] * slab          (gw   may be NULL)
+ *   gisc[b,ci]   = sum_{co,t,s} wscale*w[co,ci,t] * osc[b,co] * slab      (gisc may be NULL)
+ *   gosc[b,co]   = sum_{ci,t,s} wscale*w[co,ci,t] * isc[b,ci] * slab      (gosc may be NULL)
+ * isc / osc NULL = all ones.  gisc/gosc must be zero-filled by the caller. */
+int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const float* slabs, const float* w,
+                        float wscale, const float* isc, const float* osc, int B, int S, int Co, int Ci,
+                        int taps, te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F2  attention core of the dual-space cross-attention block (reference: Attention.forward,
+ * model_spatial_query.py:888-894): per sample and head,  sim = softmax(scale * q k^T),
+ * o = sim v, with QK^T and sim.V on v_mfma_f32_16x16x4_f32.
+ *   q [N, M, G*D], k,v [N, L, G*D] (token-major, as produced by the q/k/v linears), o [N, M, G*D],
+ *   sim [N, G, M, L].  Supported: M == L == 16, D == 32 (the only shape the model produces).
+ */
+int te_attn_fwd_f32(float* o, float* sim, const float* q, const float* k, const float* v, float scale,
+                    int N, int G, int M, int L, int D, te_stream_t stream);
+int te_attn_bwd_f32(float* gq, float* gk, float* gv, const float* go, const float* gsim_or_null,
+                    const float* q, const float* k, const float* v, const float* sim, float scale, int N,
+                    int G, int M, int L, int D, te_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TE_HIP_H */

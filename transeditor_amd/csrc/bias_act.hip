@@ -1,0 +1,187 @@
+// K1: fused bias + leaky-ReLU family for gfx950 (wave64).
+//   te_bias_act_f32      forward / grad / grad-grad in one kernel family (HBM streaming, 16 B per lane)
+//   te_bias_act_bwd_f32  gi = g * slope(ref) * scale and the per-channel bias gradient in the same pass
+//                        (wave64 shuffle reduction -> LDS across the 4 waves -> one atomic per block)
+// Semantics follow the reference op (fused_bias_act_kernel.cu:26-47); the channel index of flat
+// element i is (i / step_b) % size_b with integer arithmetic.
+#include "te_common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_one(float x, float r, int mode, float alpha) {
+    // mode = act*10 + grad
+    switch (mode) {
+        case 30: return x > 0.f ? x : x * alpha;
+        case 31: return r > 0.f ? x : x * alpha;
+        case 12:
+        case 32: return 0.f;
+        default: return x;  // 10, 11: linear
+    }
+}
+
+// one float4 per lane per iteration; requires step_b % 4 == 0 (so the 4 lanes of a vector share a channel)
+__global__ __launch_bounds__(256) void bias_act_vec4_kernel(float4* __restrict__ out, const float4* __restrict__ x,
+                                                            const float* __restrict__ b, const float4* __restrict__ ref,
+                                                            int mode, float alpha, float scale, uint32_t n4,
+                                                            uint32_t step_b4, uint32_t size_b) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = x[i];
+        if (b) {
+            const float bb = b[(i / step_b4) % size_b];
+            v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+        }
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ref) r = ref[i];
+        float4 y;
+        y.x = act_one(v.x, r.x, mode, alpha) * scale;
+        y.y = act_one(v.y, r.y, mode, alpha) * scale;
+        y.z = act_one(v.z, r.z, mode, alpha) * scale;
+        y.w = act_one(v.w, r.w, mode, alpha) * scale;
+        out[i] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_act_scalar_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                              const float* __restrict__ b, const float* __restrict__ ref,
+                                                              int mode, float alpha, float scale, int64_t n,
+                                                              int64_t step_b, int64_t size_b) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i];
+        if (b) v += b[(i / step_b) % size_b];
+        const float r = ref ? ref[i] : 0.f;
+        out[i] = act_one(v, r, mode, alpha) * scale;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* lds4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) lds4[wid] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];  // every thread gets the total
+}
+
+// [outer][C][inner], inner % 4 == 0: grid (chunks, C, outer); each block streams CH float4-vectors of one row
+constexpr int kBwdVecPerThread = 4;
+__global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restrict__ gi, float* __restrict__ gb,
+                                                                const float4* __restrict__ g, const float4* __restrict__ ref,
+                                                                float alpha, float scale, uint32_t C, uint32_t inner4) {
+    __shared__ float lds4[4];
+    const uint32_t c = blockIdx.y, n = blockIdx.z;
+    const size_t row = ((size_t)n * C + c) * inner4;
+    const uint32_t base = blockIdx.x * (256 * kBwdVecPerThread);
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < kBwdVecPerThread; ++it) {
+        const uint32_t i = base + it * 256 + threadIdx.x;
+        if (i < inner4) {
+            const float4 gv = g[row + i], rv = ref[row + i];
+            float4 o;
+            o.x = gv.x * (rv.x > 0.f ? 1.f : alpha) * scale;
+            o.y = gv.y * (rv.y > 0.f ? 1.f : alpha) * scale;
+            o.z = gv.z * (rv.z > 0.f ? 1.f : alpha) * scale;
+            o.w = gv.w * (rv.w > 0.f ? 1.f : alpha) * scale;
+            gi[row + i] = o;
+            acc += (o.x + o.y) + (o.z + o.w);
+        }
+    }
+    if (gb) {
+        const float tot = block_sum_256(acc, lds4);
+        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+    }
+}
+
+// generic layout: one block per channel, loops over (n, i)
+__global__ __launch_bounds__(256) void bias_act_bwd_chan_kernel(float* __restrict__ gi, float* __restrict__ gb,
+                                                                const float* __restrict__ g, const float* __restrict__ ref,
+                                                                float alpha, float scale, int64_t outer, int64_t C,
+                                                                int64_t inner) {
+    __shared__ float lds4[4];
+    const int64_t c = blockIdx.x;
+    const int64_t per = outer * inner;
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < per; e += 256) {
+        const int64_t n = e / inner, i = e - n * inner;
+        const int64_t idx = (n * C + c) * inner + i;
+        const float o = g[idx] * (ref[idx] > 0.f ? 1.f : alpha) * scale;
+        gi[idx] = o;
+        acc += o;
+    }
+    if (gb) {
+        const float tot = block_sum_256(acc, lds4);
+        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+    }
+}
+
+// 2-D [N][C] (inner == 1): thread per channel, coalesced across c
+__global__ __launch_bounds__(256) void bias_act_bwd_2d_kernel(float* __restrict__ gi, float* __restrict__ gb,
+                                                              const float* __restrict__ g, const float* __restrict__ ref,
+                                                              float alpha, float scale, int64_t N, int64_t C) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t idx = n * C + c;
+        const float o = g[idx] * (ref[idx] > 0.f ? 1.f : alpha) * scale;
+        gi[idx] = o;
+        acc += o;
+    }
+    if (gb) atomicAdd(gb + c, acc);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int te_bias_act_f32(float* out, const float* x, const float* b, const float* ref, int act, int grad,
+                               float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
+                               te_stream_t stream_) {
+    TE_REQUIRE(out && x, TE_ERR_NULL, "te_bias_act_f32: out/x is NULL");
+    TE_REQUIRE(size_x >= 0, TE_ERR_SHAPE, "te_bias_act_f32: size_x < 0");
+    TE_REQUIRE(!b || (step_b > 0 && size_b > 0), TE_ERR_SHAPE, "te_bias_act_f32: bias given but step_b/size_b <= 0");
+    if (size_x == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int mode = act * 10 + grad;
+    const bool vec = (size_x % 4 == 0) && (!b || step_b % 4 == 0) && aligned16(out) && aligned16(x) &&
+                     (!ref || aligned16(ref)) && (size_x / 4 < (int64_t)0xFFFFFFFF);
+    if (vec) {
+        const uint32_t n4 = (uint32_t)(size_x / 4);
+        const int grid = (int)std::min<int64_t>(te::cdiv(n4, 256), te::kNumCU * 8);
+        bias_act_vec4_kernel<<<grid, 256, 0, stream>>>((float4*)out, (const float4*)x, b, (const float4*)ref, mode, alpha,
+                                                       scale, n4, b ? (uint32_t)(step_b / 4) : 1u,
+                                                       b ? (uint32_t)size_b : 1u);
+    } else {
+        const int grid = (int)std::min<int64_t>(te::cdiv(size_x, 256), te::kNumCU * 8);
+        bias_act_scalar_kernel<<<grid, 256, 0, stream>>>(out, x, b, ref, mode, alpha, scale, size_x, b ? step_b : 1,
+                                                         b ? size_b : 1);
+    }
+    return te::launch_status("te_bias_act_f32");
+}
+
+extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const float* ref, float alpha, float scale,
+                                   int64_t outer, int64_t C, int64_t inner, te_stream_t stream_) {
+    TE_REQUIRE(gi && g && ref, TE_ERR_NULL, "te_bias_act_bwd_f32: gi/g/ref is NULL");
+    TE_REQUIRE(outer >= 0 && C > 0 && inner > 0, TE_ERR_SHAPE, "te_bias_act_bwd_f32: bad dims");
+    if (outer == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (inner == 1) {
+        bias_act_bwd_2d_kernel<<<(int)te::cdiv(C, 256), 256, 0, stream>>>(gi, gb, g, ref, alpha, scale, outer, C);
+    } else if (inner % 4 == 0 && inner >= 1024 && aligned16(gi) && aligned16(g) && aligned16(ref) && C <= 65535 &&
+               outer <= 65535) {
+        const uint32_t inner4 = (uint32_t)(inner / 4);
+        dim3 grid((unsigned)te::cdiv(inner4, 256 * kBwdVecPerThread), (unsigned)C, (unsigned)outer);
+        bias_act_bwd_rows_kernel<<<grid, 256, 0, stream>>>((float4*)gi, gb, (const float4*)g, (const float4*)ref, alpha,
+                                                           scale, (uint32_t)C, inner4);
+    } else {
+        bias_act_bwd_chan_kernel<<<(int)C, 256, 0, stream>>>(gi, gb, g, ref, alpha, scale, outer, C, inner);
+    }
+    return te::launch_status("te_bias_act_bwd_f32");
+}

@@ -1,0 +1,400 @@
+// F1: modulated-convolution family as implicit GEMM on the gfx950 fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD = the fp32 peak of the chip).
+//
+//     out[b,m,:,:] = act( osc[b,m] * sum_{k,tap} Wp[tap][k][m] * (isc[b,k] * in[b,k, . (+) tap]) + bias[m] )
+//
+// One shared (packed) weight tensor for the whole batch; the per-sample style modulation is a scaling of
+// the input channels applied while the input tile is staged into LDS, the demodulation a scaling of the
+// output channels applied in the epilogue together with bias + leaky-ReLU.  (The reference materialises B
+// per-sample weight copies and calls stock grouped convolutions: model_spatial_query.py:296-337.)
+//
+// GEMM view:  M = output channels (block tile 128),  N = output cells (block tile 32*NBW*2 cells, laid
+// out as NS samples x TH rows x TW cols, all powers of two chosen at launch so 4x4 ... 1024x1024 images
+// all fill the tile),  K = input channels, 8 per stage, times the taps.
+// 4 waves per block as 2(M) x 2(N); each wave owns MBW x NACC accumulator tiles of 32x32.
+//
+// Kinds (include/te_hip.h):
+//   3X3  3x3 stride 1 pad 1                       (forward of plain layers; with flipped/transposed packing,
+//                                                  their data gradient)
+//   1X1  ToRGB
+//   S2   3x3 stride 2 over a (2H+1)x(2W+1) input  (data gradient of T2)
+//   T2   3x3 transposed stride 2 -> (2H+1)x(2W+1) (forward of the upsampling layers).  Written as its four
+//        output phases (row parity a, col parity b): phase (a,b) of cell (i,j) is output (2i+a, 2j+b) and
+//        receives only the taps with ky = a (mod 2), kx = b (mod 2) -> 4+2+2+1 = 9 tap-GEMMs per cell,
+//        i.e. exactly the FLOPs of the zero-insertion-free transposed convolution.
+#include "te_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 struct copies lower to memcpy and stay in scratch)
+
+constexpr int KC = 8;     // input channels per stage
+constexpr int BM = 128;   // block tile, output channels
+constexpr int NTHREADS = 256;
+
+struct ConvArgs {
+    float* out;
+    const float* in;
+    const float* wp;
+    const float* isc;
+    const float* osc;
+    const float* bias;
+    int B, K, M, Kp, Mp;
+    int Hi, Wi, Ho, Wo;      // input / output spatial size
+    int H, W;                // low-resolution size (cells of T2 live on (H+1)x(W+1))
+    int ri0, rj0, rh, rw;    // cell region handled by this launch
+    int TH, TW, NS, lgTW, lgTH;
+    int tiles_x, tiles_y;    // tiles per sample group
+    int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
+    int act;
+};
+
+template <int KIND> struct Kind;
+template <> struct Kind<TE_CONV_3X3> { static constexpr int NT = 9; };
+template <> struct Kind<TE_CONV_T2>  { static constexpr int NT = 9; };
+template <> struct Kind<TE_CONV_S2>  { static constexpr int NT = 9; };
+template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
+
+// MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
+// NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
+template <int KIND, int NBW, bool HAS_ISC>
+__global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
+    constexpr int MBW = 2;
+    constexpr int NTAP = Kind<KIND>::NT;
+    constexpr bool IS_T2 = (KIND == TE_CONV_T2);
+    constexpr int NACC = IS_T2 ? 4 * NBW : NBW;
+    constexpr int NTILE = 2 * NBW * 32;           // cells per block tile
+    constexpr int WSTAGE = NTAP * KC * BM;        // floats of packed weights per stage
+    constexpr int WLD = (WSTAGE / 4) / NTHREADS;  // float4 loads per thread per stage
+    static_assert((WSTAGE / 4) % NTHREADS == 0, "weight stage must split evenly over the block");
+    constexpr int WLDR = (WSTAGE / 4 + NTHREADS - 1) / NTHREADS;
+    constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;            // [NTAP][KC][BM]
+    float* xl = smem + WSTAGE;   // [KC][CS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- tile coordinates
+    int t = blockIdx.x;
+    const int tx_i = t % p.tiles_x; t /= p.tiles_x;
+    const int ty_i = t % p.tiles_y; t /= p.tiles_y;
+    const int b0 = t * p.NS;
+    const int m0 = blockIdx.y * BM;
+    const int ci0 = p.ri0 + ty_i * p.TH, cj0 = p.rj0 + tx_i * p.TW;   // first cell of the tile
+    // origin of the input tile in input coordinates
+    int oy, ox;
+    if (KIND == TE_CONV_3X3) { oy = ci0 - 1; ox = cj0 - 1; }
+    else if (KIND == TE_CONV_S2) { oy = 2 * ci0; ox = 2 * cj0; }
+    else if (KIND == TE_CONV_T2) { oy = ci0 - 1; ox = cj0 - 1; }
+    else { oy = ci0; ox = cj0; }
+
+    // ---- per-thread staging descriptors (constant over the K loop)
+    const int tile_sp = p.TIH * p.TIW;
+    const int n_sp = p.NS * tile_sp;
+    int64_t goff[NSP];       // global offset of channel 0 (clamped to a safe address when the element is padding)
+    float gmask[NSP];        // 1 = real pixel, 0 = zero padding
+    int loff[NSP], sb[NSP];  // LDS offset (or -1: no element for this thread), sample index
+    const int64_t plane = (int64_t)p.Hi * p.Wi;
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int e = tid + NTHREADS * r;
+        goff[r] = 0; gmask[r] = 0.f; loff[r] = -1; sb[r] = 0;
+        if (e < n_sp) {
+            const int s = e / tile_sp, rem = e - s * tile_sp;
+            const int ry = rem / p.TIW, rx = rem - ry * p.TIW;
+            const int b = b0 + s, gy = oy + ry, gx = ox + rx;
+            loff[r] = s * p.SS + ry * p.TIWP + rx;
+            sb[r] = b < p.B ? b : 0;
+            if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
+                goff[r] = (int64_t)b * p.K * plane + (int64_t)gy * p.Wi + gx;
+                gmask[r] = 1.f;
+            }
+        }
+    }
+
+    // ---- per-lane B-fragment base offsets (LDS floats), one per cell block
+    int boff[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int c = wn * (NBW * 32) + nb * 32 + l31;
+        const int s = c >> (p.lgTW + p.lgTH);
+        const int ty = (c >> p.lgTW) & (p.TH - 1), tx = c & (p.TW - 1);
+        int o;
+        if (KIND == TE_CONV_S2) o = 2 * ty * p.TIWP + 2 * tx;
+        else if (KIND == TE_CONV_T2) o = (ty + 1) * p.TIWP + tx + 1;
+        else o = ty * p.TIWP + tx;
+        boff[nb] = s * p.SS + o + half * p.CS;
+    }
+    const int aoff = half * BM + wm * (MBW * 32) + l31;   // A-fragment base inside wl
+
+    f32x16 acc[MBW][NACC];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- register prefetch buffers
+    f32x4 wreg[WLDR];
+    float xreg[NSP][KC];
+
+    // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
+    // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
+    for (int k0 = -KC; k0 < p.Kp; k0 += KC) {
+        if (k0 >= 0) {
+            __syncthreads();              // every wave finished reading the previous stage
+#pragma unroll
+            for (int r = 0; r < WLDR; ++r) {
+                const int idx = tid + NTHREADS * r;
+                *reinterpret_cast<f32x4*>(wl + idx * 4) = wreg[r];
+            }
+#pragma unroll
+            for (int r = 0; r < NSP; ++r) {
+                if (loff[r] >= 0) {
+#pragma unroll
+                    for (int kk = 0; kk < KC; ++kk) xl[kk * p.CS + loff[r]] = xreg[r][kk];
+                }
+            }
+            __syncthreads();
+        }
+        const int kn = k0 + KC;
+        if (kn < p.Kp) {
+#pragma unroll
+            for (int r = 0; r < WLDR; ++r) {
+                const int idx = tid + NTHREADS * r;          // float4 index inside the stage
+                const int row = idx >> 5, c4 = idx & 31;      // row = tap*KC + kk ; 32 float4 per 128-wide row
+                const int tap = row / KC, kk = row - tap * KC;
+                wreg[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(tap * p.Kp + kn + kk) * p.Mp + m0 + c4 * 4));
+            }
+#pragma unroll
+            for (int r = 0; r < NSP; ++r) {
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk) {
+                    // unconditional loads from clamped addresses (a branch per element would serialise the loads);
+                    // padding / channel tail are zeroed by the mask
+                    const int k = kn + kk;
+                    const int kc = k < p.K ? k : p.K - 1;
+                    float v = p.in[goff[r] + (int64_t)kc * plane];
+                    float m = k < p.K ? gmask[r] : 0.f;
+                    if (HAS_ISC) m *= p.isc[sb[r] * p.K + kc];
+                    xreg[r][kk] = m != 0.f ? v * m : 0.f;
+                }
+            }
+        }
+        if (k0 < 0) continue;
+
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+#pragma unroll
+            for (int tp = 0; tp < NTAP; ++tp) {
+                const int ky = tp / 3, kx = tp % 3;
+                int toff;
+                if (KIND == TE_CONV_1X1) toff = 0;
+                else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? p.TIWP : 0) - (kx == 2 ? 1 : 0);
+                else toff = ky * p.TIWP + kx;
+                float a[MBW];
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) a[mb] = wl[(tp * KC + kk) * BM + aoff + mb * 32];
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const float bv = xl[kk * p.CS + boff[nb] + toff];
+                    const int j = IS_T2 ? nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0) : nb;
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb)
+                        acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bv, acc[mb][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: osc, bias, activation, store.  C/D layout of the 32x32 tile:
+    //      col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const size_t oplane = (size_t)p.Ho * p.Wo;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int c = wn * (NBW * 32) + nb * 32 + l31;
+        const int s = c >> (p.lgTW + p.lgTH);
+        const int ci = ci0 + ((c >> p.lgTW) & (p.TH - 1)), cj = cj0 + (c & (p.TW - 1));
+        const int b = b0 + s;
+        const bool cell_ok = b < p.B && ci < p.ri0 + p.rh && cj < p.rj0 + p.rw;
+        const int bc = b < p.B ? b : p.B - 1;
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+            const int mbase = m0 + wm * (MBW * 32) + mb * 32 + 4 * half;
+            // batch the per-row scale / bias loads (clamped, unconditional) ahead of the stores
+            float sc[16], bi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = 1.f; bi[r] = 0.f; }
+            if (p.osc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    sc[r] = p.osc[(size_t)bc * p.M + (m < p.M ? m : p.M - 1)];
+                }
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    bi[r] = p.bias[m < p.M ? m : p.M - 1];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = cell_ok && m < p.M;
+                float* obase = p.out + ((size_t)bc * p.M + (m < p.M ? m : 0)) * oplane;
+                if (!IS_T2) {
+                    float v = acc[mb][nb][r] * sc[r] + bi[r];
+                    if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                    if (ok) obase[(size_t)ci * p.Wo + cj] = v;
+                } else {
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const int Y = 2 * ci + (ph >> 1), X = 2 * cj + (ph & 1);
+                        float v = acc[mb][nb * 4 + ph][r] * sc[r] + bi[r];
+                        if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                        if (ok && Y < p.Ho && X < p.Wo) obase[(size_t)Y * p.Wo + X] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weights_kernel(float* __restrict__ wp, const float* __restrict__ w, float wscale,
+                                                           int kind, int Co, int Ci, int ntap, int K, int M, int Kp, int Mp) {
+    const int64_t total = (int64_t)ntap * Kp * Mp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int m = (int)(e % Mp);
+        const int k = (int)((e / Mp) % Kp);
+        const int tap = (int)(e / ((int64_t)Mp * Kp));
+        float v = 0.f;
+        if (m < M && k < K) {
+            if (kind == TE_PACK_FWD) v = w[((size_t)m * Ci + k) * ntap + tap];
+            else if (kind == TE_PACK_DGRAD) v = w[((size_t)k * Ci + m) * ntap + (ntap - 1 - tap)];
+            else v = w[((size_t)k * Ci + m) * ntap + tap];
+        }
+        wp[e] = v * wscale;
+    }
+}
+
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline int pow2ceil(int v) { return 1 << ilog2(v); }
+inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct PackDims { int K, M, Kp, Mp, ntap; };
+inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
+    PackDims d;
+    d.ntap = ksize * ksize;
+    d.M = (kind_pack == TE_PACK_FWD) ? Co : Ci;
+    d.K = (kind_pack == TE_PACK_FWD) ? Ci : Co;
+    d.Kp = roundup(d.K, KC);
+    d.Mp = roundup(d.M, BM);
+    return d;
+}
+
+template <int KIND, int NBW, bool HAS_ISC>
+int launch_region_t(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
+    if (rh <= 0 || rw <= 0) return 0;
+    constexpr int NTILE = 2 * NBW * 32;
+    a.ri0 = ri0; a.rj0 = rj0; a.rh = rh; a.rw = rw;
+    a.TW = std::min(32, pow2ceil(rw));
+    a.TH = std::min(pow2ceil(rh), NTILE / a.TW);
+    a.NS = NTILE / (a.TW * a.TH);
+    a.lgTW = ilog2(a.TW); a.lgTH = ilog2(a.TH);
+    a.tiles_x = (rw + a.TW - 1) / a.TW;
+    a.tiles_y = (rh + a.TH - 1) / a.TH;
+    if (KIND == TE_CONV_3X3) { a.TIH = a.TH + 2; a.TIW = a.TW + 2; }
+    else if (KIND == TE_CONV_S2) { a.TIH = 2 * a.TH + 1; a.TIW = 2 * a.TW + 1; }
+    else if (KIND == TE_CONV_T2) { a.TIH = a.TH + 1; a.TIW = a.TW + 1; }
+    else { a.TIH = a.TH; a.TIW = a.TW; }
+    a.TIWP = a.TIW;
+    a.SS = a.TIH * a.TIWP;
+    a.CS = a.NS * a.SS;
+    constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
+    if (a.NS * a.TIH * a.TIW > NSP * NTHREADS)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", a.NS, a.TIH, a.TIW);
+    const size_t lds = sizeof(float) * ((size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * a.CS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    const int sgroups = (a.B + a.NS - 1) / a.NS;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * sgroups), (unsigned)(a.Mp / BM));
+    conv_mfma_kernel<KIND, NBW, HAS_ISC><<<grid, NTHREADS, lds, s>>>(a);
+    return 0;
+}
+
+template <int KIND, int NBW>
+int launch_region(const ConvArgs& a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
+    return a.isc ? launch_region_t<KIND, NBW, true>(a, ri0, rj0, rh, rw, s)
+                 : launch_region_t<KIND, NBW, false>(a, ri0, rj0, rh, rw, s);
+}
+
+}  // namespace
+
+extern "C" int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize) {
+    const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
+    return (int64_t)d.ntap * d.Kp * d.Mp;
+}
+
+extern "C" int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci, int ksize,
+                                        te_stream_t stream_) {
+    TE_REQUIRE(wp && w, TE_ERR_NULL, "te_conv_pack_weights_f32: NULL pointer");
+    TE_REQUIRE(Co > 0 && Ci > 0 && (ksize == 1 || ksize == 3), TE_ERR_SHAPE, "te_conv_pack_weights_f32: bad dims");
+    TE_REQUIRE(kind_pack >= 0 && kind_pack <= 2, TE_ERR_UNSUPPORTED, "te_conv_pack_weights_f32: bad kind");
+    const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
+    const int64_t total = (int64_t)d.ntap * d.Kp * d.Mp;
+    const int grid = (int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8);
+    pack_weights_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(wp, w, wscale, kind_pack, Co, Ci, d.ntap, d.K, d.M, d.Kp, d.Mp);
+    return te::launch_status("te_conv_pack_weights_f32");
+}
+
+extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
+                           const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
+    TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
+    TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
+    TE_REQUIRE(act == 0 || act == 3, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0 or 3");
+    hipStream_t s = (hipStream_t)stream_;
+    ConvArgs a{};
+    a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
+    a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KC); a.Mp = roundup(M, BM); a.H = H; a.W = W;
+    int rc = 0;
+    switch (kind) {
+        case TE_CONV_3X3:
+            a.Hi = a.Ho = H; a.Wi = a.Wo = W;
+            rc = launch_region<TE_CONV_3X3, 2>(a, 0, 0, H, W, s);
+            break;
+        case TE_CONV_1X1:
+            a.Hi = a.Ho = H; a.Wi = a.Wo = W;
+            rc = launch_region<TE_CONV_1X1, 2>(a, 0, 0, H, W, s);
+            break;
+        case TE_CONV_S2:
+            a.Hi = 2 * H + 1; a.Wi = 2 * W + 1; a.Ho = H; a.Wo = W;
+            rc = launch_region<TE_CONV_S2, 2>(a, 0, 0, H, W, s);
+            break;
+        case TE_CONV_T2:
+            a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
+            if (W + 1 <= 16 || H + 1 <= 16) {
+                rc = launch_region<TE_CONV_T2, 1>(a, 0, 0, H + 1, W + 1, s);       // small images: one padded launch
+            } else {
+                rc = launch_region<TE_CONV_T2, 1>(a, 0, 0, H, W, s);               // main body
+                if (!rc) rc = launch_region<TE_CONV_T2, 1>(a, 0, W, H + 1, 1, s);   // last output column (+ corner)
+                if (!rc) rc = launch_region<TE_CONV_T2, 1>(a, H, 0, 1, W, s);       // last output row
+            }
+            break;
+        default:
+            return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
+    }
+    if (rc) return rc;
+    return te::launch_status("te_conv_f32");
+}

@@ -1,0 +1,177 @@
+// K2: upfirdn2d (zero-insert upsample -> pad/crop -> 2-D FIR, true convolution -> decimate) for gfx950.
+//
+// Arithmetic contract (reference upfirdn2d_kernel.cu:85-129, upfirdn2d.py:101-102), per axis:
+//   mid = o*down + up - 1 - pad0 ; i0 = floor(mid / up) ; j0 = (i0+1)*up - mid - 1
+//   out[o] = sum_{t>=0, j0+t*up < k}  in[i0 + t] * kflip[j0 + t*up],  kflip[j] = k[k-1-j], in[] = 0 outside.
+//
+// Two implementations:
+//   * fir_tile_kernel<UP,DOWN,KH,KW>: minor == 1; a 16x64 output tile per 256-thread block, input tile
+//     (with halo) staged once in LDS, flipped taps in registers, 4 consecutive outputs per lane, optional
+//     fused bias + leaky-ReLU epilogue.  Instantiated for the configurations the model uses.
+//   * fir_direct_kernel: any (up, down, kernel, minor); one output per thread straight from global/L2.
+#include "te_common.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ int fdiv(int a, int b) {  // floor division, b > 0
+    int q = a / b;
+    return (q * b > a) ? q - 1 : q;
+}
+
+struct FirParams {
+    int in_h, in_w, out_h, out_w;
+    int pad_x0, pad_y0;
+    int kh, kw, up_x, up_y, down_x, down_y, minor;
+    int64_t major;
+    int size_b, act;
+    float alpha, scale;
+};
+
+__device__ __forceinline__ float epilogue(float v, const float* b, int ch, const FirParams& p) {
+    if (b) v += b[ch];
+    if (p.act == 3) v = v > 0.f ? v : v * p.alpha;
+    return v * p.scale;
+}
+
+constexpr int TOH = 16, TOW = 64;
+
+template <int UP, int DOWN, int KH, int KW>
+__global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                       const float* __restrict__ k, const float* __restrict__ b,
+                                                       const FirParams p) {
+    constexpr int TIH = ((TOH - 1) * DOWN + KH - 1) / UP + 1;
+    constexpr int TIW = ((TOW - 1) * DOWN + KW - 1) / UP + 1;
+    constexpr int TIWP = (TIW + 3) & ~3;  // row stride, multiple of 4 floats
+    constexpr int NTY = (KH + UP - 1) / UP, NTX = (KW + UP - 1) / UP;
+    static_assert(KH % UP == 0 && KW % UP == 0, "taps must split evenly over the upsampling phases");
+    __shared__ float sx[TIH * TIWP];
+    __shared__ float sk[KH * KW];
+
+    // flipped taps: registers for UP == 1 (compile-time indices), LDS when the phase selects them at run time
+    float kf[KH][KW];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int c = 0; c < KW; ++c) kf[a][c] = k[(KH - 1 - a) * KW + (KW - 1 - c)];
+    if (threadIdx.x < KH * KW) sk[threadIdx.x] = k[KH * KW - 1 - threadIdx.x];
+
+    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH;
+    const int mid_x0 = ox0 * DOWN + UP - 1 - p.pad_x0, mid_y0 = oy0 * DOWN + UP - 1 - p.pad_y0;
+    const int ix0 = fdiv(mid_x0, UP), iy0 = fdiv(mid_y0, UP);
+    const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
+
+    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+        const float* xin = x + (size_t)mj * p.in_h * p.in_w;
+        __syncthreads();
+        for (int e = threadIdx.x; e < TIH * TIW; e += 256) {
+            const int ry = e / TIW, rx = e - ry * TIW;
+            const int gy = iy0 + ry, gx = ix0 + rx;
+            float v = 0.f;
+            if (gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v = xin[(size_t)gy * p.in_w + gx];
+            sx[ry * TIWP + rx] = v;
+        }
+        __syncthreads();
+        const int oy = oy0 + ty;
+        if (oy < p.out_h) {
+            const int mid_y = mid_y0 + ty * DOWN;
+            const int iy = fdiv(mid_y, UP);
+            const int jy = (iy + 1) * UP - mid_y - 1;
+            const int ry = iy - iy0;
+            float res[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mid_x = mid_x0 + (tx + q) * DOWN;
+                const int ix = fdiv(mid_x, UP);
+                const int jx = (ix + 1) * UP - mid_x - 1;
+                const int rx = ix - ix0;
+                float acc = 0.f;
+#pragma unroll
+                for (int a = 0; a < NTY; ++a)
+#pragma unroll
+                    for (int c = 0; c < NTX; ++c) {
+                        float w;
+                        if constexpr (UP == 1) w = kf[a][c];
+                        else w = sk[(jy + a * UP) * KW + jx + c * UP];   // phase-selected tap (LDS broadcast)
+                        acc += sx[(ry + a) * TIWP + rx + c] * w;
+                    }
+                res[q] = acc;
+            }
+            float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
+            const int ch = b ? (int)(mj % p.size_b) : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ox = ox0 + tx + q;
+                if (ox < p.out_w) orow[ox] = epilogue(res[q], b, ch, p);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fir_direct_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                         const float* __restrict__ k, const float* __restrict__ b,
+                                                         const FirParams p) {
+    const int64_t total = p.major * p.out_h * p.out_w * p.minor;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int64_t r = e;
+        const int mn = (int)(r % p.minor); r /= p.minor;
+        const int ox = (int)(r % p.out_w); r /= p.out_w;
+        const int oy = (int)(r % p.out_h);
+        const int64_t mj = r / p.out_h;
+        const int mid_x = ox * p.down_x + p.up_x - 1 - p.pad_x0, mid_y = oy * p.down_y + p.up_y - 1 - p.pad_y0;
+        const int ix0 = fdiv(mid_x, p.up_x), iy0 = fdiv(mid_y, p.up_y);
+        const int jx0 = (ix0 + 1) * p.up_x - mid_x - 1, jy0 = (iy0 + 1) * p.up_y - mid_y - 1;
+        float acc = 0.f;
+        for (int jy = jy0, iy = iy0; jy < p.kh; jy += p.up_y, ++iy) {
+            if (iy < 0 || iy >= p.in_h) continue;
+            for (int jx = jx0, ix = ix0; jx < p.kw; jx += p.up_x, ++ix) {
+                if (ix < 0 || ix >= p.in_w) continue;
+                acc += x[(((size_t)mj * p.in_h + iy) * p.in_w + ix) * p.minor + mn] *
+                       k[(p.kh - 1 - jy) * p.kw + (p.kw - 1 - jx)];
+            }
+        }
+        out[e] = epilogue(acc, b, b ? (int)(mj % p.size_b) : 0, p);
+    }
+}
+
+template <int UP, int DOWN, int KH, int KW>
+void launch_tile(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s) {
+    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH),
+              (unsigned)std::min<int64_t>(p.major, 32768));
+    fir_tile_kernel<UP, DOWN, KH, KW><<<grid, 256, 0, s>>>(out, x, k, b, p);
+}
+
+}  // namespace
+
+extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, int in_h, int in_w, int minor,
+                                int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                int pad_y0, int pad_y1, const float* b, int64_t size_b, int act, float alpha,
+                                float scale, te_stream_t stream_) {
+    TE_REQUIRE(out && x && k, TE_ERR_NULL, "te_upfirdn2d_f32: out/x/k is NULL");
+    TE_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0 && kh > 0 && kw > 0, TE_ERR_SHAPE,
+               "te_upfirdn2d_f32: bad dims");
+    TE_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, TE_ERR_SHAPE, "te_upfirdn2d_f32: up/down must be > 0");
+    TE_REQUIRE(act == 0 || act == 3, TE_ERR_UNSUPPORTED, "te_upfirdn2d_f32: act must be 0 or 3");
+    TE_REQUIRE(!(b || act) || minor == 1, TE_ERR_UNSUPPORTED, "te_upfirdn2d_f32: fused epilogue needs minor == 1");
+    TE_REQUIRE(!b || size_b > 0, TE_ERR_SHAPE, "te_upfirdn2d_f32: bias given but size_b <= 0");
+    FirParams p;
+    p.in_h = in_h; p.in_w = in_w;
+    p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+    p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+    TE_REQUIRE(p.out_h > 0 && p.out_w > 0, TE_ERR_SHAPE, "te_upfirdn2d_f32: empty output (%d x %d)", p.out_h, p.out_w);
+    p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+    p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.minor = minor; p.major = major;
+    p.size_b = (int)size_b; p.act = act; p.alpha = alpha; p.scale = (b || act) ? scale : 1.f;
+    if (major == 0) return 0;
+    hipStream_t s = (hipStream_t)stream_;
+    const bool sq = (up_x == up_y) && (down_x == down_y) && minor == 1;
+    if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1) launch_tile<1, 1, 4, 4>(out, x, k, b, p, s);
+    else if (sq && kh == 4 && kw == 4 && up_x == 2 && down_x == 1) launch_tile<2, 1, 4, 4>(out, x, k, b, p, s);
+    else if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 2) launch_tile<1, 2, 4, 4>(out, x, k, b, p, s);
+    else {
+        const int64_t total = major * p.out_h * p.out_w * minor;
+        const int grid = (int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 16);
+        fir_direct_kernel<<<grid, 256, 0, s>>>(out, x, k, b, p);
+    }
+    return te::launch_status("te_upfirdn2d_f32");
+}
