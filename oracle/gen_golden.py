@@ -274,11 +274,27 @@ def gen_discriminator(M):
         r1_grad_names=np.array(names))
 
 
+def gen_schema(M):
+    """state_dict key / shape schema of the reference models (checkpoint compatibility)."""
+    d = {}
+    for tag, m in (('g64', M.Generator(64, 512, 512, 10, n_trans=8, pixel_norm_op_dim=1)),
+                   ('g256', M.Generator(256, 512, 512, 14, n_trans=8, pixel_norm_op_dim=1)),
+                   ('g1024', M.Generator(1024, 512, 512, 18, n_trans=8, pixel_norm_op_dim=1)),
+                   ('d64', M.Discriminator(64)), ('d256', M.Discriminator(256))):
+        sd = m.state_dict()
+        d[tag + '.keys'] = np.array(list(sd.keys()))
+        d[tag + '.shapes'] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+        d[tag + '.nparams'] = np.array(sum(p.numel() for p in m.parameters()))
+        d[tag + '.param_names'] = np.array([n for n, _ in m.named_parameters()])
+    npz('state_dict_schema', **d)
+
+
 def main():
     assert ref_import.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     M = ref_import.import_reference()
+    gen_schema(M)
     gen_ops(M)
     gen_generator(M)
     gen_discriminator(M)

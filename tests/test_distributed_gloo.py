@@ -1,0 +1,68 @@
+"""world_size-2 data-parallel glue on CPU (gloo): the gradient exchange step and the scalar collectives
+of the train step (reference utils/distributed.py; train_spatial_query.py:249,296,494-509)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from transeditor_amd.utils import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        assert D.get_rank() == rank and D.get_world_size() == world
+        D.synchronize()
+        torch.manual_seed(rank)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        unused = torch.nn.Parameter(torch.zeros(3))           # like the generator's 13 unused noise.weight params
+        net.register_parameter('unused', unused)
+        D.broadcast_module(net)
+        w0 = [p.detach().clone() for p in net.parameters()]
+        x = torch.randn(5, 8)
+        net(x).pow(2).sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        sync = D.GradSync(net, bucket_bytes=256)               # tiny buckets: exercise several of them
+        assert len(sync.buckets) > 1
+        sync.all_reduce()
+        red = D.reduce_sum(torch.tensor(float(rank + 1)))
+        losses = D.reduce_loss_dict({'g': torch.tensor(1.0 + rank), 'd': torch.tensor(10.0 * (rank + 1))})
+        q.put((rank, [w.numpy() for w in w0], [None if g is None else g.numpy() for g in local],
+               [p.grad.numpy() for p in net.parameters()], float(red), {k: float(v) for k, v in losses.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_sync_and_scalar_collectives_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w_a, loc_a, syn_a, red_a, loss_a), (_, w_b, loc_b, syn_b, red_b, loss_b) = res
+    for a, b in zip(w_a, w_b):                                 # broadcast from rank 0
+        assert (a == b).all()
+    for la, lb, sa, sb in zip(loc_a, loc_b, syn_a, syn_b):     # mean of the local gradients, on both ranks
+        if la is None:
+            assert (sa == 0).all() and (sb == 0).all()
+            continue
+        mean = (la + lb) / 2
+        assert abs(sa - mean).max() < 1e-6 and abs(sb - mean).max() < 1e-6
+    assert red_a == red_b == 3.0
+    assert loss_a == {'d': 15.0, 'g': 1.5}                     # rank 0 holds the mean, sorted keys

@@ -1,0 +1,156 @@
+"""End-to-end parity of the MI355X generator (drop-in Generator class on the HIP kernels) against the golden
+vectors produced by the reference and against the CPU oracle.  Tolerance: north star = 1e-3 relative fp32."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import te_oracle as O
+from test_oracle_golden import generator_state
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-3
+
+
+def build(size, seed):
+    g, sd = generator_state(size, seed)
+    g.load_state_dict(sd)
+    return g.to(DEV), sd
+
+
+@pytest.fixture(scope='module')
+def g64():
+    return build(64, 0)
+
+
+def test_generator64_config1_forward_backward(golden, g64):
+    """BASELINE config 1 shapes on the GPU path: image, latent, mapped codes, input and parameter gradients."""
+    G, _ = g64
+    gold = golden('generator64_b4')
+    z, p = (t.to(DEV).requires_grad_(True) for t in synth.latents(4, 1000))
+    img, latent, _ = G(z, p, return_latents=True)
+    assert rel_err(img, gold['image']) < TOL
+    assert rel_err(latent, gold['latent']) < TOL
+    st, sp = G(z, p, return_mapped_codes=True)
+    assert rel_err(st, gold['stylecode']) < 1e-4 and rel_err(sp, gold['spatialcode']) < 1e-4
+    wimg = synth.normal(tuple(img.shape), 'wimg.64').to(DEV)
+    names = [n for n, _ in G.named_parameters()]
+    grads = torch.autograd.grad((img * wimg).sum() / img.numel(), [z, p] + list(G.parameters()), allow_unused=True)
+    assert rel_err(grads[0], gold['gz']) < TOL and rel_err(grads[1], gold['gp']) < TOL
+    assert [str(n) for n in gold['grad_names']] == names
+    unused = []
+    for n, got, want in zip(names, grads[2:], gold['grad_norms']):
+        if got is None:
+            unused.append(n)
+            assert want == 0.0, n
+        elif want > 1e-10:
+            assert abs(float(got.double().norm()) - want) / want < TOL, n
+    assert all(n.endswith('noise.weight') for n in unused) and len(unused) == 9     # 64 px: 9 StyledConvs
+    for key, pname in (('g_adjust_w', 'adjust_style.weight'), ('g_rgb1_bias', 'to_rgb1.bias'),
+                       ('g_conv1_act_bias', 'conv1.activate.bias'), ('g_last_act_bias', 'convs.7.activate.bias')):
+        assert rel_err(grads[2 + names.index(pname)], gold[key]) < TOL, key
+
+
+def test_generator64_per_layer_stats(golden, g64):
+    G, _ = g64
+    gold = golden('generator64_b4')
+    acts = {}
+    hooks = []
+    for name in ['conv1', 'to_rgb1'] + [f'convs.{i}' for i in range(8)] + [f'to_rgbs.{i}' for i in range(4)]:
+        mod = dict(G.named_modules())[name]
+        hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: acts.__setitem__(name, o.detach())))
+    z, p = (t.to(DEV) for t in synth.latents(4, 1000))
+    with torch.no_grad():
+        G(z, p)
+    for h in hooks:
+        h.remove()
+    for name, t in acts.items():
+        want = gold[f'layer.{name}.stats']
+        got = torch.stack([t.mean(), t.abs().max()]).cpu()
+        assert abs(float(got[1]) - float(want[1])) / float(want[1]) < TOL, name
+        assert abs(float(got[0]) - float(want[0])) < TOL * float(want[1]), name
+
+
+def test_generator_forward_flag_surface(golden, g64):
+    """kwarg combinations used by test_spatial_query.py (:90-103,128-137,168-177,205-214)."""
+    G, _ = g64
+    gold = golden('generator64_flags')
+    zz, pp = (t.to(DEV) for t in synth.latents(2, 1001))
+    with torch.no_grad():
+        assert rel_err(G(zz, pp, return_only_mapped_p=True), gold['mapped_p']) < 1e-4
+        assert rel_err(G(zz, pp, return_only_mapped_z=True), gold['mapped_z']) < 1e-4
+        assert rel_err(G(zz, pp, return_only_style_latent=True), gold['style_latent']) < TOL
+        out = G(zz, pp)
+        assert isinstance(out, tuple) and len(out) == 3 and out[1] is None and out[2] is None
+        assert rel_err(out[0], gold['img_default']) < TOL
+        mz, mp = gold['mapped_z'].to(DEV), gold['mapped_p'].to(DEV)
+        assert rel_err(G(mz, mp, use_style_mapping=False, use_spatial_mapping=False)[0], gold['img_nomap']) < TOL
+        assert rel_err(G(gold['style_latent'].to(DEV), pp, input_is_latent=True)[0], gold['img_from_latent']) < TOL
+        i2, l2 = G(zz, pp, return_style=True)
+        assert rel_err(l2, gold['ret_style_latent']) < TOL
+        i3, sp3 = G(zz, pp, return_p_latent=True)
+        assert rel_err(sp3, gold['ret_p_latent']) < 1e-4
+        i4, l4, n4 = G(zz, pp, return_latents=True)
+        assert n4 is None and rel_err(l4, gold['ret_style_latent']) < TOL
+        with pytest.raises(UnboundLocalError):               # same failure mode as the reference
+            G(zz, pp, trans_interact=False)
+
+
+@pytest.mark.parametrize('size', [8, 32])
+def test_generator_small_sizes_and_path_length_double_backward(golden, size):
+    gold = golden(f'generator{size}_b2')
+    G, _ = build(size, size)
+    z, p = (t.to(DEV) for t in synth.latents(2, 2000 + size))
+    img, latent, _ = G(z, p, return_latents=True)
+    assert rel_err(img, gold['image']) < TOL and rel_err(latent, gold['latent']) < TOL
+    if size == 32:
+        noise = (synth.normal(tuple(img.shape), 'pl.noise') / math.sqrt(size * size)).to(DEV)
+        pen, _, lengths = O.g_path_regularize(img, latent, 0.0, noise)          # plain autograd formula (T1)
+        assert rel_err(lengths, gold['path_lengths']) < TOL
+        assert abs(float(pen) - float(gold['path_penalty'])) / float(gold['path_penalty']) < 5 * TOL
+        names = [n for n, _ in G.named_parameters()]
+        gs = torch.autograd.grad(pen, list(G.parameters()), allow_unused=True)
+        bad = []
+        for n, got, want in zip(names, gs, gold['pl_grad_norms']):
+            if want > 1e-7:
+                e = abs(float(got.double().norm()) - want) / want
+                if e > 5 * TOL:
+                    bad.append((n, e))
+        assert not bad, bad[:8]
+
+
+def test_discriminator_golden(golden):
+    from transeditor_amd.model_spatial_query import Discriminator
+    gold = golden('discriminator64_b4')
+    D = Discriminator(64)
+    sd = D.state_dict()
+    synth.fill_state_dict(sd, 5)
+    D.load_state_dict(sd)
+    D = D.to(DEV)
+    img = synth.normal((4, 3, 64, 64), 'd.img').clamp(-1, 1).to(DEV).requires_grad_(True)
+    fake = synth.normal((4, 3, 64, 64), 'd.fake').clamp(-1, 1).to(DEV)
+    pred, fpred = D(img), D(fake)
+    assert rel_err(pred, gold['pred']) < TOL and rel_err(fpred, gold['fake_pred']) < TOL
+    r1 = O.d_r1_loss(pred, img)
+    assert abs(float(r1) - float(gold['r1'])) / float(gold['r1']) < TOL
+    gs = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * pred[0], list(D.parameters()), allow_unused=True)
+    for n, got, want in zip([str(k) for k in gold['r1_grad_names']], gs, gold['r1_grad_norms']):
+        if want > 1e-7:
+            assert abs(float(got.double().norm()) - want) / want < 5 * TOL, n
+
+
+def test_generator256_vs_oracle_and_batch_independence():
+    """FFHQ-256 architecture (BASELINE config 2 shapes): batch-2 against the CPU oracle, then the full batch 16
+    through a size-independent property: sample i of a batch-16 run equals the same latent run in a batch of 2."""
+    G, sd = build(256, 7)
+    z, p = synth.latents(16, 4242)
+    with torch.no_grad():
+        img16 = G(z.to(DEV), p.to(DEV))[0]
+        assert tuple(img16.shape) == (16, 3, 256, 256) and torch.isfinite(img16).all()
+        img2 = G(z[5:7].to(DEV), p[5:7].to(DEV))[0]
+        assert rel_err(img16[5:7], img2) < 1e-5
+        ref, _, _ = O.generator_forward({k: v for k, v in sd.items()}, z[5:7], p[5:7], 256)
+    assert rel_err(img2, ref) < TOL

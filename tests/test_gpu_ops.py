@@ -1,0 +1,262 @@
+"""Parity of every HIP op (called through the C ABI) against the CPU oracle and the committed golden
+vectors.  Floating point: the north star allows 1e-3 relative (fp32); the per-op bars here are tighter."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import te_oracle as O
+from oracle.gen_golden import UPFIRDN_CASES
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+OP_TOL = 2e-5      # single op, fp32 round-off class
+SUM_TOL = 2e-4     # long reductions (weight gradients over all pixels)
+
+
+def ops():
+    from transeditor_amd import op
+    return op
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize('name', ['2d', '4d', '3d'])
+def test_fused_leaky_relu_golden(golden, name):
+    g = golden('fused_leaky_relu')
+    x = g[f'{name}.x'].to(DEV).requires_grad_(True)
+    b = g[f'{name}.b'].to(DEV).requires_grad_(True)
+    wy = g[f'{name}.wy'].to(DEV).requires_grad_(True)
+    y = ops().fused_leaky_relu(x, b)
+    assert rel_err(y, g[f'{name}.y']) < OP_TOL
+    gx, gb = torch.autograd.grad((y * wy).sum(), (x, b), create_graph=True)
+    assert rel_err(gx, g[f'{name}.gx']) < OP_TOL and rel_err(gb, g[f'{name}.gb']) < OP_TOL
+    ggy, = torch.autograd.grad((gx * g[f'{name}.u'].to(DEV)).sum() + (gb * g[f'{name}.ub'].to(DEV)).sum(), wy)
+    assert rel_err(ggy, g[f'{name}.ggy']) < OP_TOL
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 64, 64), (3, 7, 33, 5), (16, 512), (1, 3, 1024, 1024), (2, 5, 3)])
+def test_fused_leaky_relu_vs_oracle(shape):
+    x = synth.normal(shape, 'k1.x').requires_grad_(True)
+    b = synth.normal((shape[1],), 'k1.b').requires_grad_(True)
+    w = synth.normal(shape, 'k1.w')
+    y_ref = O.fused_leaky_relu(x, b)
+    gx_ref, gb_ref = torch.autograd.grad((y_ref * w).sum(), (x, b))
+    xd, bd = x.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = ops().fused_leaky_relu(xd, bd)
+    assert torch.equal(y.cpu(), y_ref.detach())              # elementwise, no reassociation: bit-exact
+    gx, gb = torch.autograd.grad((y * w.to(DEV)).sum(), (xd, bd))
+    assert rel_err(gx, gx_ref) < 1e-6
+    assert rel_err(gb, gb_ref) < SUM_TOL
+
+
+def test_fused_leaky_relu_module_and_no_bias():
+    m = ops().FusedLeakyReLU(6).to(DEV)
+    assert tuple(m.bias.shape) == (6,) and float(m.bias.abs().sum()) == 0
+    x = synth.normal((2, 6, 4, 4), 'k1.m')
+    assert rel_err(m(x.to(DEV)), O.fused_leaky_relu(x, torch.zeros(6))) < OP_TOL
+    m2 = ops().FusedLeakyReLU(6, bias=False).to(DEV)
+    assert rel_err(m2(x.to(DEV)), O.fused_leaky_relu(x, None)) < OP_TOL
+
+
+# ------------------------------------------------------------------------------------------------ K2
+@pytest.mark.parametrize('case', UPFIRDN_CASES, ids=[c[0] for c in UPFIRDN_CASES])
+def test_upfirdn2d_golden(golden, case):
+    g = golden('upfirdn2d')
+    name, _, _, _, up, down, pad = case
+    x = g[f'{name}.x'].to(DEV).requires_grad_(True)
+    y = ops().upfirdn2d(x, g[f'{name}.k'].to(DEV), up, down, pad)
+    assert tuple(y.shape) == tuple(g[f'{name}.y'].shape)     # integer index path: exact
+    assert rel_err(y, g[f'{name}.y']) < OP_TOL
+    gx, = torch.autograd.grad((y * g[f'{name}.wy'].to(DEV)).sum(), x)
+    assert rel_err(gx, g[f'{name}.gx']) < OP_TOL
+
+
+@pytest.mark.parametrize('shape,gain,up,down,pad', [
+    ((2, 3, 65, 65), 4.0, 1, 1, (1, 1)), ((2, 5, 129, 129), 4.0, 1, 1, (1, 1)), ((2, 3, 64, 64), 1.0, 1, 1, (2, 2)),
+    ((2, 3, 32, 32), 4.0, 2, 1, (2, 1)), ((1, 3, 128, 128), 4.0, 2, 1, (2, 1)), ((2, 3, 66, 66), 4.0, 1, 2, (1, 1)),
+    ((1, 2, 257, 257), 4.0, 1, 1, (1, 1)), ((2, 3, 17, 40), 1.0, 1, 2, (2, 2))])
+def test_upfirdn2d_tiled_vs_oracle(shape, gain, up, down, pad):
+    k = O.fir_kernel((1, 3, 3, 1), gain)
+    x = synth.normal(shape, 'k2.x').requires_grad_(True)
+    y_ref = O.upfirdn2d(x, k, up, down, pad)
+    w = synth.normal(tuple(y_ref.shape), 'k2.w')
+    gx_ref, = torch.autograd.grad((y_ref * w).sum(), x)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = ops().upfirdn2d(xd, k.to(DEV), up, down, pad)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert rel_err(y, y_ref) < OP_TOL
+    gx, = torch.autograd.grad((y * w.to(DEV)).sum(), xd, create_graph=True)
+    assert rel_err(gx, gx_ref) < OP_TOL
+    # second order: the adjoint is linear in its input, so d/dw of <gx, v> is the forward op applied to v
+    v = synth.normal(shape, 'k2.v')
+    wd = w.to(DEV).requires_grad_(True)
+    gx2, = torch.autograd.grad((ops().upfirdn2d(xd, k.to(DEV), up, down, pad) * wd).sum(), xd, create_graph=True)
+    gg, = torch.autograd.grad((gx2 * v.to(DEV)).sum(), wd)
+    assert rel_err(gg, O.upfirdn2d(v, k, up, down, pad)) < OP_TOL
+
+
+def test_blur_bias_act_fused_vs_oracle():
+    from transeditor_amd.op.fir_act import blur_bias_act
+    k = O.fir_kernel((1, 3, 3, 1), 4.0)
+    x = synth.normal((2, 6, 33, 33), 'fa.x').requires_grad_(True)
+    b = synth.normal((6,), 'fa.b').requires_grad_(True)
+    y_ref = O.fused_leaky_relu(O.upfirdn2d(x, k, pad=(1, 1)), b)
+    w = synth.normal(tuple(y_ref.shape), 'fa.w')
+    gx_ref, gb_ref = torch.autograd.grad((y_ref * w).sum(), (x, b))
+    xd, bd = x.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = blur_bias_act(xd, k.to(DEV), bd, (1, 1))
+    assert rel_err(y, y_ref) < OP_TOL
+    gx, gb = torch.autograd.grad((y * w.to(DEV)).sum(), (xd, bd))
+    assert rel_err(gx, gx_ref) < OP_TOL and rel_err(gb, gb_ref) < SUM_TOL
+
+
+# ------------------------------------------------------------------------------------------------ F1 kernels
+def _ref_conv(kind, x, w):
+    if kind == '3x3':
+        return F.conv2d(x, w, padding=1)
+    if kind == '1x1':
+        return F.conv2d(x, w)
+    if kind == 'up':
+        return F.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+    raise ValueError(kind)
+
+
+CONV_SHAPES = [  # B, K(ci), M(co), H, W
+    (3, 6, 5, 7, 7), (2, 40, 36, 12, 12), (2, 136, 130, 33, 20), (16, 128, 128, 4, 4), (4, 64, 256, 8, 8),
+    (2, 32, 64, 16, 16), (1, 24, 16, 64, 64), (2, 8, 8, 5, 3), (1, 16, 32, 40, 72)]
+
+
+@pytest.mark.parametrize('kind', ['3x3', '1x1', 'up'])
+@pytest.mark.parametrize('shape', CONV_SHAPES, ids=['x'.join(map(str, s)) for s in CONV_SHAPES])
+def test_conv_trio_vs_torch(kind, shape):
+    """forward, data gradient and weight gradient of the plain convolution (closed autograd trio)."""
+    from transeditor_amd.op.modconv import conv_core
+    B, K, M, H, W = shape
+    ks = 1 if kind == '1x1' else 3
+    x = synth.normal((B, K, H, W), f'cv.x.{kind}').requires_grad_(True)
+    w = (synth.normal((M, K, ks, ks), f'cv.w.{kind}') / math.sqrt(K * ks * ks)).requires_grad_(True)
+    y_ref = _ref_conv(kind, x, w)
+    gy = synth.normal(tuple(y_ref.shape), f'cv.g.{kind}')
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * gy).sum(), (x, w))
+    xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    y = conv_core(xd, wd, kind)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert rel_err(y, y_ref) < OP_TOL, 'forward'
+    gx, gw = torch.autograd.grad((y * gy.to(DEV)).sum(), (xd, wd))
+    assert rel_err(gx, gx_ref) < OP_TOL, 'dgrad'
+    assert rel_err(gw, gw_ref) < SUM_TOL, 'wgrad'
+
+
+@pytest.mark.parametrize('kind', ['3x3', 'up'])
+def test_conv_trio_second_order(kind):
+    """grad-of-grad through the trio (what the path-length regulariser needs) vs torch autograd on CPU."""
+    from transeditor_amd.op.modconv import conv_core
+    B, K, M, H, W = 2, 12, 10, 9, 9
+    x = synth.normal((B, K, H, W), 'cv2.x').requires_grad_(True)
+    w = (synth.normal((M, K, 3, 3), 'cv2.w') / 10).requires_grad_(True)
+    s = synth.normal((B, K), 'cv2.s').requires_grad_(True)
+
+    def f(conv, x, w, s, dev):
+        y = conv(x * s[:, :, None, None], w)
+        gy = synth.normal(tuple(y.shape), 'cv2.g').to(dev)
+        gs, = torch.autograd.grad((y * gy).sum(), s, create_graph=True)
+        return torch.autograd.grad(gs.pow(2).sum(), (x, w))
+
+    ref = f(lambda a, b: _ref_conv(kind, a, b), x, w, s, 'cpu')
+    xd, wd, sd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, s))
+    got = f(lambda a, b: conv_core(a, b, kind), xd, wd, sd, DEV)
+    assert rel_err(got[0], ref[0]) < SUM_TOL and rel_err(got[1], ref[1]) < SUM_TOL
+
+
+@pytest.mark.parametrize('kind', ['3x3', '1x1', 'up'])
+@pytest.mark.parametrize('shape', [(3, 6, 5, 7, 7), (2, 72, 136, 20, 33), (16, 128, 64, 4, 4)])
+@pytest.mark.parametrize('act', [False, True])
+def test_modconv_fused_kernel_vs_composite(kind, shape, act):
+    """fused kernel (scales + bias + lrelu in the prologue/epilogue, slab-based backward) vs the plain math."""
+    from transeditor_amd.op.modconv import modconv
+    B, K, M, H, W = shape
+    ks = 1 if kind == '1x1' else 3
+    x = synth.normal((B, K, H, W), 'mf.x').requires_grad_(True)
+    w = (synth.normal((M, K, ks, ks), 'mf.w') / math.sqrt(K * ks * ks)).requires_grad_(True)
+    isc = (1 + 0.5 * synth.normal((B, K), 'mf.i')).requires_grad_(True)
+    osc = (1 + 0.3 * synth.normal((B, M), 'mf.o')).abs().add(0.1).requires_grad_(True)
+    bias = synth.normal((M,), 'mf.b').requires_grad_(True)
+    if kind == 'up' and act:
+        pytest.skip('upsampling layers fuse the activation into the blur kernel instead')
+    y_ref = _ref_conv(kind, x * isc[:, :, None, None], w) * osc[:, :, None, None] + bias[None, :, None, None]
+    if act:
+        y_ref = F.leaky_relu(y_ref, 0.2) * math.sqrt(2)
+    gy = synth.normal(tuple(y_ref.shape), 'mf.g')
+    ref = torch.autograd.grad((y_ref * gy).sum(), (x, w, isc, osc, bias))
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, isc, osc, bias)]
+    y = modconv(d[0], d[1], d[2], d[3], d[4], act, kind)
+    assert rel_err(y, y_ref) < OP_TOL
+    got = torch.autograd.grad((y * gy.to(DEV)).sum(), d)
+    for name, a, b in zip(('gx', 'gw', 'gisc', 'gosc', 'gbias'), got, ref):
+        assert rel_err(a, b) < SUM_TOL, name
+
+
+# ------------------------------------------------------------------------------------------------ F1 module
+@pytest.mark.parametrize('name', ['plain3', 'up3', 'rgb1', 'plain3_wide', 'up3_wide'])
+def test_modulated_conv2d_module_golden(golden, name):
+    """ModulatedConv2d (drop-in class) vs the reference's outputs, first grads and the second-order term."""
+    from transeditor_amd.model_spatial_query import ModulatedConv2d
+    g = golden('modulated_conv2d')
+    demod, upsmp = bool(g[f'{name}.cfg'][0]), bool(g[f'{name}.cfg'][1])
+    w = g[f'{name}.weight']
+    m = ModulatedConv2d(w.shape[2], w.shape[1], w.shape[3], 16, demodulate=demod, upsample=upsmp).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.modulation.weight.copy_(g[f'{name}.mod_w'])
+        m.modulation.bias.copy_(g[f'{name}.mod_b'])
+    x = g[f'{name}.x'].to(DEV).requires_grad_(True)
+    s = g[f'{name}.s'].to(DEV).requires_grad_(True)
+    y = m(x, s)
+    assert rel_err(y, g[f'{name}.y']) < 1e-4
+    params = [m.weight, m.modulation.weight, m.modulation.bias]
+    gr = torch.autograd.grad((y * g[f'{name}.wy'].to(DEV)).sum(), [x, s] + params, create_graph=True)
+    for got, key in zip(gr, ('gx', 'gs', 'gw', 'gmw', 'gmb')):
+        assert rel_err(got, g[f'{name}.{key}']) < 2e-4, key
+    pl = gr[1].pow(2).sum()
+    assert abs(float(pl) - float(g[f'{name}.pl'])) / float(g[f'{name}.pl']) < 2e-4
+    g2 = torch.autograd.grad(pl, [x] + params, allow_unused=True)
+    for got, key in zip(g2, ('pl_gx', 'pl_gw', 'pl_gmw', 'pl_gmb')):
+        want = g[f'{name}.{key}']
+        if float(want.abs().max()) == 0:
+            assert got is None or float(got.abs().max()) < 1e-6
+        else:
+            assert rel_err(got, want) < 5e-4, key
+
+
+# ------------------------------------------------------------------------------------------------ F2
+def test_attention_core_vs_torch():
+    from transeditor_amd.op.attention import attention_core, _torch_expr
+    q, k, v = (synth.normal((5, 16, 128), f'at.{n}').requires_grad_(True) for n in 'qkv')
+    scale = 128 ** -0.5 * 3.0
+    o_ref, sim_ref = _torch_expr(q, k, v, scale, 4)
+    go, gs = synth.normal((5, 16, 128), 'at.go'), synth.normal((5, 4, 16, 16), 'at.gs')
+    ref = torch.autograd.grad([o_ref, sim_ref], (q, k, v), [go, gs])
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (q, k, v)]
+    o, sim = attention_core(d[0], d[1], d[2], scale, 4)
+    assert rel_err(o, o_ref) < OP_TOL and rel_err(sim, sim_ref) < OP_TOL
+    got = torch.autograd.grad([o, sim], d, [go.to(DEV), gs.to(DEV)])
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-4
+
+
+@pytest.mark.parametrize('name,cin', [('b0_528', 528), ('b_512', 512)])
+def test_attention_block_golden(golden, name, cin):
+    from test_oracle_golden import attention_block_params
+    from transeditor_amd.model_spatial_query import AttentionBlock
+    g = golden('attention_block')
+    m = AttentionBlock(cin, cin, 512, lr_mul=0.01).to(DEV)
+    m.load_state_dict(attention_block_params(name, cin, cin, DEV))
+    x = g[f'{name}.x'].to(DEV).requires_grad_(True)
+    p = g[f'{name}.p'].to(DEV).requires_grad_(True)
+    y, sim = m(x, p, return_similarity=True)
+    assert rel_err(y, g[f'{name}.y']) < 1e-4 and rel_err(sim, g[f'{name}.sim']) < 1e-4
+    gx, gp = torch.autograd.grad((y * g[f'{name}.wy'].to(DEV)).sum(), (x, p))
+    assert rel_err(gx, g[f'{name}.gx']) < 5e-4 and rel_err(gp, g[f'{name}.gp']) < 5e-4

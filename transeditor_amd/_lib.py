@@ -1,0 +1,193 @@
+"""ctypes binding of libte_hip.so (C ABI: include/te_hip.h) + thin tensor-level wrappers.
+
+The product path has NO fallback: if the shared object is missing, was built for another
+architecture, or a tensor is not a contiguous fp32 CUDA(HIP) tensor, these wrappers raise.
+PyTorch is used here only for device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
+_lib = None
+
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1 = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD, PACK_SWAP = 0, 1, 2
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    'te_version': (C.c_int, []),
+    'te_last_error_string': (C.c_char_p, []),
+    'te_arch': (C.c_char_p, []),
+    'te_bias_act_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_bwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _L, _L, _L, _P]),
+    'te_upfirdn2d_f32': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                   _P, _L, _I, _F, _F, _P]),
+    'te_conv_packed_numel': (C.c_int64, [_I, _I, _I, _I]),
+    'te_conv_pack_weights_f32': (C.c_int, [_P, _P, _F, _I, _I, _I, _I, _P]),
+    'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
+    'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises RuntimeError if the extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m transeditor_amd.build` '
+                               '(there is no CPU / PyTorch fallback for the TransEditor hot path)')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            if not hasattr(L, name):
+                raise RuntimeError(f'{LIB_PATH} does not export {name}')
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.te_arch() != b'gfx950':
+            raise RuntimeError('libte_hip.so was not built for gfx950')
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed (code {rc}): {lib().te_last_error_string().decode()}')
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f'te_hip: expected a contiguous fp32 tensor on the GPU, got {t.dtype} {t.device} '
+                           f'contiguous={t.is_contiguous()} (no CPU path exists)')
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------------------------- K1
+def bias_act(x, b, ref, act, grad, alpha, scale):
+    """out = act(x + b[channel]) * scale; channel = dim 1 (step_b = prod(shape[2:]))."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    _check(lib().te_bias_act_f32(_ptr(out), _ptr(x), _ptr(b), _ptr(ref), act, grad, alpha, scale,
+                                 x.numel(), step_b, b.numel() if b is not None else 1, _stream()), 'te_bias_act_f32')
+    return out
+
+
+def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
+    g = g.contiguous()
+    gi = torch.empty_like(g)
+    Cn = g.shape[1]
+    inner = 1
+    for d in g.shape[2:]:
+        inner *= d
+    gb = torch.zeros(Cn, device=g.device, dtype=g.dtype) if want_bias else None
+    _check(lib().te_bias_act_bwd_f32(_ptr(gi), _ptr(gb), _ptr(g), _ptr(ref), alpha, scale, g.shape[0], Cn, inner,
+                                     _stream()), 'te_bias_act_bwd_f32')
+    return gi, gb
+
+
+# --------------------------------------------------------------------------------------------- K2
+def upfirdn2d_raw(x, k, up, down, pad, bias=None, act=0, alpha=0.2, scale=1.0):
+    """x [B,C,H,W] -> [B,C,H',W'];  pad = (px0, px1, py0, py1);  up/down = (x, y)."""
+    x = x.contiguous()
+    B, Cn, H, W = x.shape
+    kh, kw = k.shape
+    px0, px1, py0, py1 = pad
+    oh = (H * up[1] + py0 + py1 - kh) // down[1] + 1
+    ow = (W * up[0] + px0 + px1 - kw) // down[0] + 1
+    if oh <= 0 or ow <= 0:
+        raise RuntimeError(f'upfirdn2d: empty output {oh}x{ow}')
+    out = torch.empty(B, Cn, oh, ow, device=x.device, dtype=x.dtype)
+    _check(lib().te_upfirdn2d_f32(_ptr(out), _ptr(x), _ptr(k.contiguous()), B * Cn, H, W, 1, kh, kw, up[0], up[1],
+                                  down[0], down[1], px0, px1, py0, py1, _ptr(bias),
+                                  bias.numel() if bias is not None else 1, act, alpha, scale, _stream()),
+           'te_upfirdn2d_f32')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- F1
+def conv_pack(w, kind_pack, wscale=1.0):
+    """w [Co,Ci,k,k] (model layout) -> packed Wp[tap][Kp][Mp]."""
+    w = w.contiguous()
+    Co, Ci, ks, _ = w.shape
+    n = lib().te_conv_packed_numel(kind_pack, Co, Ci, ks)
+    wp = torch.empty(n, device=w.device, dtype=w.dtype)
+    _check(lib().te_conv_pack_weights_f32(_ptr(wp), _ptr(w), wscale, kind_pack, Co, Ci, ks, _stream()),
+           'te_conv_pack_weights_f32')
+    return wp
+
+
+def conv_out_shape(kind, B, M, H, W):
+    if kind == CONV_T2:
+        return (B, M, 2 * H + 1, 2 * W + 1)
+    return (B, M, H, W)
+
+
+def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0):
+    """H, W = LOW-resolution size (see te_hip.h).  x [B,K,Hin,Win]."""
+    x = x.contiguous()
+    B, K = x.shape[0], x.shape[1]
+    out = torch.empty(conv_out_shape(kind, B, M, H, W), device=x.device, dtype=x.dtype)
+    _check(lib().te_conv_f32(_ptr(out), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias), act, kind, B, K, M, H, W,
+                             _stream()), 'te_conv_f32')
+    return out
+
+
+def wgrad_slabs(g, x, kind, H, W):
+    g, x = g.contiguous(), x.contiguous()
+    B, Co, Ci = g.shape[0], g.shape[1], x.shape[1]
+    taps = 1 if kind == CONV_1X1 else 9
+    S = lib().te_wgrad_slab_count(kind, B, Co, Ci, H, W)
+    if S <= 0:
+        raise RuntimeError(f'te_wgrad_slab_count failed ({S})')
+    slabs = torch.empty(B, S, Co, Ci, taps, device=g.device, dtype=g.dtype)
+    _check(lib().te_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), kind, B, Co, Ci, H, W, S, _stream()), 'te_wgrad_f32')
+    return slabs
+
+
+def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc=False, want_osc=False):
+    B, S, Co, Ci, taps = slabs.shape
+    dev, dt = slabs.device, slabs.dtype
+    gw = torch.empty(Co, Ci, taps, device=dev, dtype=dt) if want_w else None
+    gisc = torch.zeros(B, Ci, device=dev, dtype=dt) if want_isc else None
+    gosc = torch.zeros(B, Co, device=dev, dtype=dt) if want_osc else None
+    _check(lib().te_wgrad_reduce_f32(_ptr(gw), _ptr(gisc), _ptr(gosc), _ptr(slabs), _ptr(w.contiguous()), wscale,
+                                     _ptr(isc), _ptr(osc), B, S, Co, Ci, taps, _stream()), 'te_wgrad_reduce_f32')
+    return gw, gisc, gosc
+
+
+# --------------------------------------------------------------------------------------------- F2
+def attn_fwd(q, k, v, scale, groups):
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    N, M, Cn = q.shape
+    L = k.shape[1]
+    D = Cn // groups
+    o = torch.empty_like(q)
+    sim = torch.empty(N, groups, M, L, device=q.device, dtype=q.dtype)
+    _check(lib().te_attn_fwd_f32(_ptr(o), _ptr(sim), _ptr(q), _ptr(k), _ptr(v), scale, N, groups, M, L, D, _stream()),
+           'te_attn_fwd_f32')
+    return o, sim
+
+
+def attn_bwd(go, gsim, q, k, v, sim, scale, groups):
+    N, M, Cn = q.shape
+    L = k.shape[1]
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _check(lib().te_attn_bwd_f32(_ptr(gq), _ptr(gk), _ptr(gv), _ptr(go.contiguous()),
+                                 _ptr(gsim.contiguous()) if gsim is not None else None, _ptr(q), _ptr(k), _ptr(v),
+                                 _ptr(sim), scale, N, groups, M, L, Cn // groups, _stream()), 'te_attn_bwd_f32')
+    return gq, gk, gv

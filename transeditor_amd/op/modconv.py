@@ -1,0 +1,171 @@
+"""Modulated convolution on the te_conv / te_wgrad kernels (reference: ModulatedConv2d.forward,
+model_spatial_query.py:296-337).
+
+Formulation: with ONE shared weight w (already multiplied by the
+equalised-lr scale), style scale s[b,ci] and demodulation d[b,co],
+
+    y[b,co] = d[b,co] * conv(s[b,ci] * x[b,ci], w)[co]        (+ bias, leaky-ReLU fused)
+
+instead of the reference's B materialised weight copies + grouped convolution.
+
+Two layers of autograd functions:
+
+* ``conv_core`` / ``_ConvDgrad`` / ``_ConvWgrad`` — the plain bilinear convolution trio, closed
+  under differentiation (each one's backward is expressed with the other two), so anything
+  built on them is differentiable to any order (R1 / path-length regularisers).
+* ``modconv`` (``_ModConvFused``) — the fast path: scales, bias and activation fused into the
+  kernels, a hand-written backward that produces dx, dW, ds, dd from ONE data-gradient conv and
+  ONE correlation pass (per-sample slabs + te_wgrad_reduce).  When its backward is itself being
+  recorded (create_graph=True) it re-derives the gradients through the differentiable trio,
+  so double backward stays exact.
+
+kinds: '3x3' (stride 1, pad 1), '1x1', 'up' (3x3 transposed stride 2 -> (2H+1)x(2W+1); the blur
+that follows in the reference, model_spatial_query.py:318-321, is a separate upfirdn2d).
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from .fused_act import fused_leaky_relu
+
+_KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2}
+
+
+def _lowres_hw(kind, x_or_g_is_output, t):
+    """low-resolution (H, W) from a tensor that is the conv input (False) or output (True)."""
+    H, W = t.shape[2], t.shape[3]
+    if kind == 'up' and x_or_g_is_output:
+        return (H - 1) // 2, (W - 1) // 2
+    return H, W
+
+
+def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0):
+    H, W = x.shape[2], x.shape[3]
+    return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
+
+
+def _dgrad_raw(g, w, kind, isc=None, osc=None):
+    """data gradient: g is shaped like the conv OUTPUT; returns a tensor shaped like the conv input.
+    isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci])."""
+    H, W = _lowres_hw(kind, True, g)
+    if kind == 'up':
+        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP), _lib.CONV_S2, w.shape[1], H, W, isc, osc)
+    return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_DGRAD), _KIND[kind], w.shape[1], H, W, isc, osc)
+
+
+def _wgrad_raw(g, x, kind):
+    H, W = x.shape[2], x.shape[3]
+    slabs = _lib.wgrad_slabs(g, x, _KIND[kind], H, W)
+    return slabs
+
+
+class _ConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, kind):
+        ctx.save_for_backward(x, w)
+        ctx.kind = kind
+        return _fwd_raw(x, w, kind)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _ConvDgrad.apply(gy, w, ctx.kind) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2]) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class _ConvDgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w, kind):
+        ctx.save_for_backward(gy, w)
+        ctx.kind = kind
+        return _dgrad_raw(gy, w, kind)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(ggx, w, ctx.kind) if ctx.needs_input_grad[0] else None
+        g_w = _ConvWgrad.apply(gy, ggx, ctx.kind, w.shape[2]) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None
+
+
+class _ConvWgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, x, kind, ksize):
+        ctx.save_for_backward(gy, x)
+        ctx.kind = kind
+        slabs = _wgrad_raw(gy, x, kind)
+        Co, Ci = gy.shape[1], x.shape[1]
+        return slabs.sum(dim=(0, 1)).reshape(Co, Ci, ksize, ksize)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        g_gy = _ConvFwd.apply(x, ggw, ctx.kind) if ctx.needs_input_grad[0] else None
+        g_x = _ConvDgrad.apply(gy, ggw, ctx.kind) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x, None, None
+
+
+def conv_core(x, w, kind='3x3'):
+    """Plain convolution y = conv(x, w) (w [Co,Ci,k,k]), differentiable to any order."""
+    return _ConvFwd.apply(x, w, kind)
+
+
+def _composite(x, w, isc, osc, bias, act, kind):
+    """The same function as the fused kernel, built from any-order differentiable pieces."""
+    if isc is not None:
+        x = x * isc[:, :, None, None]
+    y = conv_core(x, w, kind)
+    if osc is not None:
+        y = y * osc[:, :, None, None]
+    if act:
+        return fused_leaky_relu(y, bias)
+    if bias is not None:
+        y = y + bias[None, :, None, None]
+    return y
+
+
+class _ModConvFused(Function):
+    @staticmethod
+    def forward(ctx, x, w, isc, osc, bias, act, kind):
+        out = _fwd_raw(x, w, kind, isc, osc, bias, 3 if act else 0)
+        ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
+        ctx.act, ctx.kind = act, kind
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, isc, osc, bias, out = ctx.saved_tensors
+        act, kind = ctx.act, ctx.kind
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # double backward requested: differentiate the composite built from the closed trio
+            with torch.enable_grad():
+                y = _composite(x, w, isc, osc, bias, act, kind)
+                ins = [t for t, n in zip((x, w, isc, osc, bias), need[:5]) if n and t is not None]
+                gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
+            return tuple(next(gs) if (n and t is not None) else None
+                         for t, n in zip((x, w, isc, osc, bias), need[:5])) + (None, None)
+        g = g.contiguous()
+        g_bias = None
+        if act:
+            g, g_bias = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=bias is not None)
+        elif bias is not None and need[4]:
+            g_bias = g.sum(dim=(0, 2, 3))
+        gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc) if need[0] else None
+        gw = gisc = gosc = None
+        if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
+            slabs = _wgrad_raw(g, x, kind)
+            gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), 1.0, isc, osc,
+                                               want_w=need[1], want_isc=need[2] and isc is not None,
+                                               want_osc=need[3] and osc is not None)
+            if gw is not None:
+                gw = gw.reshape(w.shape)
+        return gx, gw, gisc, gosc, g_bias, None, None
+
+
+def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3'):
+    """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, w) + bias[co] )  — fused kernels."""
+    isc = isc.contiguous() if isc is not None else None
+    osc = osc.contiguous() if osc is not None else None
+    return _ModConvFused.apply(x, w, isc, osc, bias, act, kind)
