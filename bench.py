@@ -96,17 +96,19 @@ class KernelTimer:
 
 
 def cpu_baseline(size):
-    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 2, 1 warm-up + 2 timed iterations)."""
+    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 1, 1 warm-up + 1 timed iteration)."""
     from oracle import te_oracle as O
     from transeditor_amd import synth
     from transeditor_amd.model_spatial_query import Generator
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 256 hardware threads oversubscribe the small CPU convolutions badly (measured 187 s/iter); use a socket's
+    # worth of threads and say so in `cores`
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     token = 2 * (int(math.log2(size)) - 1)
     sd = Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).state_dict()
     P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'noises' not in k and 'kernel' not in k
              and not k.startswith('token') else v) for k, v in sd.items()}
     leaves = [v for v in P.values() if v.requires_grad]
-    B, iters = 2, 2
+    B, iters = 1, 1
     times = []
     for it in range(iters + 1):
         z, p = synth.latents(B, 900 + it)

@@ -29,6 +29,15 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 struct copies lower to memcpy and stay in scratch)
 
+constexpr unsigned OOBH = 0x40000000u;   // "out of bounds" half-offset: any sum containing it exceeds num_records -> load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 constexpr int KC = 8;     // input channels per stage
 constexpr int BM = 128;   // block tile, output channels
 constexpr int NTHREADS = 256;
@@ -58,8 +67,9 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 
 // MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
-template <int KIND, int NBW, bool HAS_ISC>
-__global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
+// MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
+template <int KIND, int NBW, bool HAS_ISC, bool MS>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int MBW = 2;
     constexpr int NTAP = Kind<KIND>::NT;
     constexpr bool IS_T2 = (KIND == TE_CONV_T2);
@@ -96,26 +106,26 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
     // ---- per-thread staging descriptors (constant over the K loop)
     const int tile_sp = p.TIH * p.TIW;
     const int n_sp = p.NS * tile_sp;
-    int64_t goff[NSP];       // global offset of channel 0 (clamped to a safe address when the element is padding)
-    float gmask[NSP];        // 1 = real pixel, 0 = zero padding
+    unsigned goff[NSP];      // byte offset of channel 0 relative to the tile's first sample, or OOBH for zero padding
     int loff[NSP], sb[NSP];  // LDS offset (or -1: no element for this thread), sample index
-    const int64_t plane = (int64_t)p.Hi * p.Wi;
+    const unsigned plane4 = (unsigned)p.Hi * p.Wi * 4u;
 #pragma unroll
     for (int r = 0; r < NSP; ++r) {
         const int e = tid + NTHREADS * r;
-        goff[r] = 0; gmask[r] = 0.f; loff[r] = -1; sb[r] = 0;
+        goff[r] = OOBH; loff[r] = -1; sb[r] = 0;
         if (e < n_sp) {
             const int s = e / tile_sp, rem = e - s * tile_sp;
             const int ry = rem / p.TIW, rx = rem - ry * p.TIW;
             const int b = b0 + s, gy = oy + ry, gx = ox + rx;
             loff[r] = s * p.SS + ry * p.TIWP + rx;
             sb[r] = b < p.B ? b : 0;
-            if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi) {
-                goff[r] = (int64_t)b * p.K * plane + (int64_t)gy * p.Wi + gx;
-                gmask[r] = 1.f;
-            }
+            if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+                goff[r] = (unsigned)s * p.K * plane4 + (unsigned)(gy * p.Wi + gx) * 4u;
         }
     }
+    // input of the samples of this tile through one buffer descriptor: 32-bit offsets, hardware zero fill
+    const int ns_here = min(p.NS, p.B - b0);
+    const __amdgpu_buffer_rsrc_t irs = make_rsrc(p.in + (size_t)b0 * p.K * p.Hi * p.Wi, (unsigned)ns_here * p.K * plane4);
 
     // ---- per-lane B-fragment base offsets (LDS floats), one per cell block
     int boff[NBW];
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
     // ---- register prefetch buffers
     f32x4 wreg[WLDR];
     float xreg[NSP][KC];
+    float sreg[(HAS_ISC && MS) ? NSP : 1][KC];   // style scales of the staged channels (applied when the tile is written to LDS)
 
     // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
     // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
             for (int r = 0; r < NSP; ++r) {
                 if (loff[r] >= 0) {
 #pragma unroll
-                    for (int kk = 0; kk < KC; ++kk) xl[kk * p.CS + loff[r]] = xreg[r][kk];
+                    for (int kk = 0; kk < KC; ++kk)
+                        xl[kk * p.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
                 }
             }
             __syncthreads();
@@ -176,14 +188,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_mfma_kernel(const ConvArgs p) {
             for (int r = 0; r < NSP; ++r) {
 #pragma unroll
                 for (int kk = 0; kk < KC; ++kk) {
-                    // unconditional loads from clamped addresses (a branch per element would serialise the loads);
-                    // padding / channel tail are zeroed by the mask
+                    // unconditional buffer loads: zero padding and the channel tail come back as 0 from the hardware
+                    // range check, so nothing depends on the loaded value until the tile is committed to LDS
                     const int k = kn + kk;
-                    const int kc = k < p.K ? k : p.K - 1;
-                    float v = p.in[goff[r] + (int64_t)kc * plane];
-                    float m = k < p.K ? gmask[r] : 0.f;
-                    if (HAS_ISC) m *= p.isc[sb[r] * p.K + kc];
-                    xreg[r][kk] = m != 0.f ? v * m : 0.f;
+                    const unsigned koff = k < p.K ? (unsigned)k * plane4 : OOBH;
+                    xreg[r][kk] = buf_load(irs, goff[r] + koff);
+                    if (HAS_ISC && (MS || r == 0))
+                        sreg[MS ? r : 0][kk] = p.isc[(MS ? sb[r] : b0) * p.K + (k < p.K ? k : p.K - 1)];
                 }
             }
         }
@@ -301,8 +312,8 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     return d;
 }
 
-template <int KIND, int NBW, bool HAS_ISC>
-int launch_region_t(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
+template <int KIND, int NBW, bool HAS_ISC, bool MS>
+int launch_region_tt(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
     if (rh <= 0 || rw <= 0) return 0;
     constexpr int NTILE = 2 * NBW * 32;
     a.ri0 = ri0; a.rj0 = rj0; a.rh = rh; a.rw = rw;
@@ -320,24 +331,30 @@ int launch_region_t(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s)
     a.SS = a.TIH * a.TIWP;
     a.CS = a.NS * a.SS;
     constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
+    if ((int64_t)a.NS * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", a.NS, a.K, a.Hi, a.Wi);
     if (a.NS * a.TIH * a.TIW > NSP * NTHREADS)
         return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", a.NS, a.TIH, a.TIW);
     const size_t lds = sizeof(float) * ((size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * a.CS);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     const int sgroups = (a.B + a.NS - 1) / a.NS;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * sgroups), (unsigned)(a.Mp / BM));
-    conv_mfma_kernel<KIND, NBW, HAS_ISC><<<grid, NTHREADS, lds, s>>>(a);
+    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS><<<grid, NTHREADS, lds, s>>>(a);
     return 0;
 }
 
 template <int KIND, int NBW>
 int launch_region(const ConvArgs& a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
-    return a.isc ? launch_region_t<KIND, NBW, true>(a, ri0, rj0, rh, rw, s)
-                 : launch_region_t<KIND, NBW, false>(a, ri0, rj0, rh, rw, s);
+    if (rh <= 0 || rw <= 0) return 0;
+    const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), 2 * NBW * 32 / TW);
+    const bool ms = TW * TH < 2 * NBW * 32;          // several samples share one cell tile
+    if (!a.isc) return launch_region_tt<KIND, NBW, false, false>(a, ri0, rj0, rh, rw, s);
+    return ms ? launch_region_tt<KIND, NBW, true, true>(a, ri0, rj0, rh, rw, s)
+              : launch_region_tt<KIND, NBW, true, false>(a, ri0, rj0, rh, rw, s);
 }
 
 }  // namespace

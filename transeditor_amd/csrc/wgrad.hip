@@ -20,8 +20,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int NTHREADS = 256;
-constexpr int CB = 64;   // channels per block tile on each side
+constexpr int NTHREADS = 512;   // 8 waves: 4 (plain-operand channel blocks) x 2 (shifted-operand channel blocks)
+constexpr int PCH = 128;        // channels of the plain operand per block
+constexpr int QCH = 64;         // channels of the shifted operand per block
+constexpr unsigned OOB = 0x80000000u;   // buffer offset beyond num_records: the load returns 0
 
 struct WgArgs {
     float* slabs;
@@ -30,70 +32,54 @@ struct WgArgs {
     int B, Co, Ci, H, W;     // low-res (cell grid) size
     int Hg, Wg, Hx, Wx;      // spatial size of g and x
     int S;                   // chunks per sample
-    int TH, TW, lgTW, NC;    // cell tile (NC = TH*TW cells per stage)
+    int TH, TW, lgTW, NC, lgNC;   // cell tile (NC = TH*TW cells per stage)
     int tiles_x, tiles_y;
     int QH, QW, QS;          // shifted-operand tile: rows, cols, channel stride (odd)
     int PS;                  // plain-operand channel stride (odd)
+    unsigned magic_qt, magic_qw;   // ceil(2^32 / (QH*QW)), ceil(2^32 / QW): exact division of small indices
 };
 
 template <int KIND> struct WK;
-template <> struct WK<TE_CONV_3X3> { static constexpr int NT = 9, NCELL = 64, NP = 16, NQ = 36; };
-template <> struct WK<TE_CONV_1X1> { static constexpr int NT = 1, NCELL = 64, NP = 16, NQ = 16; };
-template <> struct WK<TE_CONV_T2>  { static constexpr int NT = 9, NCELL = 32, NP = 8,  NQ = 52; };
+template <> struct WK<TE_CONV_3X3> { static constexpr int NT = 9, NCELL = 64, NP = 16, NQ = 17; };
+template <> struct WK<TE_CONV_1X1> { static constexpr int NT = 1, NCELL = 64, NP = 16, NQ = 8; };
+template <> struct WK<TE_CONV_T2>  { static constexpr int NT = 9, NCELL = 32, NP = 8,  NQ = 25; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 
 template <int KIND>
-__global__ __launch_bounds__(NTHREADS) void wgrad_mfma_kernel(const WgArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_mfma_kernel(const WgArgs p) {
     constexpr int NT = WK<KIND>::NT;
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);   // which operand carries the tap shift
-    constexpr int NP = WK<KIND>::NP;                // plain-tile elements per thread   (CB*NC / 256)
-    constexpr int NQ = WK<KIND>::NQ;                // shifted-tile elements per thread (>= CB*QH*QW / 256)
+    constexpr int NP = WK<KIND>::NP;                // plain-tile elements per thread   (PCH*NC / 512)
+    constexpr int NQ = WK<KIND>::NQ;                // shifted-tile elements per thread (>= QCH*QH*QW / 512)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pl = smem;                     // plain operand   [CB][PS]
-    float* ql = smem + CB * p.PS;         // shifted operand [CB][QS]
+    float* pl = smem;                      // plain operand   [PCH][PS]
+    float* ql = smem + PCH * p.PS;         // shifted operand [QCH][QS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wco = wid >> 1, wci = wid & 1;       // wave -> (co block, ci block)
+    const int wp = wid >> 1, wq = wid & 1;          // wave -> (plain channel block, shifted channel block)
 
     const int s_chunk = blockIdx.x % p.S, b = blockIdx.x / p.S;
-    const int co0 = blockIdx.y * CB, ci0 = blockIdx.z * CB;
+    // rows of the result = co (A operand = g), cols = ci (B operand = x)
+    const int co0 = blockIdx.y * (GSHIFT ? QCH : PCH), ci0 = blockIdx.z * (GSHIFT ? PCH : QCH);
 
     const float* gP = p.g + (size_t)b * p.Co * p.Hg * p.Wg;
     const float* xP = p.x + (size_t)b * p.Ci * p.Hx * p.Wx;
-    // plain / shifted operand descriptors
-    const float* pbase = GSHIFT ? xP : gP;
-    const float* qbase = GSHIFT ? gP : xP;
     const int pC = GSHIFT ? p.Ci : p.Co, qC = GSHIFT ? p.Co : p.Ci;
     const int pc0 = GSHIFT ? ci0 : co0, qc0 = GSHIFT ? co0 : ci0;
     const int pH = GSHIFT ? p.Hx : p.Hg, pW = GSHIFT ? p.Wx : p.Wg;
     const int qH = GSHIFT ? p.Hg : p.Hx, qW = GSHIFT ? p.Wg : p.Wx;
-
-    // per-thread staging descriptors that do not depend on the tile
-    // (packed: channel << 20 | row << 10 | col; channel 127 = no element for this thread)
-    int pd[NP];
-#pragma unroll
-    for (int r = 0; r < NP; ++r) {
-        const int e = tid + NTHREADS * r;
-        int ch = e / p.NC;
-        const int cell = e - ch * p.NC;
-        if (ch >= CB) ch = 127;
-        pd[r] = (ch << 20) | ((cell >> p.lgTW) << 10) | (cell & (p.TW - 1));
-    }
+    // one buffer descriptor per operand and sample: 32-bit offsets, hardware zero fill for masked elements
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(GSHIFT ? xP : gP, (unsigned)pC * pH * pW * 4u);
+    const __amdgpu_buffer_rsrc_t qrs = make_rsrc(GSHIFT ? gP : xP, (unsigned)qC * qH * qW * 4u);
     const int q_tile = p.QH * p.QW;
-    int qd[NQ];
-#pragma unroll
-    for (int r = 0; r < NQ; ++r) {
-        const int e = tid + NTHREADS * r;
-        int ch = e / q_tile;
-        const int rem = e - ch * q_tile;
-        if (ch >= CB) ch = 127;
-        const int ry = rem / p.QW;
-        qd[r] = (ch << 20) | (ry << 10) | (rem - ry * p.QW);
-    }
-#define DCH(d) ((d) >> 20)
-#define DY(d) (((d) >> 10) & 1023)
-#define DX(d) ((d) & 1023)
 
     f32x16 acc[NT];
 #pragma unroll
@@ -101,14 +87,11 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mfma_kernel(const WgArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // lane bases inside the LDS tiles
-    const int a_ch = (GSHIFT ? wco : wco) * 32 + l31;   // co channel of this lane (A operand rows)
-    const int b_ch = wci * 32 + l31;                    // ci channel of this lane (B operand cols)
-    // g is the A operand, x the B operand.  plain operand position = cell; shifted = f(cell) + tap offset
-    const int g_lane = a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half);
-    const int x_lane = b_ch * (GSHIFT ? p.PS : p.QS) + half;
-    const float* g_l = GSHIFT ? ql : pl;
-    const float* x_l = GSHIFT ? pl : ql;
+    // lane bases inside the LDS tiles: g is the A operand, x the B operand
+    const int a_ch = (GSHIFT ? wq : wp) * 32 + l31;     // co of this lane inside the block tile
+    const int b_ch = (GSHIFT ? wp : wq) * 32 + l31;     // ci of this lane inside the block tile
+    const float* g_l = (GSHIFT ? ql : pl) + a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half);
+    const float* x_l = (GSHIFT ? pl : ql) + b_ch * (GSHIFT ? p.PS : p.QS) + half;
 
     const int n_tiles = p.tiles_x * p.tiles_y;
     const int t_begin = (int)((int64_t)n_tiles * s_chunk / p.S), t_end = (int)((int64_t)n_tiles * (s_chunk + 1) / p.S);
@@ -118,11 +101,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mfma_kernel(const WgArgs p) {
         if (tl >= t_begin) {
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < NP; ++r)
-                if (DCH(pd[r]) < CB) pl[DCH(pd[r]) * p.PS + (DY(pd[r]) << p.lgTW) + DX(pd[r])] = preg[r];
+            for (int r = 0; r < NP; ++r) {
+                int e = tid + NTHREADS * r;
+                asm volatile("" : "+v"(e));      // keep the index math inside the loop (hoisting it costs ~100 VGPRs)
+                const int ch = e >> p.lgNC;
+                if (ch < PCH) pl[ch * p.PS + (e & (p.NC - 1))] = preg[r];
+            }
 #pragma unroll
-            for (int r = 0; r < NQ; ++r)
-                if (DCH(qd[r]) < CB) ql[DCH(qd[r]) * p.QS + DY(qd[r]) * p.QW + DX(qd[r])] = qreg[r];
+            for (int r = 0; r < NQ; ++r) {
+                unsigned e = tid + NTHREADS * r;
+                asm volatile("" : "+v"(e));
+                const unsigned ch = __umulhi(e, p.magic_qt), rem = e - ch * q_tile;
+                if (ch < QCH) ql[ch * p.QS + rem] = qreg[r];       // tile stored [row][col] with stride QW == linear rem
+            }
             __syncthreads();
         }
         const int tn = tl + 1;
@@ -134,57 +125,79 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mfma_kernel(const WgArgs p) {
             else { qy0 = ty0; qx0 = tx0; }
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
-                const int y = ty0 + DY(pd[r]), xx = tx0 + DX(pd[r]), ch = pc0 + DCH(pd[r]);
-                const bool ok = DCH(pd[r]) < CB && y < p.H && xx < p.W && ch < pC;    // plain operand lives on the cell grid
-                const size_t off = ((size_t)(ok ? ch : 0) * pH + (ok ? y : 0)) * pW + (ok ? xx : 0);
-                const float v = pbase[off];
-                preg[r] = ok ? v : 0.f;
+                int e = tid + NTHREADS * r;
+                asm volatile("" : "+v"(e));
+                const int chl = e >> p.lgNC, cell = e & (p.NC - 1);
+                const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
+                const bool ok = chl < PCH && y < p.H && xx < p.W && ch < pC;    // plain operand lives on the cell grid
+                preg[r] = buf_load(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
             }
 #pragma unroll
             for (int r = 0; r < NQ; ++r) {
-                const int y = qy0 + DY(qd[r]), xx = qx0 + DX(qd[r]), ch = qc0 + DCH(qd[r]);
-                const bool ok = DCH(qd[r]) < CB && y >= 0 && y < qH && xx >= 0 && xx < qW && ch < qC;
-                const size_t off = ((size_t)(ok ? ch : 0) * qH + (ok ? y : 0)) * qW + (ok ? xx : 0);
-                const float v = qbase[off];
-                qreg[r] = ok ? v : 0.f;
+                unsigned e = tid + NTHREADS * r;
+                asm volatile("" : "+v"(e));
+                const unsigned chl = __umulhi(e, p.magic_qt), rem = e - chl * q_tile;
+                const unsigned ry = __umulhi(rem, p.magic_qw), rx = rem - ry * p.QW;
+                const int y = qy0 + (int)ry, xx = qx0 + (int)rx, ch = qc0 + (int)chl;
+                const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
+                qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
             }
         }
         if (tl < t_begin) continue;
 
-        // ---- MFMAs over the cells of the staged tile (2 cells per k-step: lane half h takes cell 2*ks + h)
-#pragma unroll 2
-        for (int ks = 0; ks < p.NC / 2; ++ks) {
-            const int c0 = 2 * ks;
-            const int cy = c0 >> p.lgTW, cx = c0 & (p.TW - 1);
-            int sh;   // position of cell c0 inside the shifted tile (tap 0,0)
-            if (KIND == TE_CONV_T2) sh = 2 * cy * p.QW + 2 * cx;
-            else sh = cy * p.QW + cx;
+        // ---- MFMAs over the cells of the staged tile (2 cells per k-step: lane half h takes cell 2*ks + h);
+        //      operands of step ks+1 are read from LDS before the MFMAs of step ks are issued
+        const int nks = p.NC >> 1;
+        float a_c[GSHIFT ? NT : 1], b_c[GSHIFT ? 1 : NT];
+        auto pos_shift = [&](int ks) {
+            const int c0 = 2 * ks, cy = c0 >> p.lgTW, cx = c0 & (p.TW - 1);
+            return (KIND == TE_CONV_T2) ? 2 * cy * p.QW + 2 * cx : cy * p.QW + cx;
+        };
+        {
+            const int sh = pos_shift(0);
             if (!GSHIFT) {
-                const float av = g_l[g_lane + c0];
+                a_c[0] = g_l[0];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int toff = (NT == 1) ? 0 : (t / 3) * p.QW + (t % 3);
-                    const float bv = x_l[x_lane + sh + toff];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) b_c[t] = x_l[sh + ((NT == 1) ? 0 : (t / 3) * p.QW + (t % 3))];
             } else {
-                const float bv = x_l[x_lane + c0];
+                b_c[0] = x_l[0];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int toff = (t / 3) * p.QW + (t % 3);
-                    const float av = g_l[g_lane + sh + toff];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) a_c[t] = g_l[sh + (t / 3) * p.QW + (t % 3)];
+            }
+        }
+#pragma unroll 2
+        for (int ks = 0; ks < nks; ++ks) {
+            float a_n[GSHIFT ? NT : 1], b_n[GSHIFT ? 1 : NT];
+            const int kn = (ks + 1 < nks) ? ks + 1 : ks;          // last step re-reads itself (harmless)
+            const int sh = pos_shift(kn);
+            if (!GSHIFT) {
+                a_n[0] = g_l[2 * kn];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b_n[t] = x_l[sh + ((NT == 1) ? 0 : (t / 3) * p.QW + (t % 3))];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[0], b_c[t], acc[t], 0, 0, 0);
+                a_c[0] = a_n[0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b_c[t] = b_n[t];
+            } else {
+                b_n[0] = x_l[2 * kn];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_n[t] = g_l[sh + (t / 3) * p.QW + (t % 3)];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[t], b_c[0], acc[t], 0, 0, 0);
+                b_c[0] = b_n[0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_c[t] = a_n[t];
             }
         }
     }
 
     // ---- write the slab tile: rows = co, cols = ci;  slab[b][s][co][ci][tap]
     float* sl = p.slabs + ((size_t)b * p.S + s_chunk) * p.Co * p.Ci * NT;
-    const int ci = ci0 + wci * 32 + l31;
+    const int ci = ci0 + b_ch;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + (GSHIFT ? wq : wp) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < p.Co && ci < p.Ci) {
             float* dst = sl + ((size_t)co * p.Ci + ci) * NT;
 #pragma unroll
@@ -195,6 +208,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_mfma_kernel(const WgArgs p) {
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int pow2ceil(int v) { return 1 << ilog2(v); }
+inline unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }   // exact floor(e/d) for e < 2^16, d < 2^16
 
 template <int KIND>
 bool fill_geometry(WgArgs& a) {
@@ -202,9 +216,9 @@ bool fill_geometry(WgArgs& a) {
     a.TW = std::min(32, pow2ceil(a.W));
     if (a.TW < 2) return false;
     a.TH = std::max(1, std::min(pow2ceil(a.H), NCELL / a.TW));
-    a.NC = NCELL;                                  // cells per stage (positions beyond TH*TW are never valid)
-    if (a.TH * a.TW < NCELL) a.NC = a.TH * a.TW;
+    a.NC = a.TH * a.TW;                            // cells per stage (<= NCELL)
     a.lgTW = ilog2(a.TW);
+    a.lgNC = ilog2(a.NC);
     a.tiles_x = (a.W + a.TW - 1) / a.TW;
     a.tiles_y = (a.H + a.TH - 1) / a.TH;
     if (KIND == TE_CONV_3X3) { a.QH = a.TH + 2; a.QW = a.TW + 2; }
@@ -212,20 +226,24 @@ bool fill_geometry(WgArgs& a) {
     else { a.QH = a.TH; a.QW = a.TW; }
     a.QS = (a.QH * a.QW) | 1;
     a.PS = a.NC | 1;
-    return CB * a.QH * a.QW <= WK<KIND>::NQ * NTHREADS && CB * a.NC <= WK<KIND>::NP * NTHREADS;
+    a.magic_qt = magic((unsigned)(a.QH * a.QW));
+    a.magic_qw = magic((unsigned)a.QW);
+    return QCH * a.QH * a.QW <= WK<KIND>::NQ * NTHREADS && PCH * a.NC <= WK<KIND>::NP * NTHREADS;
 }
 
 template <int KIND>
 int launch_wgrad(WgArgs a, hipStream_t s) {
     if (!fill_geometry<KIND>(a)) return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: unsupported image size %dx%d", a.H, a.W);
-    // the staging loops cover exactly NP*256 plain elements: NC must make CB*NC == NP*256 or be guarded
-    const size_t lds = sizeof(float) * ((size_t)CB * a.PS + (size_t)CB * a.QS);
+    if ((int64_t)a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: per-sample tensor exceeds 2 GiB");
+    const size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_done = true;
     }
-    dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, CB), (unsigned)te::cdiv(a.Ci, CB));
+    constexpr bool GSHIFT = (KIND == TE_CONV_T2);
+    dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
     wgrad_mfma_kernel<KIND><<<grid, NTHREADS, lds, s>>>(a);
     return 0;
 }
@@ -238,16 +256,17 @@ inline int n_cell_tiles(int kind, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
+constexpr int RTHREADS = 256;
 constexpr int COB = 4;     // output channels per block
 constexpr int BMAX = 16;   // samples per pass (register array)
 
 template <int NT>
-__global__ __launch_bounds__(NTHREADS) void wgrad_reduce_kernel(float* __restrict__ gw, float* __restrict__ gisc,
+__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_kernel(float* __restrict__ gw, float* __restrict__ gisc,
                                                                 float* __restrict__ gosc, const float* __restrict__ slabs,
                                                                 const float* __restrict__ w, float wscale,
                                                                 const float* __restrict__ isc, const float* __restrict__ osc,
                                                                 int B, int S, int Co, int Ci) {
-    const int ci = blockIdx.x * NTHREADS + threadIdx.x;
+    const int ci = blockIdx.x * RTHREADS + threadIdx.x;
     const bool live = ci < Ci;
     const int cic = live ? ci : Ci - 1;
     const int lane = threadIdx.x & 63;
@@ -309,8 +328,8 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_reduce_kernel(float* __restric
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
-    const int64_t mn = te::cdiv(Co, CB) * te::cdiv(Ci, CB) * (int64_t)B;
-    int64_t S = te::cdiv(4 * te::kNumCU, mn);     // aim at >= 4 blocks per CU
+    const int64_t mn = te::cdiv((int64_t)Co * Ci, PCH * QCH) * (int64_t)B;
+    int64_t S = te::cdiv(2 * te::kNumCU, mn);     // aim at >= 2 blocks (of 8 waves) per CU
     S = std::max<int64_t>(1, std::min<int64_t>(S, tiles));
     return (int)S;
 }
@@ -319,7 +338,7 @@ extern "C" int te_wgrad_f32(float* slabs, const float* g, const float* x, int ki
                             int S, te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && H > 0 && W > 0 && S > 0, TE_ERR_SHAPE, "te_wgrad_f32: bad dims");
-    TE_REQUIRE((int64_t)B * S <= 0x7FFFFFFF && te::cdiv(Co, CB) <= 65535 && te::cdiv(Ci, CB) <= 65535, TE_ERR_SHAPE,
+    TE_REQUIRE((int64_t)B * S <= 0x7FFFFFFF && te::cdiv(Co, QCH) <= 65535 && te::cdiv(Ci, QCH) <= 65535, TE_ERR_SHAPE,
                "te_wgrad_f32: grid too large");
     WgArgs a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S;
@@ -341,9 +360,9 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
                                    te_stream_t stream_) {
     TE_REQUIRE(slabs && w, TE_ERR_NULL, "te_wgrad_reduce_f32: NULL pointer");
     TE_REQUIRE(B > 0 && S > 0 && Co > 0 && Ci > 0 && (taps == 1 || taps == 9), TE_ERR_SHAPE, "te_wgrad_reduce_f32: bad dims");
-    dim3 grid((unsigned)te::cdiv(Ci, NTHREADS), (unsigned)te::cdiv(Co, COB));
+    dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)te::cdiv(Co, COB));
     hipStream_t s = (hipStream_t)stream_;
-    if (taps == 9) wgrad_reduce_kernel<9><<<grid, NTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
-    else wgrad_reduce_kernel<1><<<grid, NTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+    if (taps == 9) wgrad_reduce_kernel<9><<<grid, RTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+    else wgrad_reduce_kernel<1><<<grid, RTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
     return te::launch_status("te_wgrad_reduce_f32");
 }

@@ -35,6 +35,7 @@ class _AttnCore(Function):
         q, k, v, sim = ctx.saved_tensors
         if torch.is_grad_enabled():
             with torch.enable_grad():
+                q, k, v = q.view_as(q), k.view_as(k), v.view_as(v)   # aliases: partial derivatives only
                 o2, sim2 = _torch_expr(q, k, v, ctx.scale, ctx.groups)
                 outs, gouts = [o2], [go if go is not None else torch.zeros_like(o2)]
                 if gsim is not None:

@@ -30,8 +30,9 @@ class _BlurBiasAct(Function):
         pad = ctx.pad
         if torch.is_grad_enabled():
             with torch.enable_grad():
-                y = fused_leaky_relu(upfirdn2d(x, kernel, pad=pad), bias)
-                gx, gb = torch.autograd.grad(y, (x, bias), g, create_graph=True, allow_unused=True)
+                xa, ba = x.view_as(x), bias.view_as(bias)          # aliases: partial derivatives only
+                y = fused_leaky_relu(upfirdn2d(xa, kernel, pad=pad), ba)
+                gx, gb = torch.autograd.grad(y, (xa, ba), g, create_graph=True, allow_unused=True)
             return gx, None, gb, None
         gpre, gb = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=True)
         pad4 = (pad[0], pad[1], pad[0], pad[1])

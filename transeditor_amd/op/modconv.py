@@ -140,12 +140,16 @@ class _ModConvFused(Function):
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():
             # double backward requested: differentiate the composite built from the closed trio
+            # The inputs may depend on each other in the OUTER graph (osc = demod is a function of isc = style
+            # scale): differentiate w.r.t. fresh aliases so each returned gradient is the PARTIAL derivative,
+            # while everything stays connected to the original tensors for the next differentiation.
             with torch.enable_grad():
-                y = _composite(x, w, isc, osc, bias, act, kind)
-                ins = [t for t, n in zip((x, w, isc, osc, bias), need[:5]) if n and t is not None]
+                al = [None if t is None else t.view_as(t) for t in (x, w, isc, osc, bias)]
+                y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind)
+                ins = [t for t, n in zip(al, need[:5]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
             return tuple(next(gs) if (n and t is not None) else None
-                         for t, n in zip((x, w, isc, osc, bias), need[:5])) + (None, None)
+                         for t, n in zip(al, need[:5])) + (None, None)
         g = g.contiguous()
         g_bias = None
         if act:
