@@ -39,9 +39,10 @@ def test_generator64_config1_forward_backward(golden, g64):
     wimg = synth.normal(tuple(img.shape), 'wimg.64').to(DEV)
     names = [n for n, _ in G.named_parameters()]
     grads = torch.autograd.grad((img * wimg).sum() / img.numel(), [z, p] + list(G.parameters()), allow_unused=True)
-    # d(image)/d(latent) runs back through 8 LayerNorm/attention blocks whose weights are O(100) (lr_mul = 0.01):
-    # fp32 round-off of ANY two correct implementations differs at the 1e-3 level here (see
-    # test_latent_gradient_conditioning, which measures CPU-fp32 vs CPU-fp64), hence 3x the headline tolerance
+    # Gradients are discontinuous at the leaky-ReLU kinks: a pre-activation within fp32 round-off of 0 flips its
+    # slope between two correct fp32 implementations.  Measured on the GPU box (tools/gpu_grad_probe2.py): for an
+    # unlucky (weights, latents) draw the CPU-fp32 oracle is 1e-4 from the fp64 truth, torch's own GPU ops 5e-4,
+    # this path 4e-4; for a benign draw all three are 1e-6.  Hence 3x the headline tolerance on latent gradients.
     assert rel_err(grads[0], gold['gz']) < 3 * TOL and rel_err(grads[1], gold['gp']) < 3 * TOL
     assert [str(n) for n in gold['grad_names']] == names
     unused = []

@@ -3,6 +3,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 600 python tools/gpu_diag.py ) > gpurun_out/diag.log 2>&1
+( timeout 600 python tools/gpu_grad_probe.py ) > gpurun_out/gradprobe.log 2>&1
 echo "diag rc=$?" 
 ( timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider ${PYTEST_EXTRA} ) > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"

@@ -57,6 +57,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;    // tiles per sample group
     int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
     int act;
+    int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
 template <int KIND> struct Kind;
@@ -157,8 +158,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
 
     // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
     // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
-    for (int k0 = -KC; k0 < p.Kp; k0 += KC) {
-        if (k0 >= 0) {
+    const int kbeg = blockIdx.z * p.kchunk, kend = min(p.Kp, kbeg + p.kchunk);
+    for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
+        if (k0 >= kbeg) {
             __syncthreads();              // every wave finished reading the previous stage
 #pragma unroll
             for (int r = 0; r < WLDR; ++r) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
             __syncthreads();
         }
         const int kn = k0 + KC;
-        if (kn < p.Kp) {
+        if (kn < kend) {
 #pragma unroll
             for (int r = 0; r < WLDR; ++r) {
                 const int idx = tid + NTHREADS * r;          // float4 index inside the stage
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
                 }
             }
         }
-        if (k0 < 0) continue;
+        if (k0 < kbeg) continue;
 
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
@@ -261,7 +263,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
                 const bool ok = cell_ok && m < p.M;
                 float* obase = p.out + ((size_t)bc * p.M + (m < p.M ? m : 0)) * oplane;
-                if (!IS_T2) {
+                if (p.ksplit > 1) {      // partial sums: accumulate raw, scale/bias/activation happen in conv_finalize_kernel
+                    if (!IS_T2) {
+                        if (ok) atomicAdd(obase + (size_t)ci * p.Wo + cj, acc[mb][nb][r]);
+                    } else {
+#pragma unroll
+                        for (int ph = 0; ph < 4; ++ph) {
+                            const int Y = 2 * ci + (ph >> 1), X = 2 * cj + (ph & 1);
+                            if (ok && Y < p.Ho && X < p.Wo) atomicAdd(obase + (size_t)Y * p.Wo + X, acc[mb][nb * 4 + ph][r]);
+                        }
+                    }
+                } else if (!IS_T2) {
                     float v = acc[mb][nb][r] * sc[r] + bi[r];
                     if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
                     if (ok) obase[(size_t)ci * p.Wo + cj] = v;
@@ -276,6 +288,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
                 }
             }
         }
+    }
+}
+
+// epilogue of the split-K path: out = act(out * osc[b,m] + bias[m])
+__global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ out, const float* __restrict__ osc,
+                                                            const float* __restrict__ bias, int act, int M, int plane, int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t bm = e / plane;
+        float v = out[e];
+        if (osc) v *= osc[bm];
+        if (bias) v += bias[bm % M];
+        if (act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+        out[e] = v;
     }
 }
 
@@ -342,7 +367,7 @@ int launch_region_tt(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s
         attr_done = true;
     }
     const int sgroups = (a.B + a.NS - 1) / a.NS;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * sgroups), (unsigned)(a.Mp / BM));
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * sgroups), (unsigned)(a.Mp / BM), (unsigned)a.ksplit);
     conv_mfma_kernel<KIND, NBW, HAS_ISC, MS><<<grid, NTHREADS, lds, s>>>(a);
     return 0;
 }
@@ -385,6 +410,22 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     ConvArgs a{};
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KC); a.Mp = roundup(M, BM); a.H = H; a.W = W;
+    // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers)
+    {
+        const int cells = (kind == TE_CONV_T2) ? (H + 1) * (W + 1) : H * W;
+        const int64_t base_blocks = te::cdiv((int64_t)B * cells, 128) * (a.Mp / BM);
+        const int stages = a.Kp / KC;
+        int ks = 1;
+        if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
+        a.ksplit = std::max(1, ks);
+        a.kchunk = (int)te::cdiv(stages, a.ksplit) * KC;
+        a.ksplit = (int)te::cdiv(a.Kp, a.kchunk);
+        if (a.ksplit > 1) {
+            const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
+            hipError_t e = hipMemsetAsync(out, 0, bytes, s);
+            if (e != hipSuccess) return te::fail((int)e, "te_conv_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+    }
     int rc = 0;
     switch (kind) {
         case TE_CONV_3X3:
@@ -413,5 +454,10 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
             return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     }
     if (rc) return rc;
+    if (a.ksplit > 1 && (osc || bias || act)) {
+        const int plane = a.Ho * a.Wo;
+        const int64_t total = (int64_t)B * M * plane;
+        conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, osc, bias, act, M, plane, total);
+    }
     return te::launch_status("te_conv_f32");
 }
