@@ -124,6 +124,21 @@ int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const float* slabs,
                         int taps, te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * M3  ToRGB: 1x1 modulated convolution to 3 channels (reference: ToRGB.forward, model_spatial_query.py:
+ * 416-425 — grouped 1x1 F.conv2d, demodulate=False).  HBM-bound streaming kernels (x [B,K,HW] touched once):
+ *   fwd   out[b,o,p] = sum_k w[o,k] isc[b,k] x[b,k,p] + bias[o]          w [3,K], isc/bias may be NULL
+ *   dgrad gx[b,k,p]  = isc[b,k] sum_o w[o,k] g[b,o,p]
+ *   wgrad slabs[b][c][o][k] = sum_{p in chunk c} g[b,o,p] x[b,k,p]       (finish with te_wgrad_reduce_f32, taps = 1)
+ * te_rgb_supported: 1 if (M == 3, K <= 512, HW % 4 == 0), else use te_conv_f32(TE_CONV_1X1).
+ */
+int te_rgb_supported(int M, int K, int HW);
+int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, int B, int K, int HW,
+                   te_stream_t stream);
+int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, int B, int K, int HW, te_stream_t stream);
+int te_rgb_wgrad_slab_count(int B, int K, int HW);
+int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * F2  attention core of the dual-space cross-attention block (reference: Attention.forward,
  * model_spatial_query.py:888-894): per sample and head,  sim = softmax(scale * q k^T),
  * o = sim v, with QK^T and sim.V on v_mfma_f32_16x16x4_f32.

@@ -199,6 +199,27 @@ def test_modconv_fused_kernel_vs_composite(kind, shape, act):
         assert rel_err(a, b) < SUM_TOL, name
 
 
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16), (3, 40, 6, 6), (2, 512, 4, 4), (2, 24, 5, 5), (2, 128, 64, 64)])
+def test_torgb_streaming_kernels(shape):
+    """ToRGB path (1x1 -> 3 channels, style scale + bias): dedicated streaming kernels when H*W % 4 == 0 and K <= 512,
+    MFMA 1x1 kernel otherwise; forward, dx, dW, ds, dbias against plain torch."""
+    from transeditor_amd.op.modconv import modconv
+    B, K, H, W = shape
+    x = synth.normal((B, K, H, W), 'rgb.x').requires_grad_(True)
+    w = (synth.normal((3, K, 1, 1), 'rgb.w') / math.sqrt(K)).requires_grad_(True)
+    isc = (1 + 0.5 * synth.normal((B, K), 'rgb.i')).requires_grad_(True)
+    bias = synth.normal((3,), 'rgb.b').requires_grad_(True)
+    y_ref = F.conv2d(x * isc[:, :, None, None], w) + bias[None, :, None, None]
+    gy = synth.normal(tuple(y_ref.shape), 'rgb.g')
+    ref = torch.autograd.grad((y_ref * gy).sum(), (x, w, isc, bias))
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, isc, bias)]
+    y = modconv(d[0], d[1], d[2], None, d[3], False, '1x1')
+    assert rel_err(y, y_ref) < OP_TOL
+    got = torch.autograd.grad((y * gy.to(DEV)).sum(), d)
+    for name, a, b in zip(('gx', 'gw', 'gisc', 'gbias'), got, ref):
+        assert rel_err(a, b) < SUM_TOL, name
+
+
 # ------------------------------------------------------------------------------------------------ F1 module
 @pytest.mark.parametrize('name', ['plain3', 'up3', 'rgb1', 'plain3_wide', 'up3_wide'])
 def test_modulated_conv2d_module_golden(golden, name):

@@ -31,6 +31,11 @@ _SIGNATURES = {
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'te_rgb_supported': (C.c_int, [_I, _I, _I]),
+    'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
+    'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
 }
@@ -168,6 +173,38 @@ def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc
     _check(lib().te_wgrad_reduce_f32(_ptr(gw), _ptr(gisc), _ptr(gosc), _ptr(slabs), _ptr(w.contiguous()), wscale,
                                      _ptr(isc), _ptr(osc), B, S, Co, Ci, taps, _stream()), 'te_wgrad_reduce_f32')
     return gw, gisc, gosc
+
+
+# --------------------------------------------------------------------------------------------- M3
+def rgb_supported(M, K, HW):
+    return bool(lib().te_rgb_supported(M, K, HW))
+
+
+def rgb_fwd(x, w, isc, bias):
+    x = x.contiguous()
+    B, K, H, W = x.shape
+    out = torch.empty(B, 3, H, W, device=x.device, dtype=x.dtype)
+    _check(lib().te_rgb_fwd_f32(_ptr(out), _ptr(x), _ptr(w.contiguous()), _ptr(isc), _ptr(bias), B, K, H * W, _stream()),
+           'te_rgb_fwd_f32')
+    return out
+
+
+def rgb_dgrad(g, w, isc, K):
+    g = g.contiguous()
+    B, _, H, W = g.shape
+    gx = torch.empty(B, K, H, W, device=g.device, dtype=g.dtype)
+    _check(lib().te_rgb_dgrad_f32(_ptr(gx), _ptr(g), _ptr(w.contiguous()), _ptr(isc), B, K, H * W, _stream()),
+           'te_rgb_dgrad_f32')
+    return gx
+
+
+def rgb_wgrad_slabs(g, x):
+    g, x = g.contiguous(), x.contiguous()
+    B, K, H, W = x.shape
+    S = lib().te_rgb_wgrad_slab_count(B, K, H * W)
+    slabs = torch.empty(B, S, 3, K, 1, device=x.device, dtype=x.dtype)
+    _check(lib().te_rgb_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), B, K, H * W, S, _stream()), 'te_rgb_wgrad_f32')
+    return slabs
 
 
 # --------------------------------------------------------------------------------------------- F2

@@ -52,11 +52,17 @@ struct ConvArgs {
     int B, K, M, Kp, Mp;
     int Hi, Wi, Ho, Wo;      // input / output spatial size
     int H, W;                // low-resolution size (cells of T2 live on (H+1)x(W+1))
-    int ri0, rj0, rh, rw;    // cell region handled by this launch
-    int TH, TW, NS, lgTW, lgTH;
-    int tiles_x, tiles_y;    // tiles per sample group
-    int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
     int act;
+    // up to 3 cell regions share one launch (T2: main body + last output column + last output row, so the thin
+    // edge regions run concurrently with the body instead of as two nearly empty launches)
+    struct Region {
+        int ri0, rj0, rh, rw;    // cell region
+        int TH, TW, NS, lgTW, lgTH;
+        int tiles_x, tiles_y;    // tiles per sample group
+        int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
+        int first_block;         // blockIdx.x of the region's first tile
+    } reg[3];
+    int nreg;
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
@@ -90,13 +96,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
 
-    // ---- tile coordinates
-    int t = blockIdx.x;
-    const int tx_i = t % p.tiles_x; t /= p.tiles_x;
-    const int ty_i = t % p.tiles_y; t /= p.tiles_y;
-    const int b0 = t * p.NS;
+    // ---- region + tile coordinates
+    const int ridx = (p.nreg > 1 && (int)blockIdx.x >= p.reg[1].first_block) + (p.nreg > 2 && (int)blockIdx.x >= p.reg[2].first_block);
+    const ConvArgs::Region g = p.reg[ridx];
+    int t = blockIdx.x - g.first_block;
+    const int tx_i = t % g.tiles_x; t /= g.tiles_x;
+    const int ty_i = t % g.tiles_y; t /= g.tiles_y;
+    const int b0 = t * g.NS;
     const int m0 = blockIdx.y * BM;
-    const int ci0 = p.ri0 + ty_i * p.TH, cj0 = p.rj0 + tx_i * p.TW;   // first cell of the tile
+    const int ci0 = g.ri0 + ty_i * g.TH, cj0 = g.rj0 + tx_i * g.TW;   // first cell of the tile
     // origin of the input tile in input coordinates
     int oy, ox;
     if (KIND == TE_CONV_3X3) { oy = ci0 - 1; ox = cj0 - 1; }
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
     else { oy = ci0; ox = cj0; }
 
     // ---- per-thread staging descriptors (constant over the K loop)
-    const int tile_sp = p.TIH * p.TIW;
-    const int n_sp = p.NS * tile_sp;
+    const int tile_sp = g.TIH * g.TIW;
+    const int n_sp = g.NS * tile_sp;
     unsigned goff[NSP];      // byte offset of channel 0 relative to the tile's first sample, or OOBH for zero padding
     int loff[NSP], sb[NSP];  // LDS offset (or -1: no element for this thread), sample index
     const unsigned plane4 = (unsigned)p.Hi * p.Wi * 4u;
@@ -116,16 +124,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
         goff[r] = OOBH; loff[r] = -1; sb[r] = 0;
         if (e < n_sp) {
             const int s = e / tile_sp, rem = e - s * tile_sp;
-            const int ry = rem / p.TIW, rx = rem - ry * p.TIW;
+            const int ry = rem / g.TIW, rx = rem - ry * g.TIW;
             const int b = b0 + s, gy = oy + ry, gx = ox + rx;
-            loff[r] = s * p.SS + ry * p.TIWP + rx;
+            loff[r] = s * g.SS + ry * g.TIWP + rx;
             sb[r] = b < p.B ? b : 0;
             if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
                 goff[r] = (unsigned)s * p.K * plane4 + (unsigned)(gy * p.Wi + gx) * 4u;
         }
     }
     // input of the samples of this tile through one buffer descriptor: 32-bit offsets, hardware zero fill
-    const int ns_here = min(p.NS, p.B - b0);
+    const int ns_here = min(g.NS, p.B - b0);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(p.in + (size_t)b0 * p.K * p.Hi * p.Wi, (unsigned)ns_here * p.K * plane4);
 
     // ---- per-lane B-fragment base offsets (LDS floats), one per cell block
@@ -133,13 +141,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int c = wn * (NBW * 32) + nb * 32 + l31;
-        const int s = c >> (p.lgTW + p.lgTH);
-        const int ty = (c >> p.lgTW) & (p.TH - 1), tx = c & (p.TW - 1);
+        const int s = c >> (g.lgTW + g.lgTH);
+        const int ty = (c >> g.lgTW) & (g.TH - 1), tx = c & (g.TW - 1);
         int o;
-        if (KIND == TE_CONV_S2) o = 2 * ty * p.TIWP + 2 * tx;
-        else if (KIND == TE_CONV_T2) o = (ty + 1) * p.TIWP + tx + 1;
-        else o = ty * p.TIWP + tx;
-        boff[nb] = s * p.SS + o + half * p.CS;
+        if (KIND == TE_CONV_S2) o = 2 * ty * g.TIWP + 2 * tx;
+        else if (KIND == TE_CONV_T2) o = (ty + 1) * g.TIWP + tx + 1;
+        else o = ty * g.TIWP + tx;
+        boff[nb] = s * g.SS + o + half * g.CS;
     }
     const int aoff = half * BM + wm * (MBW * 32) + l31;   // A-fragment base inside wl
 
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
                 if (loff[r] >= 0) {
 #pragma unroll
                     for (int kk = 0; kk < KC; ++kk)
-                        xl[kk * p.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
+                        xl[kk * g.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
                 }
             }
             __syncthreads();
@@ -209,14 +217,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
                 const int ky = tp / 3, kx = tp % 3;
                 int toff;
                 if (KIND == TE_CONV_1X1) toff = 0;
-                else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? p.TIWP : 0) - (kx == 2 ? 1 : 0);
-                else toff = ky * p.TIWP + kx;
+                else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? g.TIWP : 0) - (kx == 2 ? 1 : 0);
+                else toff = ky * g.TIWP + kx;
                 float a[MBW];
 #pragma unroll
                 for (int mb = 0; mb < MBW; ++mb) a[mb] = wl[(tp * KC + kk) * BM + aoff + mb * 32];
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
-                    const float bv = xl[kk * p.CS + boff[nb] + toff];
+                    const float bv = xl[kk * g.CS + boff[nb] + toff];
                     const int j = IS_T2 ? nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0) : nb;
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb)
@@ -232,10 +240,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int c = wn * (NBW * 32) + nb * 32 + l31;
-        const int s = c >> (p.lgTW + p.lgTH);
-        const int ci = ci0 + ((c >> p.lgTW) & (p.TH - 1)), cj = cj0 + (c & (p.TW - 1));
+        const int s = c >> (g.lgTW + g.lgTH);
+        const int ci = ci0 + ((c >> g.lgTW) & (g.TH - 1)), cj = cj0 + (c & (g.TW - 1));
         const int b = b0 + s;
-        const bool cell_ok = b < p.B && ci < p.ri0 + p.rh && cj < p.rj0 + p.rw;
+        const bool cell_ok = b < p.B && ci < g.ri0 + g.rh && cj < g.rj0 + g.rw;
         const int bc = b < p.B ? b : p.B - 1;
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
@@ -337,49 +345,65 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     return d;
 }
 
-template <int KIND, int NBW, bool HAS_ISC, bool MS>
-int launch_region_tt(ConvArgs a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
+template <int KIND, int NBW>
+int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms) {
     if (rh <= 0 || rw <= 0) return 0;
     constexpr int NTILE = 2 * NBW * 32;
-    a.ri0 = ri0; a.rj0 = rj0; a.rh = rh; a.rw = rw;
-    a.TW = std::min(32, pow2ceil(rw));
-    a.TH = std::min(pow2ceil(rh), NTILE / a.TW);
-    a.NS = NTILE / (a.TW * a.TH);
-    a.lgTW = ilog2(a.TW); a.lgTH = ilog2(a.TH);
-    a.tiles_x = (rw + a.TW - 1) / a.TW;
-    a.tiles_y = (rh + a.TH - 1) / a.TH;
-    if (KIND == TE_CONV_3X3) { a.TIH = a.TH + 2; a.TIW = a.TW + 2; }
-    else if (KIND == TE_CONV_S2) { a.TIH = 2 * a.TH + 1; a.TIW = 2 * a.TW + 1; }
-    else if (KIND == TE_CONV_T2) { a.TIH = a.TH + 1; a.TIW = a.TW + 1; }
-    else { a.TIH = a.TH; a.TIW = a.TW; }
-    a.TIWP = a.TIW;
-    a.SS = a.TIH * a.TIWP;
-    a.CS = a.NS * a.SS;
+    ConvArgs::Region& g = a.reg[a.nreg];
+    g.ri0 = ri0; g.rj0 = rj0; g.rh = rh; g.rw = rw;
+    g.TW = std::min(32, pow2ceil(rw));
+    g.TH = std::min(pow2ceil(rh), NTILE / g.TW);
+    g.NS = NTILE / (g.TW * g.TH);
+    g.lgTW = ilog2(g.TW); g.lgTH = ilog2(g.TH);
+    g.tiles_x = (rw + g.TW - 1) / g.TW;
+    g.tiles_y = (rh + g.TH - 1) / g.TH;
+    if (KIND == TE_CONV_3X3) { g.TIH = g.TH + 2; g.TIW = g.TW + 2; }
+    else if (KIND == TE_CONV_S2) { g.TIH = 2 * g.TH + 1; g.TIW = 2 * g.TW + 1; }
+    else if (KIND == TE_CONV_T2) { g.TIH = g.TH + 1; g.TIW = g.TW + 1; }
+    else { g.TIH = g.TH; g.TIW = g.TW; }
+    g.TIWP = g.TIW;
+    g.SS = g.TIH * g.TIWP;
+    g.CS = g.NS * g.SS;
     constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
-    if ((int64_t)a.NS * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
-        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", a.NS, a.K, a.Hi, a.Wi);
-    if (a.NS * a.TIH * a.TIW > NSP * NTHREADS)
-        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", a.NS, a.TIH, a.TIW);
-    const size_t lds = sizeof(float) * ((size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * a.CS);
+    if ((int64_t)g.NS * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", g.NS, a.K, a.Hi, a.Wi);
+    if (g.NS * g.TIH * g.TIW > NSP * NTHREADS)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", g.NS, g.TIH, g.TIW);
+    g.first_block = nblocks;
+    nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NS - 1) / g.NS);
+    lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS);
+    ms = ms || g.NS > 1;
+    a.nreg++;
+    return 0;
+}
+
+template <int KIND, int NBW, bool HAS_ISC, bool MS>
+void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    const int sgroups = (a.B + a.NS - 1) / a.NS;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * sgroups), (unsigned)(a.Mp / BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS><<<grid, NTHREADS, lds, s>>>(a);
-    return 0;
+    dim3 grid((unsigned)nblocks, (unsigned)(a.Mp / BM), (unsigned)a.ksplit);
+    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
 }
 
+// regions: list of {ri0, rj0, rh, rw}
 template <int KIND, int NBW>
-int launch_region(const ConvArgs& a, int ri0, int rj0, int rh, int rw, hipStream_t s) {
-    if (rh <= 0 || rw <= 0) return 0;
-    const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), 2 * NBW * 32 / TW);
-    const bool ms = TW * TH < 2 * NBW * 32;          // several samples share one cell tile
-    if (!a.isc) return launch_region_tt<KIND, NBW, false, false>(a, ri0, rj0, rh, rw, s);
-    return ms ? launch_region_tt<KIND, NBW, true, true>(a, ri0, rj0, rh, rw, s)
-              : launch_region_tt<KIND, NBW, true, false>(a, ri0, rj0, rh, rw, s);
+int launch_regions(ConvArgs a, const int (*regions)[4], int n, hipStream_t s) {
+    int nblocks = 0;
+    size_t lds_floats = 0;
+    bool ms = false;
+    a.nreg = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = add_region<KIND, NBW>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms);
+        if (rc) return rc;
+    }
+    if (nblocks == 0) return 0;
+    if (!a.isc) launch_t<KIND, NBW, false, false>(a, nblocks, lds_floats, s);
+    else if (ms) launch_t<KIND, NBW, true, true>(a, nblocks, lds_floats, s);
+    else launch_t<KIND, NBW, true, false>(a, nblocks, lds_floats, s);
+    return 0;
 }
 
 }  // namespace
@@ -410,10 +434,15 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     ConvArgs a{};
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KC); a.Mp = roundup(M, BM); a.H = H; a.W = W;
-    // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers)
+    // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
+    // split count comes from the real tile geometry of the main region and is shared by every region launch
     {
-        const int cells = (kind == TE_CONV_T2) ? (H + 1) * (W + 1) : H * W;
-        const int64_t base_blocks = te::cdiv((int64_t)B * cells, 128) * (a.Mp / BM);
+        const bool t2 = (kind == TE_CONV_T2);
+        const int ntile = t2 ? 64 : 128;
+        int rh = H, rw = W;
+        if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
+        const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
+        const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * (a.Mp / BM);
         const int stages = a.Kp / KC;
         int ks = 1;
         if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
@@ -421,35 +450,38 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
         a.kchunk = (int)te::cdiv(stages, a.ksplit) * KC;
         a.ksplit = (int)te::cdiv(a.Kp, a.kchunk);
         if (a.ksplit > 1) {
-            const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
+            const size_t bytes = sizeof(float) * (size_t)B * M * (t2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
             hipError_t e = hipMemsetAsync(out, 0, bytes, s);
             if (e != hipSuccess) return te::fail((int)e, "te_conv_f32: hipMemsetAsync: %s", hipGetErrorString(e));
         }
     }
     int rc = 0;
     switch (kind) {
-        case TE_CONV_3X3:
+        case TE_CONV_3X3: {
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
-            rc = launch_region<TE_CONV_3X3, 2>(a, 0, 0, H, W, s);
-            break;
-        case TE_CONV_1X1:
+            const int r[1][4] = {{0, 0, H, W}};
+            rc = launch_regions<TE_CONV_3X3, 2>(a, r, 1, s);
+        } break;
+        case TE_CONV_1X1: {
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
-            rc = launch_region<TE_CONV_1X1, 2>(a, 0, 0, H, W, s);
-            break;
-        case TE_CONV_S2:
+            const int r[1][4] = {{0, 0, H, W}};
+            rc = launch_regions<TE_CONV_1X1, 2>(a, r, 1, s);
+        } break;
+        case TE_CONV_S2: {
             a.Hi = 2 * H + 1; a.Wi = 2 * W + 1; a.Ho = H; a.Wo = W;
-            rc = launch_region<TE_CONV_S2, 2>(a, 0, 0, H, W, s);
-            break;
-        case TE_CONV_T2:
+            const int r[1][4] = {{0, 0, H, W}};
+            rc = launch_regions<TE_CONV_S2, 2>(a, r, 1, s);
+        } break;
+        case TE_CONV_T2: {
             a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
             if (W + 1 <= 16 || H + 1 <= 16) {
-                rc = launch_region<TE_CONV_T2, 1>(a, 0, 0, H + 1, W + 1, s);       // small images: one padded launch
+                const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
+                rc = launch_regions<TE_CONV_T2, 1>(a, r, 1, s);
             } else {
-                rc = launch_region<TE_CONV_T2, 1>(a, 0, 0, H, W, s);               // main body
-                if (!rc) rc = launch_region<TE_CONV_T2, 1>(a, 0, W, H + 1, 1, s);   // last output column (+ corner)
-                if (!rc) rc = launch_region<TE_CONV_T2, 1>(a, H, 0, 1, W, s);       // last output row
+                const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row
+                rc = launch_regions<TE_CONV_T2, 1>(a, r, 3, s);
             }
-            break;
+        } break;
         default:
             return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     }

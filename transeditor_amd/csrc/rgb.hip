@@ -1,0 +1,173 @@
+// M3: ToRGB — 1x1 modulated convolution to 3 channels (reference: ToRGB.forward, model_spatial_query.py:416-425,
+// a grouped 1x1 F.conv2d with 3 output channels per sample).  ~1.5 FLOP/byte: HBM-bound, so these kernels are pure
+// streaming (16 B per lane, every activation element touched once) instead of a 3-of-128-rows MFMA tile.
+//
+//   fwd   : out[b,o,p] = sum_k (w[o,k] * s[b,k]) * x[b,k,p] + bias[o]
+//   dgrad : gx[b,k,p]  = s[b,k] * sum_o w[o,k] * g[b,o,p]
+//   wgrad : slab[b][c][o][k] = sum_{p in chunk c} g[b,o,p] * x[b,k,p]      (unmodulated; te_wgrad_reduce_f32 finishes)
+#include "te_common.h"
+
+namespace {
+
+constexpr int KMAX = 512;
+constexpr int NOUT = 3;
+
+__global__ __launch_bounds__(256) void rgb_fwd_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                      const float* __restrict__ w, const float* __restrict__ isc,
+                                                      const float* __restrict__ bias, int K, int HW) {
+    __shared__ float ws[NOUT][KMAX];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < K; k += 256) {
+        const float s = isc ? isc[(size_t)b * K + k] : 1.f;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) ws[o][k] = w[o * K + k] * s;
+    }
+    __syncthreads();
+    const int HW4 = HW >> 2;
+    const int p4 = blockIdx.x * 256 + tid;
+    if (p4 >= HW4) return;
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)b * K * HW) + p4;
+    float4 acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+        const float4 v = xp[(size_t)k * HW4];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float c = ws[o][k];
+            acc[o].x += c * v.x; acc[o].y += c * v.y; acc[o].z += c * v.z; acc[o].w += c * v.w;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const float bb = bias ? bias[o] : 0.f;
+        acc[o].x += bb; acc[o].y += bb; acc[o].z += bb; acc[o].w += bb;
+        reinterpret_cast<float4*>(out + ((size_t)b * NOUT + o) * HW)[p4] = acc[o];
+    }
+}
+
+__global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, const float* __restrict__ g,
+                                                        const float* __restrict__ w, const float* __restrict__ isc, int K,
+                                                        int HW) {
+    __shared__ float ws[NOUT][KMAX];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < K; k += 256) {
+        const float s = isc ? isc[(size_t)b * K + k] : 1.f;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) ws[o][k] = w[o * K + k] * s;
+    }
+    __syncthreads();
+    const int HW4 = HW >> 2;
+    const int p4 = blockIdx.x * 256 + tid;
+    if (p4 >= HW4) return;
+    float4 gv[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) gv[o] = reinterpret_cast<const float4*>(g + ((size_t)b * NOUT + o) * HW)[p4];
+    float4* op = reinterpret_cast<float4*>(gx + (size_t)b * K * HW) + p4;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        const float c0 = ws[0][k], c1 = ws[1][k], c2 = ws[2][k];
+        float4 r;
+        r.x = c0 * gv[0].x + c1 * gv[1].x + c2 * gv[2].x;
+        r.y = c0 * gv[0].y + c1 * gv[1].y + c2 * gv[2].y;
+        r.z = c0 * gv[0].z + c1 * gv[1].z + c2 * gv[2].z;
+        r.w = c0 * gv[0].w + c1 * gv[1].w + c2 * gv[2].w;
+        op[(size_t)k * HW4] = r;
+    }
+}
+
+// one block per (sample, pixel chunk); x tile [K][TP] staged in LDS (row stride TP+1: conflict-free column reads),
+// thread k accumulates its 3 dot products over the chunk's pixels
+constexpr int TP = 32;
+__global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slabs, const float* __restrict__ g,
+                                                        const float* __restrict__ x, int K, int HW, int S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xl = smem;                      // [K][TP + 1]
+    float* gl = smem + K * (TP + 1);       // [NOUT][TP]
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int ntile = (HW + TP - 1) / TP;
+    const int t0 = (int)((int64_t)ntile * c / S), t1 = (int)((int64_t)ntile * (c + 1) / S);
+    const float* xb = x + (size_t)b * K * HW;
+    const float* gb = g + (size_t)b * NOUT * HW;
+    float acc[2][NOUT] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    for (int tl = t0; tl < t1; ++tl) {
+        const int p0 = tl * TP;
+        __syncthreads();
+        for (int e = tid; e < K * TP; e += 256) {
+            const int k = e / TP, pp = e - k * TP;
+            xl[k * (TP + 1) + pp] = (p0 + pp < HW) ? xb[(size_t)k * HW + p0 + pp] : 0.f;
+        }
+        if (tid < NOUT * TP) {
+            const int o = tid / TP, pp = tid - o * TP;
+            gl[tid] = (p0 + pp < HW) ? gb[(size_t)o * HW + p0 + pp] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = tid + 256 * h;
+            if (k < K) {
+#pragma unroll 8
+                for (int pp = 0; pp < TP; ++pp) {
+                    const float xv = xl[k * (TP + 1) + pp];
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) acc[h][o] += gl[o * TP + pp] * xv;
+                }
+            }
+        }
+    }
+    float* sl = slabs + ((size_t)b * S + c) * NOUT * K;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = tid + 256 * h;
+        if (k < K) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) sl[o * K + k] = acc[h][o];
+        }
+    }
+}
+
+inline bool ok_shape(int K, int HW) { return K > 0 && K <= KMAX && HW > 0 && (HW & 3) == 0; }
+
+}  // namespace
+
+extern "C" int te_rgb_supported(int M, int K, int HW) { return (M == NOUT && ok_shape(K, HW)) ? 1 : 0; }
+
+extern "C" int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, int B, int K,
+                              int HW, te_stream_t stream_) {
+    TE_REQUIRE(out && x && w, TE_ERR_NULL, "te_rgb_fwd_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && ok_shape(K, HW), TE_ERR_UNSUPPORTED, "te_rgb_fwd_f32: need K <= 512 and H*W %% 4 == 0");
+    dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
+    rgb_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(out, x, w, isc, bias, K, HW);
+    return te::launch_status("te_rgb_fwd_f32");
+}
+
+extern "C" int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, int B, int K, int HW,
+                                te_stream_t stream_) {
+    TE_REQUIRE(gx && g && w, TE_ERR_NULL, "te_rgb_dgrad_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && ok_shape(K, HW), TE_ERR_UNSUPPORTED, "te_rgb_dgrad_f32: need K <= 512 and H*W %% 4 == 0");
+    dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
+    rgb_dgrad_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, w, isc, K, HW);
+    return te::launch_status("te_rgb_dgrad_f32");
+}
+
+extern "C" int te_rgb_wgrad_slab_count(int B, int K, int HW) {
+    if (B <= 0 || K <= 0 || HW <= 0) return TE_ERR_SHAPE;
+    const int64_t ntile = te::cdiv(HW, TP);
+    int64_t S = te::cdiv(4 * te::kNumCU, B);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(S, ntile));
+}
+
+extern "C" int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream_) {
+    TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_rgb_wgrad_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_f32: need 0 < K <= 512");
+    const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)rgb_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)S, (unsigned)B);
+    rgb_wgrad_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
+    return te::launch_status("te_rgb_wgrad_f32");
+}

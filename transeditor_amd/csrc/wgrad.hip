@@ -256,69 +256,86 @@ inline int n_cell_tiles(int kind, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------ reduce
+// Two streaming kernels over the slabs (both fully parallel, loads independent of each other):
+//   reduce_w : one thread per (co, ci, tap) element, loops over a chunk of (b, s)           -> dW
+//   reduce_sc: one block per (b, 32 output channels), threads over ci                        -> d isc, d osc
 constexpr int RTHREADS = 256;
-constexpr int COB = 4;     // output channels per block
-constexpr int BMAX = 16;   // samples per pass (register array)
+constexpr int COB = 32;    // output channels per block in reduce_sc
+
+__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_w_kernel(float* __restrict__ gw, const float* __restrict__ slabs,
+                                                                  float wscale, const float* __restrict__ isc,
+                                                                  const float* __restrict__ osc, int B, int S, int Co, int Ci,
+                                                                  int NT, int nchunk) {
+    const int64_t E = (int64_t)Co * Ci * NT;
+    const int64_t e = (int64_t)blockIdx.x * RTHREADS + threadIdx.x;
+    if (e >= E) return;
+    const int ci = (int)((e / NT) % Ci), co = (int)(e / ((int64_t)NT * Ci));
+    const int BS = B * S;
+    const int j0 = (int)((int64_t)BS * blockIdx.y / nchunk), j1 = (int)((int64_t)BS * (blockIdx.y + 1) / nchunk);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const int b = j / S;
+        float v = slabs[(size_t)j * E + e];
+        if (osc) v *= osc[(size_t)b * Co + co];
+        if (isc) v *= isc[(size_t)b * Ci + ci];
+        acc += v;
+    }
+    if (nchunk > 1) atomicAdd(gw + e, acc * wscale);
+    else gw[e] = acc * wscale;
+}
 
 template <int NT>
-__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_kernel(float* __restrict__ gw, float* __restrict__ gisc,
-                                                                float* __restrict__ gosc, const float* __restrict__ slabs,
-                                                                const float* __restrict__ w, float wscale,
-                                                                const float* __restrict__ isc, const float* __restrict__ osc,
-                                                                int B, int S, int Co, int Ci) {
-    const int ci = blockIdx.x * RTHREADS + threadIdx.x;
-    const bool live = ci < Ci;
-    const int cic = live ? ci : Ci - 1;
-    const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __restrict__ gisc, float* __restrict__ gosc,
+                                                                   const float* __restrict__ slabs, const float* __restrict__ w,
+                                                                   float wscale, const float* __restrict__ isc,
+                                                                   const float* __restrict__ osc, int B, int S, int Co, int Ci) {
+    __shared__ float red[4][COB];
+    const int b = blockIdx.x, cob = blockIdx.y * COB;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t slab_sz = (size_t)Co * Ci * NT;
-    for (int bb = 0; bb < B; bb += BMAX) {
-        const int nb = min(BMAX, B - bb);
-        float pisc[BMAX];
+    const float* sb = slabs + (size_t)b * S * slab_sz;
+    for (int c0 = 0; c0 < Ci; c0 += RTHREADS) {            // usually one pass (Ci <= 256) or two (512)
+        const int ci = c0 + threadIdx.x;
+        const bool live = ci < Ci;
+        const int cic = live ? ci : Ci - 1;
+        const float is = isc ? isc[(size_t)b * Ci + cic] : 1.f;
+        float pisc = 0.f;
+        float posc[COB];
 #pragma unroll
-        for (int i = 0; i < BMAX; ++i) pisc[i] = 0.f;
-        for (int co = blockIdx.y * COB; co < min(Co, (int)(blockIdx.y + 1) * COB); ++co) {
-            float wv[NT], gacc[NT];
+        for (int j = 0; j < COB; ++j) {
+            const int co = cob + j;
+            float dot = 0.f;
+            if (co < Co) {
+                const size_t off = ((size_t)co * Ci + cic) * NT;
+                float sl[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { wv[t] = w[((size_t)co * Ci + cic) * NT + t] * wscale; gacc[t] = 0.f; }
+                for (int t = 0; t < NT; ++t) sl[t] = 0.f;
+                for (int s = 0; s < S; ++s) {
 #pragma unroll
-            for (int i = 0; i < BMAX; ++i) {
-                if (i < nb) {
-                    const int b = bb + i;
-                    float sl[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) sl[t] = 0.f;
-                    for (int s = 0; s < S; ++s) {
-                        const float* src = slabs + ((size_t)b * S + s) * slab_sz + ((size_t)co * Ci + cic) * NT;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) sl[t] += src[t];
-                    }
-                    const float os = osc ? osc[(size_t)b * Co + co] : 1.f;
-                    const float is = isc ? isc[(size_t)b * Ci + cic] : 1.f;
-                    float dot = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) { gacc[t] += os * is * sl[t]; dot += wv[t] * sl[t]; }
-                    pisc[i] += os * dot;
-                    if (gosc) {
-                        float po = live ? is * dot : 0.f;
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) po += __shfl_down(po, off, 64);
-                        if (lane == 0) atomicAdd(gosc + (size_t)b * Co + co, po);
-                    }
+                    for (int t = 0; t < NT; ++t) sl[t] += sb[(size_t)s * slab_sz + off + t];
                 }
-            }
-            if (gw && live) {
-                // several passes over b (B > BMAX) accumulate; the first pass overwrites
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    float* dst = gw + ((size_t)co * Ci + ci) * NT + t;
-                    *dst = (bb == 0 ? 0.f : *dst) + gacc[t] * wscale;
-                }
+                for (int t = 0; t < NT; ++t) dot += w[off + t] * sl[t];
+                dot *= wscale;
+                pisc += (osc ? osc[(size_t)b * Co + co] : 1.f) * dot;
             }
+            posc[j] = live ? is * dot : 0.f;
         }
-        if (gisc && live) {
+        if (gisc && live) atomicAdd(gisc + (size_t)b * Ci + ci, pisc);
+        if (gosc) {
 #pragma unroll
-            for (int i = 0; i < BMAX; ++i)
-                if (i < nb) atomicAdd(gisc + (size_t)(bb + i) * Ci + ci, pisc[i]);
+            for (int j = 0; j < COB; ++j) {
+                float v = posc[j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+                if (lane == 0) red[wid][j] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < COB && cob + threadIdx.x < Co)
+                atomicAdd(gosc + (size_t)b * Co + cob + threadIdx.x,
+                          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+            __syncthreads();
         }
     }
 }
@@ -360,9 +377,22 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
                                    te_stream_t stream_) {
     TE_REQUIRE(slabs && w, TE_ERR_NULL, "te_wgrad_reduce_f32: NULL pointer");
     TE_REQUIRE(B > 0 && S > 0 && Co > 0 && Ci > 0 && (taps == 1 || taps == 9), TE_ERR_SHAPE, "te_wgrad_reduce_f32: bad dims");
-    dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)te::cdiv(Co, COB));
     hipStream_t s = (hipStream_t)stream_;
-    if (taps == 9) wgrad_reduce_kernel<9><<<grid, RTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
-    else wgrad_reduce_kernel<1><<<grid, RTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+    if (gw) {
+        const int64_t E = (int64_t)Co * Ci * taps;
+        const int64_t blocks = te::cdiv(E, RTHREADS);
+        int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * S, te::cdiv(2 * te::kNumCU, blocks)));
+        if (nchunk > 1) {
+            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * E, s);
+            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        wgrad_reduce_w_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S, Co,
+                                                                                          Ci, taps, nchunk);
+    }
+    if (gisc || gosc) {
+        dim3 grid((unsigned)B, (unsigned)te::cdiv(Co, COB));
+        if (taps == 9) wgrad_reduce_sc_kernel<9><<<grid, RTHREADS, 0, s>>>(gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        else wgrad_reduce_sc_kernel<1><<<grid, RTHREADS, 0, s>>>(gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+    }
     return te::launch_status("te_wgrad_reduce_f32");
 }

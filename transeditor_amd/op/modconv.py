@@ -128,6 +128,14 @@ def _composite(x, w, isc, osc, bias, act, kind):
 class _ModConvFused(Function):
     @staticmethod
     def forward(ctx, x, w, isc, osc, bias, act, kind):
+        # ToRGB (1x1 to 3 channels, no demodulation / activation) is HBM-bound: dedicated streaming kernels
+        ctx.rgb = (kind == '1x1' and osc is None and not act
+                   and _lib.rgb_supported(w.shape[0], w.shape[1], x.shape[2] * x.shape[3]))
+        if ctx.rgb:
+            out = _lib.rgb_fwd(x, w.reshape(w.shape[0], w.shape[1]), isc, bias)
+            ctx.save_for_backward(x, w, isc, osc, bias, None)
+            ctx.act, ctx.kind = act, kind
+            return out
         out = _fwd_raw(x, w, kind, isc, osc, bias, 3 if act else 0)
         ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
         ctx.act, ctx.kind = act, kind
@@ -156,10 +164,13 @@ class _ModConvFused(Function):
             g, g_bias = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=bias is not None)
         elif bias is not None and need[4]:
             g_bias = g.sum(dim=(0, 2, 3))
-        gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc) if need[0] else None
+        if ctx.rgb:
+            gx = _lib.rgb_dgrad(g, w.reshape(w.shape[0], w.shape[1]), isc, x.shape[1]) if need[0] else None
+        else:
+            gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc) if need[0] else None
         gw = gisc = gosc = None
         if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
-            slabs = _wgrad_raw(g, x, kind)
+            slabs = _lib.rgb_wgrad_slabs(g, x) if ctx.rgb else _wgrad_raw(g, x, kind)
             gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), 1.0, isc, osc,
                                                want_w=need[1], want_isc=need[2] and isc is not None,
                                                want_osc=need[3] and osc is not None)
