@@ -34,6 +34,12 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def rel_l2(a, b):
+    """relative L2 error: robust against the few leaky-ReLU slope flips that separate two correct fp32 runs"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 @pytest.fixture(scope='session')
 def golden():
     cache = {}

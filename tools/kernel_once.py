@@ -1,0 +1,54 @@
+"""Launch every hot kernel a few times at its FFHQ-256 / batch-16 top shape (for rocprofv3 --pmc runs)."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transeditor_amd import _lib  # noqa: E402
+
+DEV, B = 'cuda', 16
+REP = int(os.environ.get('REP', '3'))
+
+
+def main():
+    x = torch.randn(B, 128, 256, 256, device=DEV)
+    w = torch.randn(128, 128, 3, 3, device=DEV) / 34
+    isc, osc, bias = torch.rand(B, 128, device=DEV) + 0.5, torch.rand(B, 128, device=DEV) + 0.5, torch.randn(128, device=DEV)
+    wp = _lib.conv_pack(w, _lib.PACK_FWD)
+    for _ in range(REP):
+        y = _lib.conv(x, wp, _lib.CONV_3X3, 128, 256, 256, isc, osc, bias, 3)         # conv3x3 fwd (fused epilogue)
+    for _ in range(REP):
+        sl = _lib.wgrad_slabs(y, x, _lib.CONV_3X3, 256, 256)                           # wgrad 3x3
+    for _ in range(REP):
+        _lib.wgrad_reduce(sl, w.reshape(128, 128, 9), 1.0, isc, osc, True, True, True)
+    xl = torch.randn(B, 256, 128, 128, device=DEV)
+    wu = torch.randn(128, 256, 3, 3, device=DEV) / 48
+    iscu = torch.rand(B, 256, device=DEV) + 0.5
+    wpu = _lib.conv_pack(wu, _lib.PACK_FWD)
+    for _ in range(REP):
+        t = _lib.conv(xl, wpu, _lib.CONV_T2, 128, 128, 128, iscu, osc)                 # T2 fwd -> [B,128,257,257]
+    wps = _lib.conv_pack(wu, _lib.PACK_SWAP)
+    for _ in range(REP):
+        _lib.conv(t, wps, _lib.CONV_S2, 256, 128, 128, osc, iscu)                      # S2 (dgrad of T2)
+    for _ in range(REP):
+        _lib.wgrad_slabs(t, xl, _lib.CONV_T2, 128, 128)                                # wgrad T2
+    k = torch.tensor([1., 3., 3., 1.], device=DEV)
+    k = torch.outer(k, k) / 16
+    for _ in range(REP):
+        _lib.upfirdn2d_raw(t, k, (1, 1), (1, 1), (1, 1, 1, 1), bias=bias, act=3, scale=2 ** 0.5)   # blur + bias + act
+    for _ in range(REP):
+        _lib.bias_act_bwd(x, y, 0.2, 2 ** 0.5)
+    wr = torch.randn(3, 128, device=DEV)
+    for _ in range(REP):
+        r = _lib.rgb_fwd(x, wr, isc, bias[:3].contiguous())
+    for _ in range(REP):
+        _lib.rgb_dgrad(r, wr, isc, 128)
+    for _ in range(REP):
+        _lib.rgb_wgrad_slabs(r, x)
+    torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    main()

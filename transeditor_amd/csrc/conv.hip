@@ -23,6 +23,7 @@
 //        receives only the taps with ky = a (mod 2), kx = b (mod 2) -> 4+2+2+1 = 9 tap-GEMMs per cell,
 //        i.e. exactly the FLOPs of the zero-insertion-free transposed convolution.
 #include "te_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -75,8 +76,8 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
 // MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
-template <int KIND, int NBW, bool HAS_ISC, bool MS>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_mfma_kernel(const ConvArgs p) {
+template <int KIND, int NBW, bool HAS_ISC, bool MS, int OCC>
+__global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
     constexpr int MBW = 2;
     constexpr int NTAP = Kind<KIND>::NT;
     constexpr bool IS_T2 = (KIND == TE_CONV_T2);
@@ -377,15 +378,28 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     return 0;
 }
 
-template <int KIND, int NBW, bool HAS_ISC, bool MS>
-void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+inline int conv_occ() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TE_CONV_OCC"); v = (e && atoi(e) == 2) ? 2 : 3; }
+    return v;
+}
+
+template <int KIND, int NBW, bool HAS_ISC, bool MS, int OCC>
+void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC, MS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     dim3 grid((unsigned)nblocks, (unsigned)(a.Mp / BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+}
+
+template <int KIND, int NBW, bool HAS_ISC, bool MS>
+void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+    // 3 waves/SIMD variant only for the plain 3x3 (the only kind whose register budget is close to 168)
+    if (KIND == TE_CONV_3X3 && !MS && conv_occ() == 3) launch_o<KIND, NBW, HAS_ISC, MS, (KIND == TE_CONV_3X3 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
+    else launch_o<KIND, NBW, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
 }
 
 // regions: list of {ri0, rj0, rh, rw}

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     constexpr int TIWP = (TIW + 3) & ~3;  // row stride, multiple of 4 floats
     constexpr int NTY = (KH + UP - 1) / UP, NTX = (KW + UP - 1) / UP;
     static_assert(KH % UP == 0 && KW % UP == 0, "taps must split evenly over the upsampling phases");
-    __shared__ float sx[TIH * TIWP];
+    __shared__ __attribute__((aligned(16))) float sx[TIH * TIWP + 4];
     __shared__ float sk[KH * KW];
 
     // flipped taps: registers for UP == 1 (compile-time indices), LDS when the phase selects them at run time
@@ -73,11 +73,27 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
         __syncthreads();
         const int oy = oy0 + ty;
         if (oy < p.out_h) {
+            float res[4];
+            if constexpr (UP == 1 && DOWN == 1 && KH == 4 && KW == 4) {
+                // blur fast path: the 4 outputs of this lane need the 4 x 7 window sx[ty..ty+3][tx..tx+6]; read it as
+                // two aligned 16-byte LDS loads per row (8 ds_read_b128 instead of 64 conflicting ds_read_b32)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[q] = 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(&sx[(ty + a) * TIWP + tx]);
+                    const float4 w1 = *reinterpret_cast<const float4*>(&sx[(ty + a) * TIWP + tx + 4]);
+                    const float win[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) res[q] += win[q + c] * kf[a][c];
+                }
+            } else {
             const int mid_y = mid_y0 + ty * DOWN;
             const int iy = fdiv(mid_y, UP);
             const int jy = (iy + 1) * UP - mid_y - 1;
             const int ry = iy - iy0;
-            float res[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mid_x = mid_x0 + (tx + q) * DOWN;
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
                         acc += sx[(ry + a) * TIWP + rx + c] * w;
                     }
                 res[q] = acc;
+            }
             }
             float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
             const int ch = b ? (int)(mj % p.size_b) : 0;

@@ -16,13 +16,13 @@
 // LDS tiles are [channel][position] with an ODD channel stride, so the 32 lanes of an MFMA operand read
 // (32 different channels, same position) hit 32 different banks.
 #include "te_common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int NTHREADS = 512;   // 8 waves: 4 (plain-operand channel blocks) x 2 (shifted-operand channel blocks)
-constexpr int PCH = 128;        // channels of the plain operand per block
-constexpr int QCH = 64;         // channels of the shifted operand per block
+constexpr int QCH = 64;         // channels of the shifted operand per block (2 waves)
+// NWP waves along the plain operand's channels (4 -> 512 threads, 128 x 64 tile; 2 -> 256 threads, 64 x 64 tile)
 constexpr unsigned OOB = 0x80000000u;   // buffer offset beyond num_records: the load returns 0
 
 struct WgArgs {
@@ -40,9 +40,10 @@ struct WgArgs {
 };
 
 template <int KIND> struct WK;
-template <> struct WK<TE_CONV_3X3> { static constexpr int NT = 9, NCELL = 64, NP = 16, NQ = 17; };
-template <> struct WK<TE_CONV_1X1> { static constexpr int NT = 1, NCELL = 64, NP = 16, NQ = 8; };
-template <> struct WK<TE_CONV_T2>  { static constexpr int NT = 9, NCELL = 32, NP = 8,  NQ = 25; };
+// NP = plain elements per thread = 32*NCELL/128 (independent of NWP); NQ8 = shifted elements per thread at 512 threads
+template <> struct WK<TE_CONV_3X3> { static constexpr int NT = 9, NCELL = 64, NP = 16, NQ8 = 17; };
+template <> struct WK<TE_CONV_1X1> { static constexpr int NT = 1, NCELL = 64, NP = 16, NQ8 = 8; };
+template <> struct WK<TE_CONV_T2>  { static constexpr int NT = 9, NCELL = 32, NP = 8,  NQ8 = 25; };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
@@ -51,12 +52,14 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-template <int KIND>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_mfma_kernel(const WgArgs p) {
+template <int KIND, int NWP>
+__global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p) {
+    constexpr int NTHREADS = NWP * 128;
+    constexpr int PCH = NWP * 32;
     constexpr int NT = WK<KIND>::NT;
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);   // which operand carries the tap shift
     constexpr int NP = WK<KIND>::NP;                // plain-tile elements per thread   (PCH*NC / 512)
-    constexpr int NQ = WK<KIND>::NQ;                // shifted-tile elements per thread (>= QCH*QH*QW / 512)
+    constexpr int NQ = (WK<KIND>::NQ8 * 512 + NTHREADS - 1) / NTHREADS;   // shifted-tile elements per thread
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* pl = smem;                      // plain operand   [PCH][PS]
@@ -228,7 +231,27 @@ bool fill_geometry(WgArgs& a) {
     a.PS = a.NC | 1;
     a.magic_qt = magic((unsigned)(a.QH * a.QW));
     a.magic_qw = magic((unsigned)a.QW);
-    return QCH * a.QH * a.QW <= WK<KIND>::NQ * NTHREADS && PCH * a.NC <= WK<KIND>::NP * NTHREADS;
+    return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
+}
+
+inline int wgrad_nwp() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TE_WGRAD_NWP"); v = (e && atoi(e) == 2) ? 2 : 4; }
+    return v;
+}
+
+template <int KIND, int NWP>
+void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
+    constexpr int PCH = NWP * 32;
+    const size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    constexpr bool GSHIFT = (KIND == TE_CONV_T2);
+    dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
+    wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);
 }
 
 template <int KIND>
@@ -236,15 +259,8 @@ int launch_wgrad(WgArgs a, hipStream_t s) {
     if (!fill_geometry<KIND>(a)) return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: unsupported image size %dx%d", a.H, a.W);
     if ((int64_t)a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
         return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: per-sample tensor exceeds 2 GiB");
-    const size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
-    constexpr bool GSHIFT = (KIND == TE_CONV_T2);
-    dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
-    wgrad_mfma_kernel<KIND><<<grid, NTHREADS, lds, s>>>(a);
+    if (wgrad_nwp() == 2) launch_wgrad_t<KIND, 2>(a, s);
+    else launch_wgrad_t<KIND, 4>(a, s);
     return 0;
 }
 
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
-    const int64_t mn = te::cdiv((int64_t)Co * Ci, PCH * QCH) * (int64_t)B;
+    const int64_t mn = te::cdiv((int64_t)Co * Ci, (wgrad_nwp() * 32) * QCH) * (int64_t)B;
     int64_t S = te::cdiv(2 * te::kNumCU, mn);     // aim at >= 2 blocks (of 8 waves) per CU
     S = std::max<int64_t>(1, std::min<int64_t>(S, tiles));
     return (int)S;

@@ -448,6 +448,24 @@ class Discriminator(nn.Module):                                                 
         return self.final_linear(out.view(batch, -1))
 
 
+_WIDE = 384
+
+
+def _wide_linear(x, weight, bias):
+    """F.linear for a narrow layer, evaluated as a zero-padded >= 384-wide GEMM (padding sliced off again).
+    hipBLASLt's heuristic picks a single 128x256 macro-tile for [256, 512] x [512, 128 | 256] (61 / 118 us measured
+    on MI355X, one workgroup) but a well-parallelised kernel from 384 columns on (<= 19 us, launch-bound); the
+    padding makes forward, dx and dW all land on the fast shapes.  Mathematically exact (zeros contribute 0)."""
+    out_f, in_f = weight.shape
+    if in_f < _WIDE:
+        x = F.pad(x, (0, _WIDE - in_f))
+        weight = F.pad(weight, (0, _WIDE - in_f))
+    if out_f < _WIDE:
+        weight = F.pad(weight, (0, 0, 0, _WIDE - out_f))
+    y = F.linear(x, weight)[..., :out_f]
+    return y if bias is None else y + bias
+
+
 class Attention(nn.Module):                                                          # :862-901
     def __init__(self, in_dim, param_dim, out_dim, lr_mul=1.0, groups=4, compress=4):
         assert out_dim % (groups * compress) == 0
@@ -463,13 +481,16 @@ class Attention(nn.Module):                                                     
         self.proj = EqualLinear(self.planes, out_dim, lr_mul=lr_mul)
 
     def forward(self, attention, op_param, return_similarity=False):
-        q = self.q_transform(op_param)            # [N, M, planes]; head g owns channels g*gp .. (g+1)*gp
-        k = self.k_transform(attention)
-        v = self.v_transform(attention)
+        # q/k/v/proj are 128-wide: evaluated through _wide_linear (k and v share one GEMM); same math as the
+        # EqualLinear modules (weight * scale, bias * lr_mul), whose parameters stay the state_dict entries
+        qt, kt, vt, pt = self.q_transform, self.k_transform, self.v_transform, self.proj
+        q = _wide_linear(op_param, qt.weight * qt.scale, qt.bias * qt.lr_mul)   # [N, M, planes]; head g = channels g*gp..
+        kv = _wide_linear(attention, torch.cat([kt.weight, vt.weight]) * kt.scale, torch.cat([kt.bias, vt.bias]) * kt.lr_mul)
+        k, v = kv[..., :self.planes], kv[..., self.planes:]
         # softmax(scale q k^T) v per head; the reference's reshape(N, planes, L).permute(0,2,1) (:894, with
         # L == M) lands exactly on this token-major [N, M, planes] layout
         stacked, similarity = attention_core(q, k, v, self.scale, self.groups)
-        output = self.proj(stacked)
+        output = _wide_linear(stacked, pt.weight * pt.scale, pt.bias * pt.lr_mul)
         return (output, similarity) if return_similarity else output
 
 
