@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--workload', choices=['generator', 'train'], default='generator',
+                    help='generator = BASELINE configs[1] (default, the driver contract); train = configs[2]/[3] full G+D step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     return ap.parse_args()
@@ -155,6 +157,50 @@ def main():
     timer = KernelTimer()
     if not args.no_kernel_timing:
         timer.install()
+
+    if args.workload == 'train':
+        # BASELINE configs[2] (N = 1) / configs[3] (N > 1): full train_spatial_query step with lazy R1 (1/16) and
+        # path-length (1/4) regularisers on synthetic "real" images; --steps should be a multiple of 16
+        from transeditor_amd.train_step import TrainStep, default_args
+        targs = default_args(size=size, batch=B)
+        ts = TrainStep(targs, dev, generator=G)
+        reals = [torch.randn(B, 3, size, size, device=dev).clamp(-1, 1) for _ in range(4)]
+        it = [0]
+
+        def train_iter(_):
+            ts.iteration(it[0], reals[it[0] % 4])
+            it[0] += 1
+        for i in range(args.warmup):
+            train_iter(i)
+        it[0] = 0
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            train_iter(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            print(json.dumps({
+                'metric': '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling',
+                'value': world * B * args.steps / elapsed, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': f'FFHQ-{size} full G+D train step (BASELINE configs[2]/[3]): D step, R1 every 16, G step, '
+                                       f'path-length reg every 4 on batch {B // 2}, Adam, EMA; batch {B}/GPU',
+                           'global_batch': world * B, 'parallelism': f'dp{world}'}}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     def step(i):
         for p in params:

@@ -289,6 +289,89 @@ def gen_schema(M):
     npz('state_dict_schema', **d)
 
 
+TRAIN_SIZE, TRAIN_BATCH = 32, 4
+TRAIN_PROBES = {'g': ['adjust_style.weight', 'conv1.activate.bias', 'to_rgb1.bias', 'interact.3.mlp.0.bias',
+                      'convs.5.conv.modulation.bias'],
+                'd': ['final_linear.1.weight', 'convs.0.1.bias', 'convs.2.conv1.1.bias']}
+
+
+def train_draws():
+    """Deterministic stand-ins for the random draws of ONE iteration, in the order the loop consumes them."""
+    return {'d': synth.latents(TRAIN_BATCH, 7000), 'g': synth.latents(TRAIN_BATCH, 7001),
+            'path': synth.latents(TRAIN_BATCH // 2, 7002),
+            'pl_noise': synth.normal((TRAIN_BATCH // 2, 3, TRAIN_SIZE, TRAIN_SIZE), 'train.pl'),
+            'real': synth.normal((TRAIN_BATCH, 3, TRAIN_SIZE, TRAIN_SIZE), 'train.real').clamp(-1, 1)}
+
+
+def gen_train_step(M):
+    """One iteration (i = 0: lazy R1 and path-length regularisers both fire) of the reference loop,
+    train_spatial_query.py:166-294, driven with the reference's own models, losses and EMA; Adam as :458-473."""
+    T = ref_import.reference_train_functions()
+    token = 2 * (int(math.log2(TRAIN_SIZE)) - 1)
+    mk = lambda: M.Generator(TRAIN_SIZE, 512, 512, token, n_trans=8, pixel_norm_op_dim=1)
+    G, g_ema, Dn = mk(), mk(), M.Discriminator(TRAIN_SIZE)
+    synth.fill_state_dict(G.state_dict(), 40)
+    synth.fill_state_dict(Dn.state_dict(), 41)
+    g_ema.eval()
+    T.accumulate(g_ema, G, 0)
+    r1, path_regularize, d_reg_every, g_reg_every, shrink, lr = 10.0, 2.0, 16, 4, 2, 0.002
+    gr, dr = g_reg_every / (g_reg_every + 1), d_reg_every / (d_reg_every + 1)
+    g_optim = torch.optim.Adam(G.parameters(), lr=lr * gr, betas=(0 ** gr, 0.99 ** gr))
+    d_optim = torch.optim.Adam(Dn.parameters(), lr=lr * dr, betas=(0 ** dr, 0.99 ** dr))
+    dr_ = train_draws()
+    real_img = dr_['real']
+    out = {}
+    # D step :173-194
+    T.requires_grad(G, False)
+    T.requires_grad(Dn, True)
+    fake_img, _, _ = G(*dr_['d'])
+    fake_pred, real_pred = Dn(fake_img), Dn(real_img)
+    d_loss = T.d_logistic_loss(real_pred, fake_pred)
+    out.update(d=d_loss, real_score=real_pred.mean(), fake_score=fake_pred.mean())
+    Dn.zero_grad()
+    d_loss.backward()
+    d_optim.step()
+    # R1 :196-206
+    real_img.requires_grad = True
+    real_pred = Dn(real_img)
+    r1_loss = T.d_r1_loss(real_pred, real_img)
+    Dn.zero_grad()
+    (r1 / 2 * r1_loss * d_reg_every + 0 * real_pred[0]).backward()
+    d_optim.step()
+    out['r1'] = r1_loss
+    # G step :210-224
+    T.requires_grad(G, True)
+    T.requires_grad(Dn, False)
+    fake_img, _, _ = G(*dr_['g'])
+    g_loss = T.g_nonsaturating_loss(Dn(fake_img))
+    out['g'] = g_loss
+    G.zero_grad()
+    g_loss.backward()
+    g_optim.step()
+    # path-length regulariser :226-250 (torch.randn_like replaced by the deterministic draw)
+    fake_img, latents, _ = G(*dr_['path'], return_latents=True)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: dr_['pl_noise'].to(t)
+    try:
+        path_loss, mean_path_length, path_lengths = T.g_path_regularize(fake_img, latents, 0)
+    finally:
+        torch.randn_like = orig
+    G.zero_grad()
+    weighted = path_regularize * g_reg_every * path_loss + 0 * fake_img[0, 0, 0, 0]
+    weighted.backward()
+    g_optim.step()
+    out.update(path=path_loss, path_length=path_lengths.mean(), mean_path_length=mean_path_length)
+    T.accumulate(g_ema, G, 0.5 ** (32 / (10 * 1000)))                  # :294
+    for tag, mod in (('g', G), ('d', Dn), ('ema', g_ema)):
+        sd = dict(mod.named_parameters())
+        out[f'{tag}.abs_sum'] = np.array(sum(float(v.detach().double().abs().sum()) for v in sd.values()))
+        for name in TRAIN_PROBES['d' if tag == 'd' else 'g']:
+            out[f'{tag}.{name}'] = sd[name].detach()
+    npz('train_step32_b4', **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
+    REPORT.append('train step (i=0, 32 px, batch 4): ' + ', '.join(
+        f'{k}={float(out[k]):.5f}' for k in ('d', 'r1', 'g', 'path', 'path_length', 'mean_path_length')))
+
+
 def main():
     assert ref_import.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
@@ -298,6 +381,7 @@ def main():
     gen_ops(M)
     gen_generator(M)
     gen_discriminator(M)
+    gen_train_step(M)
     with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:
         f.write('golden fixtures generated by oracle/gen_golden.py from the imported reference\n')
         f.write(f'torch {torch.__version__}, numpy {np.__version__}\n')

@@ -51,6 +51,22 @@ def reference_upfirdn2d():
     return upfirdn2d
 
 
+def reference_train_functions():
+    """The loss / bookkeeping functions of the reference's train_spatial_query.py (:49-105), executed from the
+    reference's own file via AST (the module itself imports torchvision / tensorboard / lmdb at top level)."""
+    import ast
+    import math
+    import torch.nn.functional as F
+    from torch import autograd
+    path = os.path.join(REF_ROOT, 'train_spatial_query.py')
+    tree = ast.parse(open(path).read())
+    want = {'requires_grad', 'accumulate', 'd_logistic_loss', 'd_r1_loss', 'g_nonsaturating_loss', 'g_path_regularize'}
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    ns = {'torch': torch, 'F': F, 'autograd': autograd, 'math': math}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    return types.SimpleNamespace(**{k: ns[k] for k in want})
+
+
 def import_reference():
     if 'model_spatial_query' in sys.modules and getattr(sys.modules['model_spatial_query'], '_te_ref', False):
         return sys.modules['model_spatial_query']

@@ -125,3 +125,25 @@ def test_generator_ctor_surface():
     assert g.n_latent == 8 and g.num_layers == 7 and len(g.convs) == 6 and len(g.to_rgbs) == 3
     assert list(inspect.signature(ModulatedConv2d.__init__).parameters)[1:9] == [
         'in_channel', 'out_channel', 'kernel_size', 'style_dim', 'demodulate', 'upsample', 'downsample', 'blur_kernel']
+
+
+def test_train_step_losses_match_oracle_on_cpu():
+    """Loss formulas of the train-step harness (pure torch) against the oracle's restatement."""
+    from oracle import te_oracle as O
+    from transeditor_amd import synth, train_step as T
+    rp, fp = synth.normal((6, 1), 'l.r'), synth.normal((6, 1), 'l.f')
+    assert torch.allclose(T.d_logistic_loss(rp, fp), O.d_logistic_loss(rp, fp))
+    assert torch.allclose(T.g_nonsaturating_loss(fp), O.g_nonsaturating_loss(fp))
+    lat = synth.normal((2, 4, 8), 'l.lat').requires_grad_(True)
+    A = synth.normal((8, 3 * 4 * 4), 'l.A')
+    img = torch.tanh(lat.sum(1) @ A).reshape(2, 3, 4, 4)
+    noise = synth.normal((2, 3, 4, 4), 'l.n')
+    a = T.g_path_regularize(img, lat, 0.0, noise)
+    b = O.g_path_regularize(img, lat, 0.0, noise / 4.0)
+    assert torch.allclose(a[0], b[0]) and torch.allclose(a[2], b[2])
+    m1, m2 = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+    w1, w2 = m1.weight.detach().clone(), m2.weight.detach().clone()
+    T.accumulate(m1, m2, 0.9)
+    assert torch.allclose(m1.weight, 0.9 * w1 + 0.1 * w2)
+    args = T.default_args(size=64)
+    assert args.token == 10 and args.d_reg_every == 16 and args.g_reg_every == 4

@@ -115,10 +115,17 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             }
             float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
             const int ch = b ? (int)(mj % p.size_b) : 0;
+            if ((p.out_w & 3) == 0 && ox0 + tx + 3 < p.out_w) {      // rows 16-byte aligned: one 16-byte store per lane
+                float4 v;
+                v.x = epilogue(res[0], b, ch, p); v.y = epilogue(res[1], b, ch, p);
+                v.z = epilogue(res[2], b, ch, p); v.w = epilogue(res[3], b, ch, p);
+                *reinterpret_cast<float4*>(orow + ox0 + tx) = v;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ox = ox0 + tx + q;
-                if (ox < p.out_w) orow[ox] = epilogue(res[q], b, ch, p);
+                for (int q = 0; q < 4; ++q) {
+                    const int ox = ox0 + tx + q;
+                    if (ox < p.out_w) orow[ox] = epilogue(res[q], b, ch, p);
+                }
             }
         }
     }

@@ -1,0 +1,179 @@
+"""One TransEditor training iteration on the MI355X path (BASELINE configs 3 and 4).
+
+Semantics follow the reference's `train()` loop, train_spatial_query.py:166-294 (losses :70-105, optimiser
+setup :458-473, EMA :56-61), restated as a small class instead of one long function:
+
+    D step      G frozen -> fake batch (no graph) ; softplus logistic loss on D(fake), D(real)           :173-194
+    R1          every d_reg_every: ||dD(real)/dreal||^2, weighted r1/2 * d_reg_every (+ 0 * real_pred[0])   :196-206
+    G step      D frozen -> non-saturating loss                                                            :210-224
+    path reg    every g_reg_every on batch // path_batch_shrink: path-length penalty (double backward)     :226-250
+    EMA         g_ema <- decay * g_ema + (1 - decay) * g,  decay = 0.5 ** (32 / 10000)                     :294
+
+Data parallelism (config 4): one process per GPU, `GradSync` mean all-reduce of the gradients after every
+backward (what the reference's two DDP wrappers do, :494-509) and the scalar collectives of utils/distributed.
+`--spatial_regu` (off in every BASELINE config) is not built.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import autograd, optim
+from torch.nn import functional as F
+
+from .model_spatial_query import Discriminator, Generator
+from .utils import distributed as D
+from .utils.sample import prepare_noise_new, prepare_param
+
+
+def default_args(**kw):
+    """The reference's CLI defaults that matter for one iteration (train_spatial_query.py:377-433)."""
+    a = dict(size=256, batch=16, para_num=16, latent=512, r1=10.0, path_regularize=2.0, path_batch_shrink=2,
+             d_reg_every=16, g_reg_every=4, lr=0.002, channel_multiplier=2, num_trans=8, pixel_norm_op_dim=1)
+    a.update(kw)
+    a['token'] = 2 * (int(math.log2(a['size'])) - 1)
+    return SimpleNamespace(**a)
+
+
+def d_logistic_loss(real_pred, fake_pred):                                   # :70-74
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+
+def d_r1_loss(real_pred, real_img):                                          # :77-83
+    grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+def g_nonsaturating_loss(fake_pred):                                         # :86-89
+    return F.softplus(-fake_pred).mean()
+
+
+def g_path_regularize(fake_img, latents, mean_path_length, noise, decay=0.01):   # :92-105 (noise = randn_like(img))
+    noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
+    grad, = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
+    path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
+    path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
+    path_penalty = (path_lengths - path_mean).pow(2).mean()
+    return path_penalty, path_mean.detach(), path_lengths
+
+
+def requires_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def accumulate(model1, model2, decay=0.999):                                 # :56-61, as one fused multi-tensor update
+    p1 = dict(model1.named_parameters())
+    p2 = dict(model2.named_parameters())
+    names = list(p1.keys())
+    with torch.no_grad():
+        torch._foreach_mul_([p1[k] for k in names], decay)
+        torch._foreach_add_([p1[k] for k in names], [p2[k] for k in names], alpha=1 - decay)
+
+
+class RandomSampler:
+    """Random draws of one iteration; tests substitute a deterministic one."""
+
+    def __init__(self, args, device):
+        self.args, self.device = args, device
+
+    def latents(self, n):
+        return (prepare_noise_new(n, self.args, self.device, method='query'),
+                prepare_param(n, self.args, self.device, method='spatial'))
+
+    def randn_like(self, t):
+        return torch.randn_like(t)
+
+
+class TrainStep:
+    def __init__(self, args, device, generator=None, discriminator=None, sampler=None):
+        self.args, self.device = args, device
+        mk = lambda: Generator(args.size, args.latent, args.latent, args.token, channel_multiplier=args.channel_multiplier,
+                               n_trans=args.num_trans, pixel_norm_op_dim=args.pixel_norm_op_dim).to(device)
+        self.generator = generator if generator is not None else mk()
+        self.discriminator = (discriminator if discriminator is not None
+                              else Discriminator(args.size, channel_multiplier=args.channel_multiplier).to(device))
+        self.g_ema = mk()
+        self.g_ema.eval()
+        accumulate(self.g_ema, self.generator, 0)                            # :455
+        g_ratio = args.g_reg_every / (args.g_reg_every + 1)
+        d_ratio = args.d_reg_every / (args.d_reg_every + 1)
+        self.g_optim = optim.Adam(self.generator.parameters(), lr=args.lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
+        self.d_optim = optim.Adam(self.discriminator.parameters(), lr=args.lr * d_ratio,
+                                  betas=(0 ** d_ratio, 0.99 ** d_ratio))
+        self.sampler = sampler if sampler is not None else RandomSampler(args, device)
+        self.mean_path_length = 0
+        self.mean_path_length_avg = 0
+        self.accum = 0.5 ** (32 / (10 * 1000))
+        D.broadcast_module(self.generator)
+        D.broadcast_module(self.discriminator)
+        self.g_sync, self.d_sync = D.GradSync(self.generator), D.GradSync(self.discriminator)
+        zero = torch.tensor(0.0, device=device)
+        self.loss = {'r1': zero, 'path': zero, 'path_length': zero, 'spatial_path': zero, 'spatial_path_length': zero}
+
+    # ---- the four optimisation sub-steps
+    def d_step(self, real_img):
+        G, Dn, a = self.generator, self.discriminator, self.args
+        requires_grad(G, False)
+        requires_grad(Dn, True)
+        noise, param = self.sampler.latents(a.batch)
+        fake_img, _, _ = G(noise, param)                                     # G frozen: no graph is built
+        fake_pred, real_pred = Dn(fake_img), Dn(real_img)
+        d_loss = d_logistic_loss(real_pred, fake_pred)
+        self.loss.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
+        Dn.zero_grad()
+        d_loss.backward()
+        self.d_sync.all_reduce()
+        self.d_optim.step()
+
+    def r1_step(self, real_img):
+        Dn, a = self.discriminator, self.args
+        real_img = real_img.detach().requires_grad_(True)
+        real_pred = Dn(real_img)
+        r1_loss = d_r1_loss(real_pred, real_img)
+        Dn.zero_grad()
+        (a.r1 / 2 * r1_loss * a.d_reg_every + 0 * real_pred[0]).backward()
+        self.d_sync.all_reduce()
+        self.d_optim.step()
+        self.loss['r1'] = r1_loss.detach()
+
+    def g_step(self):
+        G, Dn, a = self.generator, self.discriminator, self.args
+        requires_grad(G, True)
+        requires_grad(Dn, False)
+        noise, param = self.sampler.latents(a.batch)
+        fake_img, _, _ = G(noise, param)
+        g_loss = g_nonsaturating_loss(Dn(fake_img))
+        self.loss['g'] = g_loss.detach()
+        G.zero_grad()
+        g_loss.backward()
+        self.g_sync.all_reduce()
+        self.g_optim.step()
+
+    def path_step(self):
+        G, a = self.generator, self.args
+        n = max(1, a.batch // a.path_batch_shrink)
+        noise, param = self.sampler.latents(n)
+        fake_img, latents, _ = G(noise, param, return_latents=True)
+        path_loss, self.mean_path_length, path_lengths = g_path_regularize(
+            fake_img, latents, self.mean_path_length, self.sampler.randn_like(fake_img))
+        G.zero_grad()
+        weighted = a.path_regularize * a.g_reg_every * path_loss
+        if a.path_batch_shrink:
+            weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+        weighted.backward()
+        self.g_sync.all_reduce()
+        self.g_optim.step()
+        self.mean_path_length_avg = D.reduce_sum(self.mean_path_length).item() / D.get_world_size()
+        self.loss.update(path=path_loss.detach(), path_length=path_lengths.mean().detach())
+
+    def iteration(self, i, real_img):
+        """One iteration `i` of the reference loop on a batch of real images already on the device."""
+        a = self.args
+        self.d_step(real_img)
+        if i % a.d_reg_every == 0:
+            self.r1_step(real_img)
+        self.g_step()
+        if i % a.g_reg_every == 0:
+            self.path_step()
+        accumulate(self.g_ema, self.generator, self.accum)
+        return D.reduce_loss_dict(self.loss)
