@@ -247,8 +247,19 @@ def main():
             flops = sum(ks[k]['tflops'] * ks[k]['total_ms'] for k in conv_keys)      # TFLOP*ms
             tms = sum(ks[k]['total_ms'] for k in conv_keys)
             ach = flops / tms if tms else 0.0
+            traffic, traffic_note = None, None
+            try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_round.sh + pmc_summary.py)
+                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+                k3 = next(v for k, v in pm.items() if k.startswith('conv_mfma_kernel<0'))
+                traffic = (k3['hbm_read_mb'] + k3['hbm_write_mb']) * 1e6
+                traffic_note = (f"PMC pass of the 128->128 @256x256 batch-16 launch: FETCH_SIZE x2 (gfx950 correction) = "
+                                f"{k3['hbm_read_mb']:.0f} MB read + WRITE_SIZE {k3['hbm_write_mb']:.0f} MB written vs "
+                                f"{k3['algorithmic_mb']:.0f} MB algorithmic; MFMA utilisation {k3['mfma_util_pct']:.1f} % "
+                                f"at {k3['mhz']:.0f} MHz (profiles/r01_pmc_summary.txt)")
+            except Exception:
+                pass
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_FP32_TFLOPS, 'traffic': None,
+                               'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
                                'kernel': 'conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2, all 3x3 kinds)',
                                'kernel_time_share': tms / (ms * args.steps), 'per_kernel': ks}
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,74 @@
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_round.sh (gpurun_out/pmc/*.csv) per kernel:
+MFMA utilisation, effective clock, HBM bytes (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950
+streaming reads; WRITE_SIZE as reported), LDS bank-conflict share.  Writes profiles/<tag>_pmc_summary.{txt,json}."""
+import collections
+import csv
+import json
+import re
+import sys
+
+KEEP = ('conv_mfma', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'bias_act', 'rgb_')
+# algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
+ALG = {
+    'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
+    'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
+    'conv_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'wgrad_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'fir_tile_kernel<1, 1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
+    'bias_act_bwd_rows': dict(flops=0, bytes=3 * 16 * 128 * 256 * 256 * 4),
+    'rgb_fwd': dict(flops=0, bytes=16 * 131 * 256 * 256 * 4),
+    'rgb_dgrad': dict(flops=0, bytes=16 * 131 * 256 * 256 * 4),
+    'rgb_wgrad': dict(flops=0, bytes=16 * 131 * 256 * 256 * 4),
+}
+
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'^void ', '', n)
+    return n.split('(')[0]
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        k = short(r['Kernel_Name'])
+        if not any(s in k for s in KEEP):
+            continue
+        agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3)
+    return agg, dur
+
+
+def main(src='gpurun_out/pmc', tag='profiles/r01'):
+    mf, dur = load(f'{src}/mfma_counter_collection.csv')
+    fe, _ = load(f'{src}/fetch_counter_collection.csv')
+    wr, _ = load(f'{src}/write_counter_collection.csv')
+    ld, _ = load(f'{src}/lds_counter_collection.csv')
+    out = {}
+    lines = [f'{"kernel":42s} {"us":>8s} {"MHz":>6s} {"MFMA%":>6s} {"TF/s":>6s} {"HBM rd MB":>10s} {"wr MB":>8s} {"alg MB":>8s} '
+             f'{"GB/s":>7s} {"LDSconf%":>8s}']
+    for k in mf:
+        last = lambda d, c: (d[k][c][-1] if k in d and c in d[k] else float('nan'))
+        us = sorted(dur[k])[len(dur[k]) // 2]
+        gui = last(mf, 'GRBM_GUI_ACTIVE') / 8.0                       # summed over the 8 XCDs
+        mhz = gui / us
+        busy = last(mf, 'SQ_VALU_MFMA_BUSY_CYCLES')
+        util = 100.0 * busy / (gui * 1024) if gui else 0.0            # 256 CUs x 4 SIMDs
+        rd = 2.0 * last(fe, 'FETCH_SIZE') * 1024 / 1e6                 # gfx950: FETCH_SIZE reports half of a streaming read
+        wrm = last(wr, 'WRITE_SIZE') * 1024 / 1e6
+        alg = next((v for p, v in ALG.items() if k.startswith(p)), None)
+        tf = alg['flops'] / us / 1e6 if alg and alg['flops'] else 0.0
+        conf = 100.0 * last(ld, 'SQ_LDS_BANK_CONFLICT') / max(last(ld, 'SQ_LDS_IDX_ACTIVE'), 1.0)
+        out[k] = dict(us=us, mhz=mhz, mfma_util_pct=util, tflops=tf, hbm_read_mb=rd, hbm_write_mb=wrm,
+                      algorithmic_mb=(alg['bytes'] / 1e6 if alg else None), gbs=(rd + wrm) / us * 1e3, lds_conflict_pct=conf)
+        lines.append(f'{k[:42]:42s} {us:8.1f} {mhz:6.0f} {util:6.1f} {tf:6.1f} {rd:10.1f} {wrm:8.1f} '
+                     f'{(alg["bytes"] / 1e6 if alg else float("nan")):8.1f} {(rd + wrm) / us * 1e3:7.0f} {conf:8.1f}')
+    open(tag + '_pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
+    json.dump(out, open(tag + '_pmc_summary.json', 'w'), indent=1)
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:])
