@@ -121,7 +121,13 @@ def _ref_conv(kind, x, w):
         return F.conv2d(x, w)
     if kind == 'up':
         return F.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+    if kind == 'down':
+        return F.conv2d(x, w, stride=2)
     raise ValueError(kind)
+
+
+def _in_hw(kind, H, W):
+    return (2 * H + 1, 2 * W + 1) if kind == 'down' else (H, W)
 
 
 CONV_SHAPES = [  # B, K(ci), M(co), H, W
@@ -129,14 +135,14 @@ CONV_SHAPES = [  # B, K(ci), M(co), H, W
     (2, 32, 64, 16, 16), (1, 24, 16, 64, 64), (2, 8, 8, 5, 3), (1, 16, 32, 40, 72)]
 
 
-@pytest.mark.parametrize('kind', ['3x3', '1x1', 'up'])
+@pytest.mark.parametrize('kind', ['3x3', '1x1', 'up', 'down'])
 @pytest.mark.parametrize('shape', CONV_SHAPES, ids=['x'.join(map(str, s)) for s in CONV_SHAPES])
 def test_conv_trio_vs_torch(kind, shape):
     """forward, data gradient and weight gradient of the plain convolution (closed autograd trio)."""
     from transeditor_amd.op.modconv import conv_core
     B, K, M, H, W = shape
     ks = 1 if kind == '1x1' else 3
-    x = synth.normal((B, K, H, W), f'cv.x.{kind}').requires_grad_(True)
+    x = synth.normal((B, K, *_in_hw(kind, H, W)), f'cv.x.{kind}').requires_grad_(True)
     w = (synth.normal((M, K, ks, ks), f'cv.w.{kind}') / math.sqrt(K * ks * ks)).requires_grad_(True)
     y_ref = _ref_conv(kind, x, w)
     gy = synth.normal(tuple(y_ref.shape), f'cv.g.{kind}')
@@ -150,12 +156,12 @@ def test_conv_trio_vs_torch(kind, shape):
     assert rel_err(gw, gw_ref) < SUM_TOL, 'wgrad'
 
 
-@pytest.mark.parametrize('kind', ['3x3', 'up'])
+@pytest.mark.parametrize('kind', ['3x3', 'up', 'down'])
 def test_conv_trio_second_order(kind):
-    """grad-of-grad through the trio (what the path-length regulariser needs) vs torch autograd on CPU."""
+    """grad-of-grad through the trio (what the path-length / R1 regularisers need) vs torch autograd on CPU."""
     from transeditor_amd.op.modconv import conv_core
     B, K, M, H, W = 2, 12, 10, 9, 9
-    x = synth.normal((B, K, H, W), 'cv2.x').requires_grad_(True)
+    x = synth.normal((B, K, *_in_hw(kind, H, W)), 'cv2.x').requires_grad_(True)
     w = (synth.normal((M, K, 3, 3), 'cv2.w') / 10).requires_grad_(True)
     s = synth.normal((B, K), 'cv2.s').requires_grad_(True)
 
@@ -218,6 +224,32 @@ def test_torgb_streaming_kernels(shape):
     got = torch.autograd.grad((y * gy.to(DEV)).sum(), d)
     for name, a, b in zip(('gx', 'gw', 'gisc', 'gbias'), got, ref):
         assert rel_err(a, b) < SUM_TOL, name
+
+
+@pytest.mark.parametrize('kind,shape', [('3x3', (2, 24, 40, 9, 9)), ('1x1', (2, 3, 130, 16, 16)), ('down', (2, 136, 72, 8, 8)),
+                                        ('down', (4, 32, 32, 2, 2)), ('3x3', (4, 513, 512, 4, 4))])
+def test_discriminator_conv_kinds_fused_bias_act(kind, shape):
+    """EqualConv2d + FusedLeakyReLU as one fused launch (no modulation), incl. R1-style double backward wrt the input."""
+    from transeditor_amd.op.modconv import modconv
+    B, K, M, H, W = shape
+    ks = 1 if kind == '1x1' else 3
+    x = synth.normal((B, K, *_in_hw(kind, H, W)), 'dc.x').requires_grad_(True)
+    w = (synth.normal((M, K, ks, ks), 'dc.w') / math.sqrt(K * ks * ks)).requires_grad_(True)
+    bias = synth.normal((M,), 'dc.b').requires_grad_(True)
+
+    def run(conv, x, w, bias, dev):
+        y = conv(x, w, bias)
+        gy = synth.normal(tuple(y.shape), 'dc.g').to(dev)
+        gx, = torch.autograd.grad((y * gy).sum(), x, create_graph=True)
+        r1 = gx.pow(2).sum()
+        return y, gx, torch.autograd.grad(r1, (w, bias), retain_graph=True), torch.autograd.grad((y * gy).sum(), (w, bias))
+
+    ref = run(lambda a, b, c: F.leaky_relu(_ref_conv(kind, a, b) + c[None, :, None, None], 0.2) * math.sqrt(2), x, w, bias, 'cpu')
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, bias)]
+    got = run(lambda a, b, c: modconv(a, b, None, None, c, True, kind), d[0], d[1], d[2], DEV)
+    assert rel_err(got[0], ref[0]) < OP_TOL and rel_err(got[1], ref[1]) < OP_TOL
+    for a, b in zip(got[2] + got[3], ref[2] + ref[3]):
+        assert rel_err(a, b) < 5e-4
 
 
 # ------------------------------------------------------------------------------------------------ F1 module

@@ -96,8 +96,25 @@ class EqualConv2d(nn.Module):                                                   
         self.stride, self.padding = stride, padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input):
-        return F.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+    def forward(self, input, act_bias=None):
+        """`act_bias` (extension used by ConvLayer): fuse '+ act_bias' and the scaled leaky-ReLU that follows.
+        The four configurations the discriminator uses run on the MI355X convolution kernels (same family as the
+        generator, no modulation); anything else falls back to the library convolution."""
+        w = self.weight * self.scale
+        k, cfg = self.weight.shape[2], (self.weight.shape[2], self.stride, self.padding)
+        act = act_bias is not None
+        bias = act_bias if act else self.bias
+        if input.is_cuda and input.dtype == torch.float32:
+            if cfg == (3, 1, 1):
+                return modconv(input, w, None, None, bias, act, '3x3')
+            if cfg == (1, 1, 0):
+                return modconv(input, w, None, None, bias, act, '1x1')
+            if cfg == (3, 2, 0) and input.shape[2] % 2 == 1 and input.shape[3] % 2 == 1:
+                return modconv(input, w, None, None, bias, act, 'down')
+            if cfg == (1, 2, 0):
+                return modconv(input[:, :, ::2, ::2].contiguous(), w, None, None, bias, act, '1x1')
+        out = F.conv2d(input, w, bias=self.bias, stride=self.stride, padding=self.padding)
+        return fused_leaky_relu(out, act_bias) if act else out
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},'
@@ -407,6 +424,22 @@ class ConvLayer(nn.Sequential):                                                 
         if activate:
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
+
+    def forward(self, input):
+        """Same sequence as nn.Sequential, with EqualConv2d -> FusedLeakyReLU fused into the conv epilogue."""
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, EqualConv2d) and isinstance(nxt, FusedLeakyReLU) and nxt.bias is not None
+                    and m.bias is None and nxt.negative_slope == 0.2 and abs(nxt.scale - 2 ** 0.5) < 1e-12):
+                input = m(input, act_bias=nxt.bias)
+                i += 2
+            else:
+                input = m(input)
+                i += 1
+        return input
 
 
 class ResBlock(nn.Module):                                                           # :780-798

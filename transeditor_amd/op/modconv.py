@@ -20,7 +20,9 @@ Two layers of autograd functions:
   so double backward stays exact.
 
 kinds: '3x3' (stride 1, pad 1), '1x1', 'up' (3x3 transposed stride 2 -> (2H+1)x(2W+1); the blur
-that follows in the reference, model_spatial_query.py:318-321, is a separate upfirdn2d).
+that follows in the reference, model_spatial_query.py:318-321, is a separate upfirdn2d), 'down' (3x3 stride 2,
+pad 0 over a (2H+1)x(2W+1) input -> HxW: the discriminator's blurred downsampling conv, :744-768; it is the
+adjoint kernel pair of 'up').
 """
 import torch
 from torch.autograd import Function
@@ -28,19 +30,21 @@ from torch.autograd import Function
 from .. import _lib
 from .fused_act import fused_leaky_relu
 
-_KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2}
+_KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2, 'down': _lib.CONV_S2}
 
 
-def _lowres_hw(kind, x_or_g_is_output, t):
-    """low-resolution (H, W) from a tensor that is the conv input (False) or output (True)."""
+def _lowres_hw(kind, is_output, t):
+    """low-resolution (H, W) of the problem from the conv input (is_output=False) or output (True)."""
     H, W = t.shape[2], t.shape[3]
-    if kind == 'up' and x_or_g_is_output:
+    if (kind == 'up' and is_output) or (kind == 'down' and not is_output):
+        if H % 2 == 0 or W % 2 == 0:
+            raise RuntimeError(f"kind '{kind}': high-resolution side must be (2H+1)x(2W+1), got {H}x{W}")
         return (H - 1) // 2, (W - 1) // 2
     return H, W
 
 
 def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0):
-    H, W = x.shape[2], x.shape[3]
+    H, W = _lowres_hw(kind, False, x)
     return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
 
 
@@ -48,15 +52,26 @@ def _dgrad_raw(g, w, kind, isc=None, osc=None):
     """data gradient: g is shaped like the conv OUTPUT; returns a tensor shaped like the conv input.
     isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci])."""
     H, W = _lowres_hw(kind, True, g)
-    if kind == 'up':
+    if kind == 'up':       # adjoint of the transposed conv = strided conv
         return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP), _lib.CONV_S2, w.shape[1], H, W, isc, osc)
+    if kind == 'down':     # adjoint of the strided conv = transposed conv
+        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP), _lib.CONV_T2, w.shape[1], H, W, isc, osc)
     return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_DGRAD), _KIND[kind], w.shape[1], H, W, isc, osc)
 
 
 def _wgrad_raw(g, x, kind):
+    """per-sample correlation slabs [B, S, Co, Ci, taps] ('down': [B, S, Ci, Co, taps], see _slab_sum)."""
+    if kind == 'down':     # same correlation as 'up' with the roles of the two tensors swapped
+        H, W = g.shape[2], g.shape[3]
+        return _lib.wgrad_slabs(x, g, _lib.CONV_T2, H, W)
     H, W = x.shape[2], x.shape[3]
-    slabs = _lib.wgrad_slabs(g, x, _KIND[kind], H, W)
-    return slabs
+    return _lib.wgrad_slabs(g, x, _KIND[kind], H, W)
+
+
+def _slab_sum(slabs, kind):
+    """plain (unmodulated) weight gradient [Co, Ci, taps] from the slabs"""
+    gw = slabs.sum(dim=(0, 1))
+    return gw.transpose(0, 1) if kind == 'down' else gw
 
 
 class _ConvFwd(Function):
@@ -96,7 +111,7 @@ class _ConvWgrad(Function):
         ctx.kind = kind
         slabs = _wgrad_raw(gy, x, kind)
         Co, Ci = gy.shape[1], x.shape[1]
-        return slabs.sum(dim=(0, 1)).reshape(Co, Ci, ksize, ksize)
+        return _slab_sum(slabs, kind).reshape(Co, Ci, ksize, ksize)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -171,6 +186,10 @@ class _ModConvFused(Function):
         gw = gisc = gosc = None
         if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
             slabs = _lib.rgb_wgrad_slabs(g, x) if ctx.rgb else _wgrad_raw(g, x, kind)
+            if kind == 'down':
+                if isc is not None or osc is not None:
+                    raise RuntimeError("kind 'down' carries no style modulation (discriminator path)")
+                return gx, (_slab_sum(slabs, kind).reshape(w.shape) if need[1] else None), None, None, g_bias, None, None
             gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), 1.0, isc, osc,
                                                want_w=need[1], want_isc=need[2] and isc is not None,
                                                want_osc=need[3] and osc is not None)
