@@ -59,6 +59,8 @@ struct ConvArgs {
     struct Region {
         int ri0, rj0, rh, rw;    // cell region
         int TH, TW, NS, lgTW, lgTH;
+        int NSv;                 // samples actually staged per tile (<= NS; smaller when the input tiles of NS samples
+                                 // would not fit the staging budget: the remaining cells of the tile stay unused)
         int tiles_x, tiles_y;    // tiles per sample group
         int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
         int first_block;         // blockIdx.x of the region's first tile
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     int t = blockIdx.x - g.first_block;
     const int tx_i = t % g.tiles_x; t /= g.tiles_x;
     const int ty_i = t % g.tiles_y; t /= g.tiles_y;
-    const int b0 = t * g.NS;
+    const int b0 = t * g.NSv;
     const int m0 = blockIdx.y * BM;
     const int ci0 = g.ri0 + ty_i * g.TH, cj0 = g.rj0 + tx_i * g.TW;   // first cell of the tile
     // origin of the input tile in input coordinates
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 
     // ---- per-thread staging descriptors (constant over the K loop)
     const int tile_sp = g.TIH * g.TIW;
-    const int n_sp = g.NS * tile_sp;
+    const int n_sp = g.NSv * tile_sp;
     unsigned goff[NSP];      // byte offset of channel 0 relative to the tile's first sample, or OOBH for zero padding
     int loff[NSP], sb[NSP];  // LDS offset (or -1: no element for this thread), sample index
     const unsigned plane4 = (unsigned)p.Hi * p.Wi * 4u;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         }
     }
     // input of the samples of this tile through one buffer descriptor: 32-bit offsets, hardware zero fill
-    const int ns_here = min(g.NS, p.B - b0);
+    const int ns_here = min(g.NSv, p.B - b0);
     const __amdgpu_buffer_rsrc_t irs = make_rsrc(p.in + (size_t)b0 * p.K * p.Hi * p.Wi, (unsigned)ns_here * p.K * plane4);
 
     // ---- per-lane B-fragment base offsets (LDS floats), one per cell block
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         const int s = c >> (g.lgTW + g.lgTH);
         const int ci = ci0 + ((c >> g.lgTW) & (g.TH - 1)), cj = cj0 + (c & (g.TW - 1));
         const int b = b0 + s;
-        const bool cell_ok = b < p.B && ci < g.ri0 + g.rh && cj < g.rj0 + g.rw;
+        const bool cell_ok = s < g.NSv && b < p.B && ci < g.ri0 + g.rh && cj < g.rj0 + g.rw;
         const int bc = b < p.B ? b : p.B - 1;
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) {
@@ -366,14 +368,16 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     g.SS = g.TIH * g.TIWP;
     g.CS = g.NS * g.SS;
     constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
-    if ((int64_t)g.NS * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
-        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", g.NS, a.K, a.Hi, a.Wi);
-    if (g.NS * g.TIH * g.TIW > NSP * NTHREADS)
-        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", g.NS, g.TIH, g.TIW);
+    g.NSv = g.NS;
+    while (g.NSv > 1 && g.NSv * g.TIH * g.TIW > NSP * NTHREADS) g.NSv >>= 1;
+    if ((int64_t)g.NSv * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", g.NSv, a.K, a.Hi, a.Wi);
+    if (g.NSv * g.TIH * g.TIW > NSP * NTHREADS)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", g.NSv, g.TIH, g.TIW);
     g.first_block = nblocks;
-    nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NS - 1) / g.NS);
+    nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NSv - 1) / g.NSv);
     lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS);
-    ms = ms || g.NS > 1;
+    ms = ms || g.NSv > 1;
     a.nreg++;
     return 0;
 }
