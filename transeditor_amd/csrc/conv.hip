@@ -402,7 +402,7 @@ void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
 template <int KIND, int NBW, bool HAS_ISC, bool MS>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     // 3 waves/SIMD variant only for the plain 3x3 (the only kind whose register budget is close to 168)
-    if (KIND == TE_CONV_3X3 && !MS && conv_occ() == 3) launch_o<KIND, NBW, HAS_ISC, MS, (KIND == TE_CONV_3X3 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
+    if (KIND == TE_CONV_3X3 && NBW == 2 && !MS && conv_occ() == 3) launch_o<KIND, NBW, HAS_ISC, MS, (KIND == TE_CONV_3X3 && NBW == 2 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
     else launch_o<KIND, NBW, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
 }
 
@@ -478,6 +478,7 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
         case TE_CONV_3X3: {
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
+            // (a 128 x 256 block tile, NBW = 4, measured the same 133 TF/s: the kernel sits at the clock-limited peak)
             rc = launch_regions<TE_CONV_3X3, 2>(a, r, 1, s);
         } break;
         case TE_CONV_1X1: {

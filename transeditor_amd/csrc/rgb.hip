@@ -94,9 +94,20 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slab
     for (int tl = t0; tl < t1; ++tl) {
         const int p0 = tl * TP;
         __syncthreads();
-        for (int e = tid; e < K * TP; e += 256) {
-            const int k = e / TP, pp = e - k * TP;
-            xl[k * (TP + 1) + pp] = (p0 + pp < HW) ? xb[(size_t)k * HW + p0 + pp] : 0.f;
+        for (int e0 = 0; e0 < K * TP; e0 += 256 * 8) {        // 8 loads in flight per lane, then the LDS writes
+            float st[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + tid + 256 * j, k = e / TP, pp = e - k * TP;
+                const bool ok = e < K * TP && p0 + pp < HW;
+                const float v = xb[ok ? (size_t)k * HW + p0 + pp : 0];
+                st[j] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + tid + 256 * j, k = e / TP, pp = e - k * TP;
+                if (e < K * TP) xl[k * (TP + 1) + pp] = st[j];
+            }
         }
         if (tid < NOUT * TP) {
             const int o = tid / TP, pp = tid - o * TP;

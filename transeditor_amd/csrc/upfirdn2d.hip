@@ -63,12 +63,24 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
         const float* xin = x + (size_t)mj * p.in_h * p.in_w;
         __syncthreads();
-        for (int e = threadIdx.x; e < TIH * TIW; e += 256) {
+        // all loads of the tile are issued before the first LDS write (clamped address + select: no branch, so the
+        // NLD global loads of a lane are in flight together instead of one latency after the other)
+        constexpr int NLD = (TIH * TIW + 255) / 256;
+        float stage[NLD];
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int e = threadIdx.x + 256 * r;
             const int ry = e / TIW, rx = e - ry * TIW;
             const int gy = iy0 + ry, gx = ix0 + rx;
-            float v = 0.f;
-            if (gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) v = xin[(size_t)gy * p.in_w + gx];
-            sx[ry * TIWP + rx] = v;
+            const bool ok = e < TIH * TIW && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w;
+            const float v = xin[ok ? (size_t)gy * p.in_w + gx : 0];
+            stage[r] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            const int e = threadIdx.x + 256 * r;
+            const int ry = e / TIW, rx = e - ry * TIW;
+            if (e < TIH * TIW) sx[ry * TIWP + rx] = stage[r];
         }
         __syncthreads();
         const int oy = oy0 + ty;

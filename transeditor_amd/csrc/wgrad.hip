@@ -301,6 +301,43 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_w_kernel(float* __restr
     else gw[e] = acc * wscale;
 }
 
+// 16 bytes per lane: requires E % 4 == 0 and 16-byte aligned slabs
+__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_w4_kernel(float* __restrict__ gw, const float* __restrict__ slabs,
+                                                                   float wscale, const float* __restrict__ isc,
+                                                                   const float* __restrict__ osc, int B, int S, int Co, int Ci,
+                                                                   int NT, int nchunk) {
+    const int64_t E = (int64_t)Co * Ci * NT;
+    const int64_t e = ((int64_t)blockIdx.x * RTHREADS + threadIdx.x) * 4;
+    if (e >= E) return;
+    int ci[4], co[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ci[j] = (int)(((e + j) / NT) % Ci); co[j] = (int)((e + j) / ((int64_t)NT * Ci)); }
+    const int BS = B * S;
+    const int j0 = (int)((int64_t)BS * blockIdx.y / nchunk), j1 = (int)((int64_t)BS * (blockIdx.y + 1) / nchunk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const int b = j / S;
+        float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)j * E + e);
+        float sc[4] = {1.f, 1.f, 1.f, 1.f};
+        if (osc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc[q] *= osc[(size_t)b * Co + co[q]];
+        }
+        if (isc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc[q] *= isc[(size_t)b * Ci + ci[q]];
+        }
+        acc.x += v.x * sc[0]; acc.y += v.y * sc[1]; acc.z += v.z * sc[2]; acc.w += v.w * sc[3];
+    }
+    if (nchunk > 1) {
+        atomicAdd(gw + e, acc.x * wscale); atomicAdd(gw + e + 1, acc.y * wscale);
+        atomicAdd(gw + e + 2, acc.z * wscale); atomicAdd(gw + e + 3, acc.w * wscale);
+    } else {
+        *reinterpret_cast<float4*>(gw + e) = make_float4(acc.x * wscale, acc.y * wscale, acc.z * wscale, acc.w * wscale);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __restrict__ gisc, float* __restrict__ gosc,
                                                                    const float* __restrict__ slabs, const float* __restrict__ w,
@@ -396,14 +433,17 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
     hipStream_t s = (hipStream_t)stream_;
     if (gw) {
         const int64_t E = (int64_t)Co * Ci * taps;
-        const int64_t blocks = te::cdiv(E, RTHREADS);
+        const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0;
+        const int64_t blocks = te::cdiv(vec ? E / 4 : E, RTHREADS);
         int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * S, te::cdiv(2 * te::kNumCU, blocks)));
         if (nchunk > 1) {
             hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * E, s);
             if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
         }
-        wgrad_reduce_w_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S, Co,
-                                                                                          Ci, taps, nchunk);
+        if (vec) wgrad_reduce_w4_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S,
+                                                                                                    Co, Ci, taps, nchunk);
+        else wgrad_reduce_w_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S, Co,
+                                                                                               Ci, taps, nchunk);
     }
     if (gisc || gosc) {
         dim3 grid((unsigned)B, (unsigned)te::cdiv(Co, COB));
