@@ -37,6 +37,9 @@ struct WgArgs {
     int QH, QW, QS;          // shifted-operand tile: rows, cols, channel stride (odd)
     int PS;                  // plain-operand channel stride (odd)
     unsigned magic_qt, magic_qw;   // ceil(2^32 / (QH*QW)), ceil(2^32 / QW): exact division of small indices
+    unsigned magic_q8, magic_q2;   // ceil(2^32 / (QH*8)), ceil(2^32 / (QH*2))
+    unsigned magic_q16, magic_q1;  // ceil(2^32 / (QH*16)), ceil(2^32 / QH)   (transposed kind: 65-wide rows = 16 x 16 B + 1)
+    int vec;                       // 16-byte staging path: TW == 32 and W % 32 == 0 (rows of both operands 16 B aligned)
 };
 
 template <int KIND> struct WK;
@@ -50,6 +53,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 }
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
 template <int KIND, int NWP>
@@ -101,7 +108,77 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
 
     float preg[NP], qreg[NQ];
     for (int tl = t_begin - 1; tl < t_end; ++tl) {
-        if (tl >= t_begin) {
+        constexpr bool QVEC = (KIND != TE_CONV_T2);     // the shifted operand of T2 has odd row width: scalar loads
+        constexpr int NP4 = NP / 4, NQ4 = (KIND == TE_CONV_3X3) ? (NQ - 1) / 4 : NQ / 4;
+        constexpr bool TVEC = (KIND == TE_CONV_T2);
+        if (TVEC && tl >= t_begin && p.vec) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < NP4; ++r) {
+                int it = tid + NTHREADS * r;
+                asm volatile("" : "+v"(it));
+                const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
+                if (chl < PCH) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pl[chl * p.PS + cell + j] = preg[4 * r + j];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NQ / 4; ++r) {
+                unsigned it = tid + NTHREADS * r;
+                asm volatile("" : "+v"(it));
+                const unsigned chl = __umulhi(it, p.magic_q16), rem = it - chl * (p.QH * 16);
+                if (chl < QCH) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ql[chl * p.QS + (rem >> 4) * p.QW + 4 * (rem & 15) + j] = qreg[4 * r + j];
+                }
+            }
+            {
+                const unsigned it = tid, chl = __umulhi(it, p.magic_q1), ry = it - chl * p.QH;
+                if (chl < QCH) ql[chl * p.QS + ry * p.QW + 64] = qreg[NQ - 1];
+            }
+            __syncthreads();
+        } else if (QVEC && tl >= t_begin && p.vec) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < NP4; ++r) {
+                int it = tid + NTHREADS * r;
+                asm volatile("" : "+v"(it));
+                const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
+                if (chl < PCH) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pl[chl * p.PS + cell + j] = preg[4 * r + j];
+                }
+            }
+            if (QVEC) {
+                const int halo = (KIND == TE_CONV_3X3) ? 1 : 0;
+#pragma unroll
+                for (int r = 0; r < NQ4; ++r) {
+                    unsigned it = tid + NTHREADS * r;
+                    asm volatile("" : "+v"(it));
+                    const unsigned chl = __umulhi(it, p.magic_q8), rem = it - chl * (p.QH * 8);
+                    const unsigned ry = rem >> 3, seg = rem & 7;
+                    if (chl < QCH) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ql[chl * p.QS + ry * p.QW + halo + 4 * seg + j] = qreg[4 * r + j];
+                    }
+                }
+                if (KIND == TE_CONV_3X3) {
+                    unsigned it = tid;
+                    const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
+                    if (chl < QCH) ql[chl * p.QS + (rem >> 1) * p.QW + ((rem & 1) ? p.QW - 1 : 0)] = qreg[4 * NQ4];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) {
+                    unsigned e = tid + NTHREADS * r;
+                    asm volatile("" : "+v"(e));
+                    const unsigned ch = __umulhi(e, p.magic_qt), rem = e - ch * q_tile;
+                    if (ch < QCH) ql[ch * p.QS + rem] = qreg[r];
+                }
+            }
+            __syncthreads();
+        } else if (tl >= t_begin) {
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
@@ -126,6 +203,79 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
             if (KIND == TE_CONV_3X3) { qy0 = ty0 - 1; qx0 = tx0 - 1; }
             else if (KIND == TE_CONV_T2) { qy0 = 2 * ty0; qx0 = 2 * tx0; }
             else { qy0 = ty0; qx0 = tx0; }
+            if (TVEC && p.vec) {
+#pragma unroll
+                for (int r = 0; r < NP4; ++r) {
+                    int it = tid + NTHREADS * r;
+                    asm volatile("" : "+v"(it));
+                    const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
+                    const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
+                    const bool ok = chl < PCH && y < p.H && ch < pC;
+                    const f32x4 v = buf_load4(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
+                }
+#pragma unroll
+                for (int r = 0; r < NQ / 4; ++r) {     // 16-byte loads at 4-byte alignment (rows are 2W+1 wide)
+                    unsigned it = tid + NTHREADS * r;
+                    asm volatile("" : "+v"(it));
+                    const unsigned chl = __umulhi(it, p.magic_q16), rem = it - chl * (p.QH * 16);
+                    const int y = qy0 + (int)(rem >> 4), xx = qx0 + 4 * (int)(rem & 15), ch = qc0 + (int)chl;
+                    const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && ch < qC;
+                    const f32x4 v = buf_load4(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qreg[4 * r + j] = v[j];
+                }
+                {
+                    const unsigned it = tid, chl = __umulhi(it, p.magic_q1), ry = it - chl * p.QH;
+                    const int y = qy0 + (int)ry, xx = qx0 + 64, ch = qc0 + (int)chl;
+                    const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
+                    qreg[NQ - 1] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+                }
+            } else if (QVEC && p.vec) {
+#pragma unroll
+                for (int r = 0; r < NP4; ++r) {
+                    int it = tid + NTHREADS * r;
+                    asm volatile("" : "+v"(it));
+                    const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
+                    const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
+                    const bool ok = chl < PCH && y < p.H && ch < pC;
+                    const f32x4 v = buf_load4(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
+                }
+                if (QVEC) {
+#pragma unroll
+                    for (int r = 0; r < NQ4; ++r) {
+                        unsigned it = tid + NTHREADS * r;
+                        asm volatile("" : "+v"(it));
+                        const unsigned chl = __umulhi(it, p.magic_q8), rem = it - chl * (p.QH * 8);
+                        const int y = qy0 + (int)(rem >> 3), xx = tx0 + 4 * (int)(rem & 7), ch = qc0 + (int)chl;
+                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && ch < qC;
+                        const f32x4 v = buf_load4(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) qreg[4 * r + j] = v[j];
+                    }
+                    if (KIND == TE_CONV_3X3) {     // the two halo columns of every (channel, row)
+                        unsigned it = tid;
+                        const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
+                        const int y = qy0 + (int)(rem >> 1), xx = (rem & 1) ? tx0 + p.TW : tx0 - 1, ch = qc0 + (int)chl;
+                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
+                        qreg[4 * NQ4] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NQ; ++r) {
+                        unsigned e = tid + NTHREADS * r;
+                        asm volatile("" : "+v"(e));
+                        const unsigned chl = __umulhi(e, p.magic_qt), rem = e - chl * q_tile;
+                        const unsigned ry = __umulhi(rem, p.magic_qw), rx = rem - ry * p.QW;
+                        const int y = qy0 + (int)ry, xx = qx0 + (int)rx, ch = qc0 + (int)chl;
+                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
+                        qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 int e = tid + NTHREADS * r;
@@ -144,6 +294,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 const int y = qy0 + (int)ry, xx = qx0 + (int)rx, ch = qc0 + (int)chl;
                 const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
                 qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+            }
             }
         }
         if (tl < t_begin) continue;
@@ -209,6 +360,12 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     }
 }
 
+inline int wgrad_nwp() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TE_WGRAD_NWP"); v = (e && atoi(e) == 2) ? 2 : 4; }
+    return v;
+}
+
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int pow2ceil(int v) { return 1 << ilog2(v); }
 inline unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }   // exact floor(e/d) for e < 2^16, d < 2^16
@@ -231,13 +388,15 @@ bool fill_geometry(WgArgs& a) {
     a.PS = a.NC | 1;
     a.magic_qt = magic((unsigned)(a.QH * a.QW));
     a.magic_qw = magic((unsigned)a.QW);
+    a.magic_q8 = magic((unsigned)(a.QH * 8));
+    a.magic_q2 = magic((unsigned)(a.QH * 2));
+    a.magic_q16 = magic((unsigned)(a.QH * 16));
+    a.magic_q1 = magic((unsigned)a.QH);
+    // the 16-byte staging path needs full 32-cell rows whose global rows are 16 B aligned, and its one edge pass
+    // (QCH * QH * 2 scalars) must fit a single sweep of the block
+    a.vec = (wgrad_nwp() == 4 && a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
+             (((uintptr_t)a.g | (uintptr_t)a.x) & 15) == 0) ? 1 : 0;
     return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
-}
-
-inline int wgrad_nwp() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TE_WGRAD_NWP"); v = (e && atoi(e) == 2) ? 2 : 4; }
-    return v;
 }
 
 template <int KIND, int NWP>
