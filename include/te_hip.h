@@ -78,7 +78,7 @@ int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, 
  * modulation / demodulation are row/column scalings fused into the kernel:
  *     out[b,m,:,:] = act( osc[b,m] * conv(isc[b,k] * in[b,k,:,:], W)[m] + bias[m] )
  *
- * Weights are consumed in a packed layout  Wp[tap][Kp][Mp]  (Kp = K rounded up to 8, Mp = M
+ * Weights are consumed in a packed layout  Wp[tap][Kp][Mp]  (Kp = K rounded up to 16, Mp = M
  * rounded up to 128, zero padded) produced by te_conv_pack_weights_f32.
  */
 

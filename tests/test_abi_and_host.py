@@ -44,7 +44,7 @@ def test_argument_validation_returns_error_codes(libpath):
     L = _lib.lib()
     assert L.te_bias_act_f32(None, None, None, None, 3, 0, 0.2, 1.0, 16, 1, 1, None) == -1
     assert b'NULL' in L.te_last_error_string()
-    assert L.te_conv_packed_numel(0, 5, 6, 3) == 9 * 8 * 128
+    assert L.te_conv_packed_numel(0, 5, 6, 3) == 9 * 16 * 128
     assert L.te_conv_packed_numel(1, 512, 256, 3) == 9 * 512 * 256
     assert L.te_wgrad_slab_count(0, 16, 128, 128, 256, 256) >= 1
     assert L.te_wgrad_slab_count(0, 0, 128, 128, 256, 256) < 0

@@ -39,8 +39,14 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
 
-constexpr int KC = 8;     // input channels per stage
-constexpr int BM = 128;   // block tile, output channels
+constexpr int KPAD = 16;    // packed weights: K padded to a multiple of 16 (stages take 8 or 16 channels)
+constexpr int MPAD = 128;   // packed weights: M padded to a multiple of 128 (block tiles cover 64 or 128 rows)
+
+// per-kind tile configuration: NBW cell blocks (32 cells) per wave, MBW 32-row M blocks per wave, KC channels per stage
+template <int KIND> struct Cfg { static constexpr int NBW = 2, MBW = 2, KC = 8; };
+// transposed conv: 4 phase accumulators per cell block -> 32 x 64 cells per wave and 16 channels per stage keep the
+// MFMA work per staged weight byte equal to the plain 3x3 kernel (64 M x 128 cells per block)
+template <> struct Cfg<TE_CONV_T2> { static constexpr int NBW = 2, MBW = 1, KC = 16; };
 constexpr int NTHREADS = 256;
 
 struct ConvArgs {
@@ -64,6 +70,7 @@ struct ConvArgs {
         int tiles_x, tiles_y;    // tiles per sample group
         int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
         int first_block;         // blockIdx.x of the region's first tile
+        int tapmask;             // taps that can contribute in this region (thin T2 edge regions need 3 of 9)
     } reg[3];
     int nreg;
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
@@ -78,9 +85,10 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
 // MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
-template <int KIND, int NBW, bool HAS_ISC, bool MS, int OCC>
+template <int KIND, bool HAS_ISC, bool MS, int OCC>
 __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
-    constexpr int MBW = 2;
+    constexpr int NBW = Cfg<KIND>::NBW, MBW = Cfg<KIND>::MBW, KC = Cfg<KIND>::KC;
+    constexpr int BM = 2 * MBW * 32;              // block tile, output channels
     constexpr int NTAP = Kind<KIND>::NT;
     constexpr bool IS_T2 = (KIND == TE_CONV_T2);
     constexpr int NACC = IS_T2 ? 4 * NBW : NBW;
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     constexpr int WLD = (WSTAGE / 4) / NTHREADS;  // float4 loads per thread per stage
     static_assert((WSTAGE / 4) % NTHREADS == 0, "weight stage must split evenly over the block");
     constexpr int WLDR = (WSTAGE / 4 + NTHREADS - 1) / NTHREADS;
-    constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
+    constexpr int NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;            // [NTAP][KC][BM]
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < WLDR; ++r) {
                 const int idx = tid + NTHREADS * r;          // float4 index inside the stage
-                const int row = idx >> 5, c4 = idx & 31;      // row = tap*KC + kk ; 32 float4 per 128-wide row
+                const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
                 const int tap = row / KC, kk = row - tap * KC;
                 wreg[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(tap * p.Kp + kn + kk) * p.Mp + m0 + c4 * 4));
             }
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         for (int kk = 0; kk < KC; kk += 2) {
 #pragma unroll
             for (int tp = 0; tp < NTAP; ++tp) {
+                if (IS_T2 && !((g.tapmask >> tp) & 1)) continue;      // block-uniform: skipped taps only see zero padding
                 const int ky = tp / 3, kx = tp % 3;
                 int toff;
                 if (KIND == TE_CONV_1X1) toff = 0;
@@ -343,19 +352,28 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     d.ntap = ksize * ksize;
     d.M = (kind_pack == TE_PACK_FWD) ? Co : Ci;
     d.K = (kind_pack == TE_PACK_FWD) ? Ci : Co;
-    d.Kp = roundup(d.K, KC);
-    d.Mp = roundup(d.M, BM);
+    d.Kp = roundup(d.K, KPAD);
+    d.Mp = roundup(d.M, MPAD);
     return d;
 }
 
-template <int KIND, int NBW>
-int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms) {
+template <int KIND>
+int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms, bool force_single) {
     if (rh <= 0 || rw <= 0) return 0;
+    constexpr int NBW = Cfg<KIND>::NBW, KC = Cfg<KIND>::KC, BM = 2 * Cfg<KIND>::MBW * 32;
     constexpr int NTILE = 2 * NBW * 32;
     ConvArgs::Region& g = a.reg[a.nreg];
     g.ri0 = ri0; g.rj0 = rj0; g.rh = rh; g.rw = rw;
+    constexpr int NSP_ = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
+    auto tile_in = [](int th, int tw) {        // input-tile elements of one sample
+        if (KIND == TE_CONV_3X3) return (th + 2) * (tw + 2);
+        if (KIND == TE_CONV_S2) return (2 * th + 1) * (2 * tw + 1);
+        if (KIND == TE_CONV_T2) return (th + 1) * (tw + 1);
+        return th * tw;
+    };
     g.TW = std::min(32, pow2ceil(rw));
     g.TH = std::min(pow2ceil(rh), NTILE / g.TW);
+    while (g.TH > 1 && tile_in(g.TH, g.TW) > NSP_ * NTHREADS) g.TH >>= 1;   // thin edge regions: one sample must fit
     g.NS = NTILE / (g.TW * g.TH);
     g.lgTW = ilog2(g.TW); g.lgTH = ilog2(g.TH);
     g.tiles_x = (rw + g.TW - 1) / g.TW;
@@ -367,14 +385,19 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     g.TIWP = g.TIW;
     g.SS = g.TIH * g.TIWP;
     g.CS = g.NS * g.SS;
-    constexpr int NSP = (KIND == TE_CONV_S2) ? (NBW == 2 ? 3 : 5) : (KIND == TE_CONV_3X3 ? 2 : 1);
-    g.NSv = g.NS;
+    constexpr int NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
+    // edge regions of a single-sample launch stay single-sample, so the whole launch keeps the cheap scalar
+    // style-scale path (MS = false); their tiles are merely less full
+    g.NSv = force_single ? 1 : g.NS;
     while (g.NSv > 1 && g.NSv * g.TIH * g.TIW > NSP * NTHREADS) g.NSv >>= 1;
     if ((int64_t)g.NSv * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
         return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", g.NSv, a.K, a.Hi, a.Wi);
     if (g.NSv * g.TIH * g.TIW > NSP * NTHREADS)
         return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", g.NSv, g.TIH, g.TIW);
     g.first_block = nblocks;
+    g.tapmask = 0x1FF;
+    if (KIND == TE_CONV_T2 && ri0 == a.H && rh == 1) g.tapmask = 0x1C0;            // last output row: only ky == 2 reaches it
+    if (KIND == TE_CONV_T2 && rj0 == a.W && rw == 1) g.tapmask = 0x124;            // last output column: only kx == 2
     nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NSv - 1) / g.NSv);
     lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS);
     ms = ms || g.NSv > 1;
@@ -388,39 +411,41 @@ inline int conv_occ() {
     return v;
 }
 
-template <int KIND, int NBW, bool HAS_ISC, bool MS, int OCC>
+template <int KIND, bool HAS_ISC, bool MS, int OCC>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+    constexpr int BM = 2 * Cfg<KIND>::MBW * 32;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, NBW, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    dim3 grid((unsigned)nblocks, (unsigned)(a.Mp / BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, NBW, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+    dim3 grid((unsigned)nblocks, (unsigned)te::cdiv(a.M, BM), (unsigned)a.ksplit);
+    conv_mfma_kernel<KIND, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
 }
 
-template <int KIND, int NBW, bool HAS_ISC, bool MS>
+template <int KIND, bool HAS_ISC, bool MS>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     // 3 waves/SIMD variant only for the plain 3x3 (the only kind whose register budget is close to 168)
-    if (KIND == TE_CONV_3X3 && NBW == 2 && !MS && conv_occ() == 3) launch_o<KIND, NBW, HAS_ISC, MS, (KIND == TE_CONV_3X3 && NBW == 2 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
-    else launch_o<KIND, NBW, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
+    if (KIND == TE_CONV_3X3 && !MS && conv_occ() == 3) launch_o<KIND, HAS_ISC, MS, (KIND == TE_CONV_3X3 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
+    else launch_o<KIND, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
 }
 
 // regions: list of {ri0, rj0, rh, rw}
-template <int KIND, int NBW>
+template <int KIND>
 int launch_regions(ConvArgs a, const int (*regions)[4], int n, hipStream_t s) {
     int nblocks = 0;
     size_t lds_floats = 0;
     bool ms = false;
     a.nreg = 0;
     for (int i = 0; i < n; ++i) {
-        const int rc = add_region<KIND, NBW>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms);
+        const int rc = add_region<KIND>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms,
+                                        i > 0 && a.nreg > 0 && a.reg[0].NSv == 1);
         if (rc) return rc;
     }
     if (nblocks == 0) return 0;
-    if (!a.isc) launch_t<KIND, NBW, false, false>(a, nblocks, lds_floats, s);
-    else if (ms) launch_t<KIND, NBW, true, true>(a, nblocks, lds_floats, s);
-    else launch_t<KIND, NBW, true, false>(a, nblocks, lds_floats, s);
+    if (!a.isc) launch_t<KIND, false, false>(a, nblocks, lds_floats, s);
+    else if (ms) launch_t<KIND, true, true>(a, nblocks, lds_floats, s);
+    else launch_t<KIND, true, false>(a, nblocks, lds_floats, s);
     return 0;
 }
 
@@ -451,16 +476,18 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     hipStream_t s = (hipStream_t)stream_;
     ConvArgs a{};
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
-    a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KC); a.Mp = roundup(M, BM); a.H = H; a.W = W;
+    a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
+    const bool t2k = (kind == TE_CONV_T2);
+    const int KC = t2k ? Cfg<TE_CONV_T2>::KC : 8, BM = t2k ? 2 * Cfg<TE_CONV_T2>::MBW * 32 : 128;
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
     // split count comes from the real tile geometry of the main region and is shared by every region launch
     {
         const bool t2 = (kind == TE_CONV_T2);
-        const int ntile = t2 ? 64 : 128;
+        const int ntile = 2 * 2 * 32;      // cells per block tile (NBW = 2 for every kind)
         int rh = H, rw = W;
         if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
         const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
-        const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * (a.Mp / BM);
+        const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * te::cdiv(M, BM);
         const int stages = a.Kp / KC;
         int ks = 1;
         if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
@@ -479,26 +506,26 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
             // (a 128 x 256 block tile, NBW = 4, measured the same 133 TF/s: the kernel sits at the clock-limited peak)
-            rc = launch_regions<TE_CONV_3X3, 2>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_3X3>(a, r, 1, s);
         } break;
         case TE_CONV_1X1: {
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
-            rc = launch_regions<TE_CONV_1X1, 2>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_1X1>(a, r, 1, s);
         } break;
         case TE_CONV_S2: {
             a.Hi = 2 * H + 1; a.Wi = 2 * W + 1; a.Ho = H; a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
-            rc = launch_regions<TE_CONV_S2, 2>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_S2>(a, r, 1, s);
         } break;
         case TE_CONV_T2: {
             a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
             if (W + 1 <= 16 || H + 1 <= 16) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
-                rc = launch_regions<TE_CONV_T2, 1>(a, r, 1, s);
+                rc = launch_regions<TE_CONV_T2>(a, r, 1, s);
             } else {
                 const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row
-                rc = launch_regions<TE_CONV_T2, 1>(a, r, 3, s);
+                rc = launch_regions<TE_CONV_T2>(a, r, 3, s);
             }
         } break;
         default:
