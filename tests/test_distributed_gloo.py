@@ -36,10 +36,28 @@ def _worker(rank, world, port, q):
         sync = D.GradSync(net, bucket_bytes=256)               # tiny buckets: exercise several of them
         assert len(sync.buckets) > 1
         sync.all_reduce()
+        first_sync = [p.grad.clone() for p in net.parameters()]
+        # second step: the hooks installed by GradSync fire DURING backward (buckets launch as they fill up)
+        for prm in net.parameters():
+            prm.grad = None
+        x2 = torch.randn(5, 8)
+        net(x2).pow(2).sum().backward()
+        assert any(w is not None for w in sync._work), 'hook-driven launch did not happen'
+        hook_local = None    # local grads were overwritten in place by the flat copy only after all_reduce()
+        sync.all_reduce()
+        hooked = [p.grad.clone() for p in net.parameters() if p is not unused] + [unused.grad.clone()]
+        ref_net_grads = torch.autograd.grad(net(x2).pow(2).sum(), [prm for prm in net.parameters() if prm is not unused])
+        # frozen module: nothing to exchange, nothing breaks
+        for prm in net.parameters():
+            prm.requires_grad = False
+        sync.all_reduce()
+        for prm in net.parameters():
+            prm.requires_grad = True
         red = D.reduce_sum(torch.tensor(float(rank + 1)))
         losses = D.reduce_loss_dict({'g': torch.tensor(1.0 + rank), 'd': torch.tensor(10.0 * (rank + 1))})
         q.put((rank, [w.numpy() for w in w0], [None if g is None else g.numpy() for g in local],
-               [p.grad.numpy() for p in net.parameters()], float(red), {k: float(v) for k, v in losses.items()}))
+               [g.numpy() for g in first_sync], float(red), {k: float(v) for k, v in losses.items()},
+               [g.numpy() for g in hooked], [g.numpy() for g in ref_net_grads]))
     finally:
         dist.destroy_process_group()
 
@@ -55,7 +73,12 @@ def test_gradient_sync_and_scalar_collectives_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w_a, loc_a, syn_a, red_a, loss_a), (_, w_b, loc_b, syn_b, red_b, loss_b) = res
+    (_, w_a, loc_a, syn_a, red_a, loss_a, hk_a, rf_a), (_, w_b, loc_b, syn_b, red_b, loss_b, hk_b, rf_b) = res
+    # hook-driven step: both ranks hold the mean of the two local gradients (last entry = the unused parameter: zeros)
+    for i, (ra, rb) in enumerate(zip(rf_a, rf_b)):
+        mean = (ra + rb) / 2
+        assert abs(hk_a[i] - mean).max() < 1e-6 and abs(hk_b[i] - mean).max() < 1e-6
+    assert (hk_a[-1] == 0).all() and (hk_b[-1] == 0).all()
     for a, b in zip(w_a, w_b):                                 # broadcast from rank 0
         assert (a == b).all()
     for la, lb, sa, sb in zip(loc_a, loc_b, syn_a, syn_b):     # mean of the local gradients, on both ranks

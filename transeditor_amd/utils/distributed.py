@@ -73,16 +73,22 @@ def broadcast_module(module, src=0):
 
 
 class GradSync:
-    """Bucketed mean all-reduce of `module`'s gradients.
+    """Bucketed mean all-reduce of `module`'s gradients, overlapped with the backward pass.
 
         sync = GradSync(generator)          # once
         loss.backward(); sync.all_reduce()  # every step, before optimizer.step()
+
+    Parameters are bucketed in REVERSE registration order (the order backward produces their gradients).  A
+    post-accumulate hook copies each fresh gradient into its bucket's flat buffer; when the last gradient of a bucket
+    has arrived the bucket's all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps the rest of the
+    backward.  `all_reduce()` issues whatever is left (buckets holding parameters that received no gradient, e.g. the
+    unused `noise.weight`s, are completed with zeros), waits, averages and writes the result back into `.grad`.
     """
 
-    def __init__(self, module, bucket_bytes=64 << 20):
+    def __init__(self, module, bucket_bytes=32 << 20):
         self.params = [p for p in module.parameters()]
         self.buckets, cur, cur_bytes = [], [], 0
-        for p in self.params:
+        for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self.buckets.append(cur)
@@ -92,37 +98,76 @@ class GradSync:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
-
-    def all_reduce(self):
-        world = get_world_size()
-        if world == 1:
-            return
-        works = []
+        self._slot = {}                                   # param -> (bucket index, offset)
         for bi, bucket in enumerate(self.buckets):
-            live = [p for p in bucket if p.requires_grad]
-            if not live:
-                continue
-            n = sum(p.numel() for p in live)
-            flat = self._flat[bi]
-            if flat is None or flat.numel() != n or flat.device != live[0].device:
-                flat = self._flat[bi] = torch.empty(n, device=live[0].device, dtype=live[0].dtype)
             off = 0
-            for p in live:
+            for p in bucket:
+                self._slot[p] = (bi, off)
+                off += p.numel()
+        self._seen = [set() for _ in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._hooked = False
+        if get_world_size() > 1:
+            self._install_hooks()
+
+    # ---- internals
+    def _buffer(self, bi):
+        bucket = self.buckets[bi]
+        n = sum(p.numel() for p in bucket)
+        flat = self._flat[bi]
+        if flat is None or flat.numel() != n or flat.device != bucket[0].device:
+            flat = self._flat[bi] = torch.empty(n, device=bucket[0].device, dtype=bucket[0].dtype)
+        return flat
+
+    def _install_hooks(self):
+        if self._hooked:
+            return
+        self._hooked = True
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, p):
+        bi, off = self._slot[p]
+        if self._work[bi] is not None:                    # a second backward before all_reduce(): handled there
+            return
+        self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self._seen[bi].add(p)
+        if len(self._seen[bi]) == sum(1 for q in self.buckets[bi] if q.requires_grad):
+            self._launch(bi)
+
+    def _launch(self, bi):
+        flat = self._buffer(bi)
+        for p in self.buckets[bi]:
+            if p not in self._seen[bi]:                   # no gradient (unused or frozen): contributes zeros / its grad
+                _, off = self._slot[p]
                 seg = flat[off:off + p.numel()]
                 if p.grad is None:
                     seg.zero_()
                 else:
                     seg.copy_(p.grad.reshape(-1))
-                off += p.numel()
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, live))
-        for work, flat, live in works:
-            work.wait()
+        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def all_reduce(self):
+        world = get_world_size()
+        if world == 1:
+            return
+        active = [bi for bi, b in enumerate(self.buckets) if any(p.requires_grad for p in b)]
+        for bi in active:
+            if self._work[bi] is None:
+                self._launch(bi)
+        for bi in active:
+            self._work[bi].wait()
+            flat = self._flat[bi]
             flat.div_(world)
-            off = 0
-            for p in live:
+            for p in self.buckets[bi]:
+                if not p.requires_grad:
+                    continue
+                _, off = self._slot[p]
                 seg = flat[off:off + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = seg.clone()
                 else:
                     p.grad.copy_(seg)
-                off += p.numel()
+        for bi in range(len(self.buckets)):
+            self._seen[bi].clear()
+            self._work[bi] = None
