@@ -184,3 +184,76 @@ def test_generator256_vs_oracle_and_batch_independence():
         assert rel_err(img16[5:7], img2) < 1e-5
         ref, _, _ = O.generator_forward({k: v for k, v in sd.items()}, z[5:7], p[5:7], 256)
     assert rel_err(img2, ref) < TOL
+
+
+def _variant(size, seed, **ctor):
+    from transeditor_amd.model_spatial_query import Generator
+    token = 2 * (int(math.log2(size)) - 1)
+    G = Generator(size, 512, 512, token, n_trans=ctor.pop('n_trans', 2), pixel_norm_op_dim=1, **ctor)
+    sd = G.state_dict()
+    synth.fill_state_dict(sd, seed)
+    G.load_state_dict(sd)
+    return G.to(DEV), sd
+
+
+def test_noise_injection_variant_vs_oracle():
+    """layer_noise_injection=True (--inject_noise): unfused conv -> noise -> FusedLeakyReLU path with fixed noise buffers."""
+    size = 16
+    G, sd = _variant(size, 31, layer_noise_injection=True)
+    z, p = synth.latents(2, 901)
+    with torch.no_grad():
+        img = G(z.to(DEV), p.to(DEV), randomize_noise=False)[0]
+        lat, spc, _, _, _ = O.generator_latent(sd, z, p, n_trans=2)
+        noise = [sd[f'noises.noise_{i}'] for i in range(G.num_layers)]
+        ref = O.synthesis(sd, lat, spc, size, inject_noise=True, noise=noise)
+    assert rel_err(img, ref) < TOL
+    ns = G.make_noise()
+    assert len(ns) == G.num_layers and ns[0].shape == (1, 1, 4, 4) and ns[-1].shape == (1, 1, size, size) and ns[0].is_cuda
+
+
+def test_no_trans_and_num_region_variants_vs_oracle():
+    size = 8
+    G, sd = _variant(size, 32, no_trans=True)
+    z, p = synth.latents(2, 902)
+    with torch.no_grad():
+        img = G(z.to(DEV), p.to(DEV))[0]
+        lat, spc, _, _, _ = O.generator_latent(sd, z, p, trans_interact=False)
+        assert rel_err(img, O.synthesis(sd, lat, spc, size)) < TOL
+    assert not any(k.startswith('interact') for k in sd)
+    G2, sd2 = _variant(size, 33, num_region=2)             # only 8 of the 16 tokens are mapped, the rest stay zero
+    with torch.no_grad():
+        mz, mp = G2(z.to(DEV), p.to(DEV), return_mapped_codes=True)
+        assert float(mp[:, :, 8:].abs().max()) == 0 and float(mz[:, :, 8:].abs().max()) == 0
+        img2 = G2(z.to(DEV), p.to(DEV))[0]
+        lat2, spc2, st2, sp2, _ = O.generator_latent(sd2, z, p, n_trans=2, num_region=2)
+        assert rel_err(mp, sp2) < 1e-4 and rel_err(img2, O.synthesis(sd2, lat2, spc2, size)) < TOL
+
+
+def test_non_contiguous_and_wrong_dtype_inputs():
+    from transeditor_amd.op import fused_leaky_relu, upfirdn2d
+    x = synth.normal((2, 6, 5, 8), 'nc.x').to(DEV)
+    xt = x.transpose(2, 3)                                   # non-contiguous view: made contiguous internally (:58-60)
+    b = synth.normal((6,), 'nc.b').to(DEV)
+    assert rel_err(fused_leaky_relu(xt, b), O.fused_leaky_relu(xt.cpu(), b.cpu())) < 1e-6
+    k = O.fir_kernel((1, 3, 3, 1)).to(DEV)
+    assert rel_err(upfirdn2d(xt, k, pad=(2, 1)), O.upfirdn2d(xt.cpu().contiguous(), k.cpu(), pad=(2, 1))) < 1e-5
+    with pytest.raises(RuntimeError, match='fp32'):
+        fused_leaky_relu(x.half(), b.half())                 # fp32 only: fails loudly instead of silently casting
+
+
+def test_generator1024_config5_shapes():
+    """FFHQ-1024 architecture (BASELINE config 5): batch-1 forward against the CPU oracle, and one fwd+bwd at the
+    config's batch 4 through finiteness / gradient coverage (deep upfirdn pyramid, 1025x1025 intermediates)."""
+    G, sd = build(1024, 9)
+    z, p = synth.latents(4, 5151)
+    with torch.no_grad():
+        img1 = G(z[:1].to(DEV), p[:1].to(DEV))[0]
+        ref, _, _ = O.generator_forward(sd, z[:1], p[:1], 1024)
+    assert tuple(img1.shape) == (1, 3, 1024, 1024) and rel_err(img1, ref) < TOL
+    zd, pd = z.to(DEV).requires_grad_(True), p.to(DEV).requires_grad_(True)
+    img = G(zd, pd)[0]
+    img.square().mean().backward()
+    assert torch.isfinite(zd.grad).all() and torch.isfinite(pd.grad).all()
+    missing = [n for n, q in G.named_parameters() if q.grad is None]
+    assert len(missing) == 17 and all(n.endswith('noise.weight') for n in missing)
+    assert rel_err(img[:1], img1) < 1e-5
