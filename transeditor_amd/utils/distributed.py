@@ -106,6 +106,10 @@ class GradSync:
                 off += p.numel()
         self._seen = [set() for _ in self.buckets]
         self._work = [None] * len(self.buckets)
+        # parameters observed to receive no gradient (the generator's `noise.weight`s): learnt at the first
+        # all_reduce() and no longer waited for, so their buckets can still launch from the hooks
+        self._unused = set()
+        self._late = []                                   # gradients that arrived after their bucket was launched
         self._hooked = False
         if get_world_size() > 1:
             self._install_hooks()
@@ -128,11 +132,13 @@ class GradSync:
 
     def _on_grad(self, p):
         bi, off = self._slot[p]
-        if self._work[bi] is not None:                    # a second backward before all_reduce(): handled there
+        if self._work[bi] is not None:                    # bucket already in flight (parameter thought unused): fix up later
+            self._late.append(p)
             return
         self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._seen[bi].add(p)
-        if len(self._seen[bi]) == sum(1 for q in self.buckets[bi] if q.requires_grad):
+        expected = sum(1 for q in self.buckets[bi] if q.requires_grad and q not in self._unused)
+        if len(self._seen[bi] - self._unused) >= expected:
             self._launch(bi)
 
     def _launch(self, bi):
@@ -153,14 +159,20 @@ class GradSync:
             return
         active = [bi for bi, b in enumerate(self.buckets) if any(p.requires_grad for p in b)]
         for bi in active:
+            for p in self.buckets[bi]:
+                if p.requires_grad and p.grad is None:
+                    self._unused.add(p)
+                elif p in self._unused and p in self._seen[bi]:
+                    self._unused.discard(p)               # it does get gradients after all
             if self._work[bi] is None:
                 self._launch(bi)
+        late = set(self._late)
         for bi in active:
             self._work[bi].wait()
             flat = self._flat[bi]
             flat.div_(world)
             for p in self.buckets[bi]:
-                if not p.requires_grad:
+                if not p.requires_grad or p in late:
                     continue
                 _, off = self._slot[p]
                 seg = flat[off:off + p.numel()].view_as(p)
@@ -168,6 +180,11 @@ class GradSync:
                     p.grad = seg.clone()
                 else:
                     p.grad.copy_(seg)
+        for p in self._late:                              # rare: reduce stragglers one by one and stop treating them as unused
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+            p.grad.div_(world)
+            self._unused.discard(p)
+        self._late.clear()
         for bi in range(len(self.buckets)):
             self._seen[bi].clear()
             self._work[bi] = None
