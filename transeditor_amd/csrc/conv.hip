@@ -42,11 +42,21 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off
 constexpr int KPAD = 16;    // packed weights: K padded to a multiple of 16 (stages take 8 or 16 channels)
 constexpr int MPAD = 128;   // packed weights: M padded to a multiple of 128 (block tiles cover 64 or 128 rows)
 
-// per-kind tile configuration: NBW cell blocks (32 cells) per wave, MBW 32-row M blocks per wave, KC channels per stage
-template <int KIND> struct Cfg { static constexpr int NBW = 2, MBW = 2, KC = 8; };
-// transposed conv: 4 phase accumulators per cell block -> 32 x 64 cells per wave and 16 channels per stage keep the
-// MFMA work per staged weight byte equal to the plain 3x3 kernel (64 M x 128 cells per block)
-template <> struct Cfg<TE_CONV_T2> { static constexpr int NBW = 2, MBW = 1, KC = 16; };
+// Tile configuration per (kind, tile class TC).  4 waves as WM (along M) x 4/WM (along the cells); each wave owns MBW
+// 32-row M blocks and NBW 32-cell blocks; KC input channels per stage; NSP staging sweeps for the input tile.
+//   TC 0: M >= 96 -> block 128 (M) x 128 cells      TC 1: M ~ 64 -> 64 x 256 cells      TC 2: M <= 32 -> 32 x 256 cells
+// (narrow layers of the 512 / 1024 px generators, ToRGB fallbacks) so the MFMA rows are not padded 2-4x with zeros.
+template <int KIND, int TC> struct Cfg;
+template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+// transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
+// MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
+template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
+template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
+template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 constexpr int NTHREADS = 256;
 
 struct ConvArgs {
@@ -85,19 +95,18 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
 // MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
-template <int KIND, bool HAS_ISC, bool MS, int OCC>
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
 __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
-    constexpr int NBW = Cfg<KIND>::NBW, MBW = Cfg<KIND>::MBW, KC = Cfg<KIND>::KC;
-    constexpr int BM = 2 * MBW * 32;              // block tile, output channels
+    using C = Cfg<KIND, TC>;
+    constexpr int NBW = C::NBW, MBW = C::MBW, KC = C::KC, WM = C::WM, WN = 4 / C::WM, NSP = C::NSP;
+    constexpr int BM = WM * MBW * 32;             // block tile, output channels
     constexpr int NTAP = Kind<KIND>::NT;
     constexpr bool IS_T2 = (KIND == TE_CONV_T2);
     constexpr int NACC = IS_T2 ? 4 * NBW : NBW;
-    constexpr int NTILE = 2 * NBW * 32;           // cells per block tile
+    constexpr int NTILE = WN * NBW * 32;          // cells per block tile
     constexpr int WSTAGE = NTAP * KC * BM;        // floats of packed weights per stage
-    constexpr int WLD = (WSTAGE / 4) / NTHREADS;  // float4 loads per thread per stage
-    static_assert((WSTAGE / 4) % NTHREADS == 0, "weight stage must split evenly over the block");
-    constexpr int WLDR = (WSTAGE / 4 + NTHREADS - 1) / NTHREADS;
-    constexpr int NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
+    constexpr int WLDR = (WSTAGE / 4 + NTHREADS - 1) / NTHREADS;   // 16-byte weight loads per thread per stage
+    constexpr bool WEVEN = (WSTAGE / 4) % NTHREADS == 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;            // [NTAP][KC][BM]
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
 
     // ---- region + tile coordinates
     const int ridx = (p.nreg > 1 && (int)blockIdx.x >= p.reg[1].first_block) + (p.nreg > 2 && (int)blockIdx.x >= p.reg[2].first_block);
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < WLDR; ++r) {
                 const int idx = tid + NTHREADS * r;
-                *reinterpret_cast<f32x4*>(wl + idx * 4) = wreg[r];
+                if (WEVEN || idx < WSTAGE / 4) *reinterpret_cast<f32x4*>(wl + idx * 4) = wreg[r];
             }
 #pragma unroll
             for (int r = 0; r < NSP; ++r) {
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         if (kn < kend) {
 #pragma unroll
             for (int r = 0; r < WLDR; ++r) {
-                const int idx = tid + NTHREADS * r;          // float4 index inside the stage
+                int idx = tid + NTHREADS * r;          // float4 index inside the stage
+                if (!WEVEN && idx >= WSTAGE / 4) idx = WSTAGE / 4 - 1;      // clamped duplicate load, never committed
                 const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
                 const int tap = row / KC, kk = row - tap * KC;
                 wreg[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(tap * p.Kp + kn + kk) * p.Mp + m0 + c4 * 4));
@@ -357,14 +367,14 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     return d;
 }
 
-template <int KIND>
+template <int KIND, int TC>
 int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms, bool force_single) {
     if (rh <= 0 || rw <= 0) return 0;
-    constexpr int NBW = Cfg<KIND>::NBW, KC = Cfg<KIND>::KC, BM = 2 * Cfg<KIND>::MBW * 32;
-    constexpr int NTILE = 2 * NBW * 32;
+    constexpr int KC = Cfg<KIND, TC>::KC, BM = tile_bm<KIND, TC>();
+    constexpr int NTILE = tile_cells<KIND, TC>();
     ConvArgs::Region& g = a.reg[a.nreg];
     g.ri0 = ri0; g.rj0 = rj0; g.rh = rh; g.rw = rw;
-    constexpr int NSP_ = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
+    constexpr int NSP_ = Cfg<KIND, TC>::NSP;
     auto tile_in = [](int th, int tw) {        // input-tile elements of one sample
         if (KIND == TE_CONV_3X3) return (th + 2) * (tw + 2);
         if (KIND == TE_CONV_S2) return (2 * th + 1) * (2 * tw + 1);
@@ -385,7 +395,7 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     g.TIWP = g.TIW;
     g.SS = g.TIH * g.TIWP;
     g.CS = g.NS * g.SS;
-    constexpr int NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1);
+    constexpr int NSP = Cfg<KIND, TC>::NSP;
     // edge regions of a single-sample launch stay single-sample, so the whole launch keeps the cheap scalar
     // style-scale path (MS = false); their tiles are merely less full
     g.NSv = force_single ? 1 : g.NS;
@@ -411,42 +421,54 @@ inline int conv_occ() {
     return v;
 }
 
-template <int KIND, bool HAS_ISC, bool MS, int OCC>
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
-    constexpr int BM = 2 * Cfg<KIND>::MBW * 32;
+    constexpr int BM = tile_bm<KIND, TC>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_done = true;
     }
     dim3 grid((unsigned)nblocks, (unsigned)te::cdiv(a.M, BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
 }
 
-template <int KIND, bool HAS_ISC, bool MS>
+template <int KIND, int TC, bool HAS_ISC, bool MS>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
-    // 3 waves/SIMD variant only for the plain 3x3 (the only kind whose register budget is close to 168)
-    if (KIND == TE_CONV_3X3 && !MS && conv_occ() == 3) launch_o<KIND, HAS_ISC, MS, (KIND == TE_CONV_3X3 && !MS) ? 3 : 2>(a, nblocks, lds_floats, s);
-    else launch_o<KIND, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
+    // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168)
+    constexpr bool CAN3 = (KIND == TE_CONV_3X3 && TC == 0 && !MS);
+    if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2>(a, nblocks, lds_floats, s);
+    else launch_o<KIND, TC, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
 }
 
 // regions: list of {ri0, rj0, rh, rw}
-template <int KIND>
-int launch_regions(ConvArgs a, const int (*regions)[4], int n, hipStream_t s) {
+template <int KIND, int TC>
+int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s) {
     int nblocks = 0;
     size_t lds_floats = 0;
     bool ms = false;
     a.nreg = 0;
     for (int i = 0; i < n; ++i) {
-        const int rc = add_region<KIND>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms,
+        const int rc = add_region<KIND, TC>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms,
                                         i > 0 && a.nreg > 0 && a.reg[0].NSv == 1);
         if (rc) return rc;
     }
     if (nblocks == 0) return 0;
-    if (!a.isc) launch_t<KIND, false, false>(a, nblocks, lds_floats, s);
-    else if (ms) launch_t<KIND, true, true>(a, nblocks, lds_floats, s);
-    else launch_t<KIND, true, false>(a, nblocks, lds_floats, s);
+    if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s);
+    else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s);
+    else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s);
     return 0;
+}
+
+inline int tile_class(int M) { return M >= 96 ? 0 : (M >= 48 ? 1 : 2); }
+
+template <int KIND>
+int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_t s) {
+    switch (tile_class(a.M)) {
+        case 0: return launch_regions_tc<KIND, 0>(a, regions, n, s);
+        case 1: return launch_regions_tc<KIND, 1>(a, regions, n, s);
+        default: return launch_regions_tc<KIND, 2>(a, regions, n, s);
+    }
 }
 
 }  // namespace
@@ -478,12 +500,14 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     const bool t2k = (kind == TE_CONV_T2);
-    const int KC = t2k ? Cfg<TE_CONV_T2>::KC : 8, BM = t2k ? 2 * Cfg<TE_CONV_T2>::MBW * 32 : 128;
+    const int tc = tile_class(M);
+    const int KC = t2k ? 16 : 8;
+    const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
     // split count comes from the real tile geometry of the main region and is shared by every region launch
     {
         const bool t2 = (kind == TE_CONV_T2);
-        const int ntile = 2 * 2 * 32;      // cells per block tile (NBW = 2 for every kind)
+        const int ntile = t2 ? 128 : (tc == 0 ? 128 : 256);      // cells per block tile of the chosen tile class
         int rh = H, rw = W;
         if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
         const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);

@@ -360,6 +360,9 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     }
 }
 
+// block tile: 8 waves (128 x 64 channels) by default; narrow layers (both channel counts <= 64, the 512 / 1024 px
+// generator tail) use the 4-wave 64 x 64 tile so half of the plain-operand rows are not zero padding
+inline int pick_nwp(int Co, int Ci);
 inline int wgrad_nwp() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TE_WGRAD_NWP"); v = (e && atoi(e) == 2) ? 2 : 4; }
@@ -394,10 +397,12 @@ bool fill_geometry(WgArgs& a) {
     a.magic_q1 = magic((unsigned)a.QH);
     // the 16-byte staging path needs full 32-cell rows whose global rows are 16 B aligned, and its one edge pass
     // (QCH * QH * 2 scalars) must fit a single sweep of the block
-    a.vec = (wgrad_nwp() == 4 && a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
+    a.vec = (pick_nwp(a.Co, a.Ci) == 4 && a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
              (((uintptr_t)a.g | (uintptr_t)a.x) & 15) == 0) ? 1 : 0;
     return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
 }
+
+inline int pick_nwp(int Co, int Ci) { return (wgrad_nwp() == 2 || (Co <= 64 && Ci <= 64)) ? 2 : 4; }
 
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
@@ -418,7 +423,7 @@ int launch_wgrad(WgArgs a, hipStream_t s) {
     if (!fill_geometry<KIND>(a)) return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: unsupported image size %dx%d", a.H, a.W);
     if ((int64_t)a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
         return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: per-sample tensor exceeds 2 GiB");
-    if (wgrad_nwp() == 2) launch_wgrad_t<KIND, 2>(a, s);
+    if (pick_nwp(a.Co, a.Ci) == 2) launch_wgrad_t<KIND, 2>(a, s);
     else launch_wgrad_t<KIND, 4>(a, s);
     return 0;
 }
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
-    const int64_t mn = te::cdiv((int64_t)Co * Ci, (wgrad_nwp() * 32) * QCH) * (int64_t)B;
+    const int64_t mn = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH) * (int64_t)B;
     int64_t S = te::cdiv(2 * te::kNumCU, mn);     // aim at >= 2 blocks (of 8 waves) per CU
     S = std::max<int64_t>(1, std::min<int64_t>(S, tiles));
     return (int)S;
