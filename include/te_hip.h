@@ -151,6 +151,17 @@ int te_attn_bwd_f32(float* gq, float* gk, float* gv, const float* go, const floa
                     const float* q, const float* k, const float* v, const float* sim, float scale, int N,
                     int G, int M, int L, int D, te_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * G2/A2  small dense layers (reference: EqualLinear.forward, model_spatial_query.py:213-221 — F.linear on
+ * weight * scale with bias * lr_mul, optional activation).  One fused launch on fp32 MFMA:
+ *     C[i,j] = act( alpha * sum_k A(i,k) * B(k,j) + beta * bias[j] ) + residual[i,j]      C, residual, pre: [I,J] row-major
+ * A(i,k) = a[i*sai + k*sak],  B(k,j) = b[k*sbk + j*sbj]  (element strides, so y = x W^T, dx = g W and dW = g^T x all map
+ * onto it).  bias / residual / pre (pre-activation copy) may be NULL.  act: 0 none, 1 GELU(erf), 3 lrelu(0.2)*sqrt(2).
+ */
+int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias, const float* residual,
+                      int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, float alpha, float beta,
+                      int act, te_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -313,3 +313,61 @@ def test_attention_block_golden(golden, name, cin):
     assert rel_err(y, g[f'{name}.y']) < 1e-4 and rel_err(sim, g[f'{name}.sim']) < 1e-4
     gx, gp = torch.autograd.grad((y * g[f'{name}.wy'].to(DEV)).sum(), (x, p))
     assert rel_err(gx, g[f'{name}.gx']) < 5e-4 and rel_err(gp, g[f'{name}.gp']) < 5e-4
+
+
+# ------------------------------------------------------------------------------------------------ G2/A2 small GEMM
+LINEAR_CASES = [   # rows-shape, K, N, act, residual, bias
+    ((16, 16), 512, 128, None, False, True),       # attention q/k/v
+    ((16, 16), 128, 512, None, True, True),        # attention proj + skip
+    ((16, 16), 512, 512, 'gelu', False, True),     # MLP up
+    ((16,), 512, 256, None, False, True),          # modulation (row slice of the latent)
+    ((4, 512), 16, 14, None, False, True),         # adjust_style: K = 16, N = 14 (ragged tile)
+    ((5,), 512, 1, None, False, True),             # discriminator's last layer (N = 1)
+    ((7,), 96, 40, 'lrelu', False, True),          # fused_lrelu mapping-style layer, ragged everything
+    ((33,), 36, 65, None, False, False),           # no bias
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,K,N,act,use_res,use_bias', LINEAR_CASES)
+def test_linear_fused_matches_torch(rows, K, N, act, use_res, use_bias):
+    from transeditor_amd.op.linear import _torch_expr, linear_fused
+    g = torch.Generator().manual_seed(K * 7 + N)
+    dev = 'cuda'
+    x = torch.randn(*rows, K, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(N, K, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True) if use_bias else None
+    r = torch.randn(*rows, N, generator=g).to(dev).requires_grad_(True) if use_res else None
+    alpha, beta = 1 / math.sqrt(K), 0.7
+    ins = [t for t in (x, w, b, r) if t is not None]
+    y = linear_fused(x, w, b, alpha, beta, act, r)
+    y_ref = _torch_expr(x.double(), w.double(), None if b is None else b.double(), alpha, beta, act,
+                        None if r is None else r.double())
+    assert y.shape == y_ref.shape
+    assert rel_err(y, y_ref.float()) < 1e-5
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    got = torch.autograd.grad(y, ins, gy)
+    want = torch.autograd.grad(y_ref, ins, gy.double())
+    for a_, b_ in zip(got, want):
+        assert rel_err(a_, b_.float()) < 2e-5
+    # recorded backward (path-length regulariser route): second derivative through the torch expression
+    gx, = torch.autograd.grad(linear_fused(x, w, b, alpha, beta, act, r), x, gy, create_graph=True)
+    gx_ref, = torch.autograd.grad(_torch_expr(x, w, b, alpha, beta, act, r), x, gy, create_graph=True)
+    got2 = torch.autograd.grad(gx.square().sum(), w)
+    want2 = torch.autograd.grad(gx_ref.square().sum(), w)
+    assert rel_err(got2[0], want2[0]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_linear_fused_strided_rows():
+    from transeditor_amd.op.linear import _torch_expr, linear_fused
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(16, 14, 512, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(64, 512, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(64, generator=g).cuda()
+    y = linear_fused(lat[:, 5], w, b, 0.04, 1.0)
+    y_ref = _torch_expr(lat[:, 5], w, b, 0.04, 1.0, None, None)
+    assert rel_err(y, y_ref) < 1e-5
+    gy = torch.randn(16, 64, generator=g).cuda()
+    for a_, b_ in zip(torch.autograd.grad(y, (lat, w), gy), torch.autograd.grad(y_ref, (lat, w), gy)):
+        assert rel_err(a_, b_) < 2e-5

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
 }
@@ -205,6 +206,20 @@ def rgb_wgrad_slabs(g, x):
     slabs = torch.empty(B, S, 3, K, 1, device=x.device, dtype=x.dtype)
     _check(lib().te_rgb_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), B, K, H * W, S, _stream()), 'te_rgb_wgrad_f32')
     return slabs
+
+
+# --------------------------------------------------------------------------------------------- G2/A2
+def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alpha=1.0, beta=1.0, act=0, want_pre=False):
+    """C[I,J] = act(alpha * A B + beta * bias) + residual with strided operands (see te_hip.h); a / b are the base
+    tensors (contiguous storage, addressed through the element strides)."""
+    c = torch.empty(I, J, device=a.device, dtype=a.dtype)
+    pre = torch.empty_like(c) if want_pre else None
+    for t in (a, b):           # addressed through explicit strides: only device / dtype are checked
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
+    _check(lib().te_small_gemm_f32(_ptr(c), _ptr(pre), a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), I, J, K, sai, sak, sbk,
+                                   sbj, alpha, beta, act, _stream()), 'te_small_gemm_f32')
+    return c, pre
 
 
 # --------------------------------------------------------------------------------------------- F2

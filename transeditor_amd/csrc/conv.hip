@@ -308,12 +308,26 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                     if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
                     if (ok) obase[(size_t)ci * p.Wo + cj] = v;
                 } else {
+                    // the two column phases of a cell are adjacent outputs: one 8-byte store per row phase (rows are 2W+1
+                    // wide, so the pair is only 4-byte aligned, which global stores accept)
 #pragma unroll
-                    for (int ph = 0; ph < 4; ++ph) {
-                        const int Y = 2 * ci + (ph >> 1), X = 2 * cj + (ph & 1);
-                        float v = acc[mb][nb * 4 + ph][r] * sc[r] + bi[r];
-                        if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
-                        if (ok && Y < p.Ho && X < p.Wo) obase[(size_t)Y * p.Wo + X] = v;
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int Y = 2 * ci + a2, X = 2 * cj;
+                        float v0 = acc[mb][nb * 4 + 2 * a2][r] * sc[r] + bi[r];
+                        float v1 = acc[mb][nb * 4 + 2 * a2 + 1][r] * sc[r] + bi[r];
+                        if (p.act == 3) {
+                            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * 1.4142135623730951f;
+                            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * 1.4142135623730951f;
+                        }
+                        if (ok && Y < p.Ho) {
+                            float* dst = obase + (size_t)Y * p.Wo + X;
+                            if (X + 1 < p.Wo) {
+                                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                                *reinterpret_cast<f32x2u*>(dst) = f32x2u{v0, v1};
+                            } else if (X < p.Wo) {
+                                dst[0] = v0;
+                            }
+                        }
                     }
                 }
             }

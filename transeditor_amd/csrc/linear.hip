@@ -1,0 +1,134 @@
+// Small dense layers of the mapping / attention stack (reference: EqualLinear.forward, model_spatial_query.py:213-221,
+// used ~60 times per generator pass on [256 | 16, 512]-sized activations).  These GEMMs are far too small for a
+// library GEMM's tile heuristics (hipBLASLt picks one 128x256 macro-tile for [256,512]x[512,128]: 61 us) and each
+// costs 3-8 separate launches (weight * scale, bias * lr_mul, GEMM, bias add, activation, residual).  One kernel:
+//
+//     C[i,j] = act( alpha * sum_k A(i,k) * B(k,j) + beta * bias[j] ) + residual[i,j]
+//
+// with arbitrary element strides for A and B, so the same kernel computes  y = x W^T  (forward),  dx = g W  and
+// dW = g^T x.  Exact fp32 on v_mfma_f32_32x32x2_f32.  No LDS staging: everything is L2-resident (<= 1 MB operands); a
+// block of 1-16 waves owns one 32x32 output tile, the waves split K and combine through LDS.  Operands whose
+// reduction index is contiguous are read 16 bytes per lane (one load feeds 4 MFMAs).
+#include "te_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LinArgs {
+    float* c;
+    float* pre;              // optional: pre-activation output (for the GELU backward)
+    const float* a;
+    const float* b;
+    const float* bias;
+    const float* residual;
+    int I, J, K;
+    int64_t sai, sak, sbk, sbj;   // element strides: A(i,k) = a[i*sai + k*sak], B(k,j) = b[k*sbk + j*sbj]
+    float alpha, beta;
+    int act;                 // 0 none, 1 GELU (erf), 3 leaky-ReLU(0.2) * sqrt(2)
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// AV / BV: the operand's reduction stride is 1 and rows are 16-byte aligned -> float4 loads.
+// NW waves share one 32x32 tile and split K (host picks NW so a wave's slice is <= 64: every load of the slice is in
+// flight at once, the kernel costs one memory latency + <= 32 MFMAs); all waves then reduce the NW partial tiles through
+// LDS, one output element per thread, so the epilogue's loads and stores are coalesced rows.
+template <int NW, bool AV, bool BV>
+__global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
+    __shared__ float red[NW][32 * 32];     // 64 KB at NW = 16
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int ia = min(i0 + l31, p.I - 1), jb = min(j0 + l31, p.J - 1);     // clamped: padded rows / columns are never stored
+    const float* ap = p.a + (int64_t)ia * p.sai;
+    const float* bp = p.b + (int64_t)jb * p.sbj;
+    // this wave's K range (multiples of 8 so the float4 path stays aligned)
+    const int kq = ((p.K + 8 * NW - 1) / (8 * NW)) * 8;
+    const int kb = wid * kq, ke = min(p.K, kb + kq);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll 8
+    for (int k = kb; k < ke; k += 8) {
+        // lane (row, half) supplies k = k + 4*half + {0,1,2,3} over four MFMAs (A and B use the same assignment)
+        const int kk = k + 4 * half;
+        float av[4], bv[4];
+        if (AV && kk + 3 < ke) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(ap + kk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = t[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = (kk + q < ke) ? ap[(int64_t)(kk + q) * p.sak] : 0.f;
+        }
+        if (BV && kk + 3 < ke) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bp + kk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = t[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = (kk + q < ke) ? bp[(int64_t)(kk + q) * p.sbk] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    }
+
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 1024; e += NW * 64) {
+        const int row = e >> 5, col = e & 31, i = i0 + row, j = j0 + col;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][e];
+        if (i < p.I && j < p.J) {
+            v *= p.alpha;
+            if (p.bias) v += p.bias[j] * p.beta;
+            const int64_t o = (int64_t)i * p.J + j;
+            if (p.pre) p.pre[o] = v;
+            if (p.act == 1) v = gelu_erf(v);
+            else if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+            if (p.residual) v += p.residual[o];
+            p.c[o] = v;
+        }
+    }
+}
+
+template <int NW>
+void launch_nw(const LinArgs& p, bool av, bool bv, dim3 grid, hipStream_t s) {
+    if (av && bv) small_gemm_kernel<NW, true, true><<<grid, NW * 64, 0, s>>>(p);
+    else if (av) small_gemm_kernel<NW, true, false><<<grid, NW * 64, 0, s>>>(p);
+    else if (bv) small_gemm_kernel<NW, false, true><<<grid, NW * 64, 0, s>>>(p);
+    else small_gemm_kernel<NW, false, false><<<grid, NW * 64, 0, s>>>(p);
+}
+
+}  // namespace
+
+extern "C" int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias,
+                                 const float* residual, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
+                                 int64_t sbj, float alpha, float beta, int act, te_stream_t stream_) {
+    TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_f32: NULL pointer");
+    TE_REQUIRE(I > 0 && J > 0 && K > 0, TE_ERR_SHAPE, "te_small_gemm_f32: bad dims");
+    TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_f32: act must be 0, 1 or 3");
+    LinArgs p{c, pre, a, b, bias, residual, I, J, K, sai, sak, sbk, sbj, alpha, beta, act};
+    const bool av = sak == 1 && sai % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
+    const bool bv = sbk == 1 && sbj % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
+    dim3 grid((unsigned)te::cdiv(J, 32), (unsigned)te::cdiv(I, 32));
+    hipStream_t s = (hipStream_t)stream_;
+    // waves per tile: a wave's K slice <= 64 where possible, and more waves when the grid alone cannot fill the chip
+    const int64_t tiles = (int64_t)grid.x * grid.y;
+    int nw = K > 256 ? 8 : (K > 64 ? 4 : (K > 16 ? 2 : 1));
+    if (K >= 512 && (K > 512 || tiles < 2 * te::kNumCU)) nw = 16;
+    if (nw == 16) launch_nw<16>(p, av, bv, grid, s);
+    else if (nw == 8) launch_nw<8>(p, av, bv, grid, s);
+    else if (nw == 4) launch_nw<4>(p, av, bv, grid, s);
+    else if (nw == 2) launch_nw<2>(p, av, bv, grid, s);
+    else launch_nw<1>(p, av, bv, grid, s);
+    return te::launch_status("te_small_gemm_f32");
+}

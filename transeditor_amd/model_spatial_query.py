@@ -26,6 +26,7 @@ from torch.nn import functional as F
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
+from .op.linear import linear_fused
 from .op.modconv import modconv
 
 CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm,
@@ -130,10 +131,14 @@ class EqualLinear(nn.Module):                                                   
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
         self.lr_mul = lr_mul
 
-    def forward(self, input):
+    def forward(self, input, act=None, residual=None):
+        """One fused launch (op/linear.py): act(scale * x W^T + lr_mul * b) + residual.  `act` / `residual` are
+        extensions used by the attention blocks ('gelu', skip connection); activation='fused_lrelu' is the reference's."""
         if self.activation:
-            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
-        return F.linear(input, self.weight * self.scale, bias=None if self.bias is None else self.bias * self.lr_mul)
+            if self.bias is None:       # the reference fails the same way (bias * lr_mul on None)
+                raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'float'")
+            return linear_fused(input, self.weight, self.bias, self.scale, self.lr_mul, 'lrelu')
+        return linear_fused(input, self.weight, self.bias, self.scale, self.lr_mul, act, residual)
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
@@ -481,24 +486,6 @@ class Discriminator(nn.Module):                                                 
         return self.final_linear(out.view(batch, -1))
 
 
-_WIDE = 384
-
-
-def _wide_linear(x, weight, bias):
-    """F.linear for a narrow layer, evaluated as a zero-padded >= 384-wide GEMM (padding sliced off again).
-    hipBLASLt's heuristic picks a single 128x256 macro-tile for [256, 512] x [512, 128 | 256] (61 / 118 us measured
-    on MI355X, one workgroup) but a well-parallelised kernel from 384 columns on (<= 19 us, launch-bound); the
-    padding makes forward, dx and dW all land on the fast shapes.  Mathematically exact (zeros contribute 0)."""
-    out_f, in_f = weight.shape
-    if in_f < _WIDE:
-        x = F.pad(x, (0, _WIDE - in_f))
-        weight = F.pad(weight, (0, _WIDE - in_f))
-    if out_f < _WIDE:
-        weight = F.pad(weight, (0, 0, 0, _WIDE - out_f))
-    y = F.linear(x, weight)[..., :out_f]
-    return y if bias is None else y + bias
-
-
 class Attention(nn.Module):                                                          # :862-901
     def __init__(self, in_dim, param_dim, out_dim, lr_mul=1.0, groups=4, compress=4):
         assert out_dim % (groups * compress) == 0
@@ -513,17 +500,13 @@ class Attention(nn.Module):                                                     
         self.v_transform = EqualLinear(in_dim, self.planes, lr_mul=lr_mul)
         self.proj = EqualLinear(self.planes, out_dim, lr_mul=lr_mul)
 
-    def forward(self, attention, op_param, return_similarity=False):
-        # q/k/v/proj are 128-wide: evaluated through _wide_linear (k and v share one GEMM); same math as the
-        # EqualLinear modules (weight * scale, bias * lr_mul), whose parameters stay the state_dict entries
-        qt, kt, vt, pt = self.q_transform, self.k_transform, self.v_transform, self.proj
-        q = _wide_linear(op_param, qt.weight * qt.scale, qt.bias * qt.lr_mul)   # [N, M, planes]; head g = channels g*gp..
-        kv = _wide_linear(attention, torch.cat([kt.weight, vt.weight]) * kt.scale, torch.cat([kt.bias, vt.bias]) * kt.lr_mul)
-        k, v = kv[..., :self.planes], kv[..., self.planes:]
+    def forward(self, attention, op_param, return_similarity=False, residual=None):
+        q = self.q_transform(op_param)                     # [N, M, planes]; head g = channels g*gp..
+        k, v = self.k_transform(attention), self.v_transform(attention)
         # softmax(scale q k^T) v per head; the reference's reshape(N, planes, L).permute(0,2,1) (:894, with
         # L == M) lands exactly on this token-major [N, M, planes] layout
         stacked, similarity = attention_core(q, k, v, self.scale, self.groups)
-        output = _wide_linear(stacked, pt.weight * pt.scale, pt.bias * pt.lr_mul)
+        output = self.proj(stacked, residual=residual)     # the block's skip connection rides in the epilogue
         return (output, similarity) if return_similarity else output
 
 
@@ -538,8 +521,9 @@ class AttentionBlock(nn.Module):                                                
             self.proj = EqualLinear(in_dim, out_dim, lr_mul=lr_mul)
 
     def forward(self, x, op_param, return_similarity=False):
-        a = self.atten(F.layer_norm(x, x.size()[1:]), op_param, return_similarity=return_similarity)
-        a, similarity = a if return_similarity else (a, None)
-        x = (self.proj(x) if self.out_dim != self.in_dim else x) + a
-        x = x + self.mlp(F.layer_norm(x, x.size()[1:]))
+        skip = self.proj(x) if self.out_dim != self.in_dim else x
+        a = self.atten(F.layer_norm(x, x.size()[1:]), op_param, return_similarity=return_similarity, residual=skip)
+        x, similarity = a if return_similarity else (a, None)           # x = skip + attention (:926-930)
+        h = self.mlp[0](F.layer_norm(x, x.size()[1:]), act='gelu')      # Linear + GELU, then Linear + skip (:932-934)
+        x = self.mlp[2](h, residual=x)
         return (x, similarity) if return_similarity else x
