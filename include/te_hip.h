@@ -126,15 +126,16 @@ int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const float* slabs,
 /* ---------------------------------------------------------------------------------------------
  * M3  ToRGB: 1x1 modulated convolution to 3 channels (reference: ToRGB.forward, model_spatial_query.py:
  * 416-425 — grouped 1x1 F.conv2d, demodulate=False).  HBM-bound streaming kernels (x [B,K,HW] touched once):
- *   fwd   out[b,o,p] = sum_k w[o,k] isc[b,k] x[b,k,p] + bias[o]          w [3,K], isc/bias may be NULL
- *   dgrad gx[b,k,p]  = isc[b,k] sum_o w[o,k] g[b,o,p]
+ *   fwd   out[b,o,p] = sum_k wscale w[o,k] isc[b,k] x[b,k,p] + bias[o]   w [3,K], isc/bias may be NULL
+ *   dgrad gx[b,k,p]  = wscale isc[b,k] sum_o w[o,k] g[b,o,p]
  *   wgrad slabs[b][c][o][k] = sum_{p in chunk c} g[b,o,p] x[b,k,p]       (finish with te_wgrad_reduce_f32, taps = 1)
  * te_rgb_supported: 1 if (M == 3, K <= 512, HW % 4 == 0), else use te_conv_f32(TE_CONV_1X1).
  */
 int te_rgb_supported(int M, int K, int HW);
-int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, int B, int K, int HW,
-                   te_stream_t stream);
-int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, int B, int K, int HW, te_stream_t stream);
+int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, float wscale, int B,
+                   int K, int HW, te_stream_t stream);
+int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, float wscale, int B, int K, int HW,
+                     te_stream_t stream);
 int te_rgb_wgrad_slab_count(int B, int K, int HW);
 int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream);
 
@@ -157,10 +158,24 @@ int te_attn_bwd_f32(float* gq, float* gk, float* gv, const float* go, const floa
  *     C[i,j] = act( alpha * sum_k A(i,k) * B(k,j) + beta * bias[j] ) + residual[i,j]      C, residual, pre: [I,J] row-major
  * A(i,k) = a[i*sai + k*sak],  B(k,j) = b[k*sbk + j*sbj]  (element strides, so y = x W^T, dx = g W and dW = g^T x all map
  * onto it).  bias / residual / pre (pre-activation copy) may be NULL.  act: 0 none, 1 GELU(erf), 3 lrelu(0.2)*sqrt(2).
+ * arowsum (may be NULL): arowsum[i] = rs_scale * sum_k A(i,k) — the bias gradient, for free, in the dW = g^T x call.
  */
 int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias, const float* residual,
-                      int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, float alpha, float beta,
-                      int act, te_stream_t stream);
+                      float* arowsum, float rs_scale, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
+                      int64_t sbj, float alpha, float beta, int act, te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * M1  demodulation coefficients (reference: ModulatedConv2d.forward, model_spatial_query.py:300-304 —
+ * rsqrt(sum (scale * W * style)^2 + 1e-8) over B materialised weight copies).  Shared-weight form:
+ *   wsq[co,ci] = wscale^2 sum_t w[co,ci,t]^2            (output, kept for the backward)
+ *   d[b,co]    = rsqrt(sum_ci s[b,ci]^2 wsq[co,ci] + eps)
+ * backward, u = -gd d^3 / 2:  gw[co,ci,t] = 2 wscale^2 w sum_b u[b,co] s[b,ci]^2,  gs[b,ci] = 2 s sum_co u[b,co] wsq[co,ci]
+ * (gw / gs may be NULL; B <= 64 in the backward).  w [Co,Ci,T], s [B,Ci], d / gd [B,Co].
+ */
+int te_demod_fwd_f32(float* d, float* wsq, const float* w, const float* s, float wscale, float eps, int B, int Co, int Ci,
+                     int T, te_stream_t stream);
+int te_demod_bwd_f32(float* gw, float* gs, const float* gd, const float* d, const float* w, const float* wsq,
+                     const float* s, float wscale, int B, int Co, int Ci, int T, te_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -192,13 +192,14 @@ def test_modconv_fused_kernel_vs_composite(kind, shape, act):
     bias = synth.normal((M,), 'mf.b').requires_grad_(True)
     if kind == 'up' and act:
         pytest.skip('upsampling layers fuse the activation into the blur kernel instead')
-    y_ref = _ref_conv(kind, x * isc[:, :, None, None], w) * osc[:, :, None, None] + bias[None, :, None, None]
+    ws = 1.0 if B == 3 else 1.7           # equalised-lr constant applied inside the kernels (pack / reducer)
+    y_ref = _ref_conv(kind, x * isc[:, :, None, None], w * ws) * osc[:, :, None, None] + bias[None, :, None, None]
     if act:
         y_ref = F.leaky_relu(y_ref, 0.2) * math.sqrt(2)
     gy = synth.normal(tuple(y_ref.shape), 'mf.g')
     ref = torch.autograd.grad((y_ref * gy).sum(), (x, w, isc, osc, bias))
     d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, isc, osc, bias)]
-    y = modconv(d[0], d[1], d[2], d[3], d[4], act, kind)
+    y = modconv(d[0], d[1], d[2], d[3], d[4], act, kind, ws)
     assert rel_err(y, y_ref) < OP_TOL
     got = torch.autograd.grad((y * gy.to(DEV)).sum(), d)
     for name, a, b in zip(('gx', 'gw', 'gisc', 'gosc', 'gbias'), got, ref):
@@ -215,11 +216,11 @@ def test_torgb_streaming_kernels(shape):
     w = (synth.normal((3, K, 1, 1), 'rgb.w') / math.sqrt(K)).requires_grad_(True)
     isc = (1 + 0.5 * synth.normal((B, K), 'rgb.i')).requires_grad_(True)
     bias = synth.normal((3,), 'rgb.b').requires_grad_(True)
-    y_ref = F.conv2d(x * isc[:, :, None, None], w) + bias[None, :, None, None]
+    y_ref = F.conv2d(x * isc[:, :, None, None], w * 0.6) + bias[None, :, None, None]
     gy = synth.normal(tuple(y_ref.shape), 'rgb.g')
     ref = torch.autograd.grad((y_ref * gy).sum(), (x, w, isc, bias))
     d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, isc, bias)]
-    y = modconv(d[0], d[1], d[2], None, d[3], False, '1x1')
+    y = modconv(d[0], d[1], d[2], None, d[3], False, '1x1', 0.6)
     assert rel_err(y, y_ref) < OP_TOL
     got = torch.autograd.grad((y * gy.to(DEV)).sum(), d)
     for name, a, b in zip(('gx', 'gw', 'gisc', 'gbias'), got, ref):
@@ -244,12 +245,38 @@ def test_discriminator_conv_kinds_fused_bias_act(kind, shape):
         r1 = gx.pow(2).sum()
         return y, gx, torch.autograd.grad(r1, (w, bias), retain_graph=True), torch.autograd.grad((y * gy).sum(), (w, bias))
 
-    ref = run(lambda a, b, c: F.leaky_relu(_ref_conv(kind, a, b) + c[None, :, None, None], 0.2) * math.sqrt(2), x, w, bias, 'cpu')
+    ref = run(lambda a, b, c: F.leaky_relu(_ref_conv(kind, a, b * 1.3) + c[None, :, None, None], 0.2) * math.sqrt(2), x, w, bias, 'cpu')
     d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, bias)]
-    got = run(lambda a, b, c: modconv(a, b, None, None, c, True, kind), d[0], d[1], d[2], DEV)
+    got = run(lambda a, b, c: modconv(a, b, None, None, c, True, kind, 1.3), d[0], d[1], d[2], DEV)
     assert rel_err(got[0], ref[0]) < OP_TOL and rel_err(got[1], ref[1]) < OP_TOL
     for a, b in zip(got[2] + got[3], ref[2] + ref[3]):
         assert rel_err(a, b) < 5e-4
+
+
+@pytest.mark.parametrize('shape', [(16, 512, 512, 9), (3, 40, 24, 9), (2, 3, 130, 1), (64, 128, 256, 9)])
+def test_demod_kernels(shape):
+    """d = rsqrt(sum (wscale w s)^2 + eps) (model_spatial_query.py:300-304): forward, gw / gs, and the recorded backward."""
+    from transeditor_amd.op.style import _torch_expr, demod
+    B, Co, Ci, T = shape
+    k = 3 if T == 9 else 1
+    w = synth.normal((Co, Ci, k, k), 'dm.w').requires_grad_(True)
+    s = (1 + 0.5 * synth.normal((B, Ci), 'dm.s')).requires_grad_(True)
+    ws = 1 / math.sqrt(Ci * T)
+    gd = synth.normal((B, Co), 'dm.g')
+
+    def run(f, w, s, gd):
+        d = f(w, s, ws, 1e-8)
+        gw, gs = torch.autograd.grad(d, (w, s), gd, create_graph=True)
+        return d, gw, gs, torch.autograd.grad(gs.pow(2).sum() + gw.pow(2).sum(), (w, s))
+
+    ref = run(_torch_expr, w.double(), s.double(), gd.double())
+    wd, sd = (t.detach().to(DEV).requires_grad_(True) for t in (w, s))
+    d = demod(wd, sd, ws, 1e-8)
+    assert rel_err(d, ref[0].float()) < 1e-5
+    gw, gs = torch.autograd.grad(d, (wd, sd), gd.to(DEV))
+    assert rel_err(gw, ref[1].float()) < 2e-5 and rel_err(gs, ref[2].float()) < 2e-5
+    got = run(demod, wd, sd, gd.to(DEV))
+    assert rel_err(got[3][0], ref[3][0].float()) < 1e-4 and rel_err(got[3][1], ref[3][1].float()) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ F1 module

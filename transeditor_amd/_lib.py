@@ -32,11 +32,13 @@ _SIGNATURES = {
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     'te_rgb_supported': (C.c_int, [_I, _I, _I]),
-    'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
     'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
+    'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
+    'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
+    'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
 }
@@ -181,20 +183,20 @@ def rgb_supported(M, K, HW):
     return bool(lib().te_rgb_supported(M, K, HW))
 
 
-def rgb_fwd(x, w, isc, bias):
+def rgb_fwd(x, w, isc, bias, wscale=1.0):
     x = x.contiguous()
     B, K, H, W = x.shape
     out = torch.empty(B, 3, H, W, device=x.device, dtype=x.dtype)
-    _check(lib().te_rgb_fwd_f32(_ptr(out), _ptr(x), _ptr(w.contiguous()), _ptr(isc), _ptr(bias), B, K, H * W, _stream()),
+    _check(lib().te_rgb_fwd_f32(_ptr(out), _ptr(x), _ptr(w.contiguous()), _ptr(isc), _ptr(bias), wscale, B, K, H * W, _stream()),
            'te_rgb_fwd_f32')
     return out
 
 
-def rgb_dgrad(g, w, isc, K):
+def rgb_dgrad(g, w, isc, K, wscale=1.0):
     g = g.contiguous()
     B, _, H, W = g.shape
     gx = torch.empty(B, K, H, W, device=g.device, dtype=g.dtype)
-    _check(lib().te_rgb_dgrad_f32(_ptr(gx), _ptr(g), _ptr(w.contiguous()), _ptr(isc), B, K, H * W, _stream()),
+    _check(lib().te_rgb_dgrad_f32(_ptr(gx), _ptr(g), _ptr(w.contiguous()), _ptr(isc), wscale, B, K, H * W, _stream()),
            'te_rgb_dgrad_f32')
     return gx
 
@@ -209,17 +211,43 @@ def rgb_wgrad_slabs(g, x):
 
 
 # --------------------------------------------------------------------------------------------- G2/A2
-def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alpha=1.0, beta=1.0, act=0, want_pre=False):
+def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alpha=1.0, beta=1.0, act=0, want_pre=False,
+               rowsum_scale=None):
     """C[I,J] = act(alpha * A B + beta * bias) + residual with strided operands (see te_hip.h); a / b are the base
-    tensors (contiguous storage, addressed through the element strides)."""
+    tensors (contiguous storage, addressed through the element strides).  Returns (C, pre | None, rowsum | None);
+    rowsum_scale != None asks for rowsum[i] = rowsum_scale * sum_k A(i,k)."""
     c = torch.empty(I, J, device=a.device, dtype=a.dtype)
     pre = torch.empty_like(c) if want_pre else None
+    rs = torch.empty(I, device=a.device, dtype=a.dtype) if rowsum_scale is not None else None
     for t in (a, b):           # addressed through explicit strides: only device / dtype are checked
         if not (t.is_cuda and t.dtype == torch.float32):
             raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
-    _check(lib().te_small_gemm_f32(_ptr(c), _ptr(pre), a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), I, J, K, sai, sak, sbk,
-                                   sbj, alpha, beta, act, _stream()), 'te_small_gemm_f32')
-    return c, pre
+    _check(lib().te_small_gemm_f32(_ptr(c), _ptr(pre), a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rs),
+                                   rowsum_scale if rowsum_scale is not None else 0.0, I, J, K, sai, sak, sbk, sbj, alpha,
+                                   beta, act, _stream()), 'te_small_gemm_f32')
+    return c, pre, rs
+
+
+# --------------------------------------------------------------------------------------------- M1
+def demod_fwd(w, s, wscale, eps):
+    """w [Co,Ci,T] raw weights, s [B,Ci] -> (d [B,Co], wsq [Co,Ci])"""
+    Co, Ci, T = w.shape
+    B = s.shape[0]
+    d = torch.empty(B, Co, device=w.device, dtype=w.dtype)
+    wsq = torch.empty(Co, Ci, device=w.device, dtype=w.dtype)
+    _check(lib().te_demod_fwd_f32(_ptr(d), _ptr(wsq), _ptr(w), _ptr(s), wscale, eps, B, Co, Ci, T, _stream()),
+           'te_demod_fwd_f32')
+    return d, wsq
+
+
+def demod_bwd(gd, d, w, wsq, s, wscale, want_w=True, want_s=True):
+    Co, Ci, T = w.shape
+    B = s.shape[0]
+    gw = torch.empty_like(w) if want_w else None
+    gs = torch.empty_like(s) if want_s else None
+    _check(lib().te_demod_bwd_f32(_ptr(gw), _ptr(gs), _ptr(gd.contiguous()), _ptr(d), _ptr(w), _ptr(wsq), _ptr(s), wscale,
+                                  B, Co, Ci, T, _stream()), 'te_demod_bwd_f32')
+    return gw, gs
 
 
 # --------------------------------------------------------------------------------------------- F2

@@ -23,6 +23,8 @@ struct LinArgs {
     const float* b;
     const float* bias;
     const float* residual;
+    float* arowsum;          // optional: arowsum[i] = rs_scale * sum_k A(i,k)  (bias gradient when A = g^T)
+    float rs_scale;
     int I, J, K;
     int64_t sai, sak, sbk, sbj;   // element strides: A(i,k) = a[i*sai + k*sak], B(k,j) = b[k*sbk + j*sbj]
     float alpha, beta;
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float asum = 0.f;
 
 #pragma unroll 8
     for (int k = kb; k < ke; k += 8) {
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        asum += (av[0] + av[1]) + (av[2] + av[3]);
     }
 
     // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -98,6 +102,17 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
             p.c[o] = v;
         }
     }
+    if (p.arowsum && blockIdx.x == 0) {          // uniform branch; the tile partials are consumed, reuse the LDS
+        __syncthreads();
+        red[0][tid] = asum;
+        __syncthreads();
+        if (tid < 32 && i0 + tid < p.I) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[0][w * 64 + tid] + red[0][w * 64 + 32 + tid];
+            p.arowsum[i0 + tid] = t * p.rs_scale;
+        }
+    }
 }
 
 template <int NW>
@@ -111,12 +126,13 @@ void launch_nw(const LinArgs& p, bool av, bool bv, dim3 grid, hipStream_t s) {
 }  // namespace
 
 extern "C" int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias,
-                                 const float* residual, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
-                                 int64_t sbj, float alpha, float beta, int act, te_stream_t stream_) {
+                                 const float* residual, float* arowsum, float rs_scale, int I, int J, int K,
+                                 int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, float alpha, float beta, int act,
+                                 te_stream_t stream_) {
     TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_f32: NULL pointer");
     TE_REQUIRE(I > 0 && J > 0 && K > 0, TE_ERR_SHAPE, "te_small_gemm_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_f32: act must be 0, 1 or 3");
-    LinArgs p{c, pre, a, b, bias, residual, I, J, K, sai, sak, sbk, sbj, alpha, beta, act};
+    LinArgs p{c, pre, a, b, bias, residual, arowsum, rs_scale, I, J, K, sai, sak, sbk, sbj, alpha, beta, act};
     const bool av = sak == 1 && sai % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
     const bool bv = sbk == 1 && sbj % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
     dim3 grid((unsigned)te::cdiv(J, 32), (unsigned)te::cdiv(I, 32));

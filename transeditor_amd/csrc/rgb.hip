@@ -14,11 +14,11 @@ constexpr int NOUT = 3;
 
 __global__ __launch_bounds__(256) void rgb_fwd_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ isc,
-                                                      const float* __restrict__ bias, int K, int HW) {
+                                                      const float* __restrict__ bias, float wscale, int K, int HW) {
     __shared__ float ws[NOUT][KMAX];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int k = tid; k < K; k += 256) {
-        const float s = isc ? isc[(size_t)b * K + k] : 1.f;
+        const float s = (isc ? isc[(size_t)b * K + k] : 1.f) * wscale;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) ws[o][k] = w[o * K + k] * s;
     }
@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(float* __restrict__ out, c
 }
 
 __global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, const float* __restrict__ g,
-                                                        const float* __restrict__ w, const float* __restrict__ isc, int K,
-                                                        int HW) {
+                                                        const float* __restrict__ w, const float* __restrict__ isc,
+                                                        float wscale, int K, int HW) {
     __shared__ float ws[NOUT][KMAX];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int k = tid; k < K; k += 256) {
-        const float s = isc ? isc[(size_t)b * K + k] : 1.f;
+        const float s = (isc ? isc[(size_t)b * K + k] : 1.f) * wscale;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) ws[o][k] = w[o * K + k] * s;
     }
@@ -144,21 +144,21 @@ inline bool ok_shape(int K, int HW) { return K > 0 && K <= KMAX && HW > 0 && (HW
 
 extern "C" int te_rgb_supported(int M, int K, int HW) { return (M == NOUT && ok_shape(K, HW)) ? 1 : 0; }
 
-extern "C" int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, int B, int K,
-                              int HW, te_stream_t stream_) {
+extern "C" int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc, const float* bias, float wscale,
+                              int B, int K, int HW, te_stream_t stream_) {
     TE_REQUIRE(out && x && w, TE_ERR_NULL, "te_rgb_fwd_f32: NULL pointer");
     TE_REQUIRE(B > 0 && ok_shape(K, HW), TE_ERR_UNSUPPORTED, "te_rgb_fwd_f32: need K <= 512 and H*W %% 4 == 0");
     dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
-    rgb_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(out, x, w, isc, bias, K, HW);
+    rgb_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(out, x, w, isc, bias, wscale, K, HW);
     return te::launch_status("te_rgb_fwd_f32");
 }
 
-extern "C" int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, int B, int K, int HW,
-                                te_stream_t stream_) {
+extern "C" int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, float wscale, int B, int K,
+                                int HW, te_stream_t stream_) {
     TE_REQUIRE(gx && g && w, TE_ERR_NULL, "te_rgb_dgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && ok_shape(K, HW), TE_ERR_UNSUPPORTED, "te_rgb_dgrad_f32: need K <= 512 and H*W %% 4 == 0");
     dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
-    rgb_dgrad_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, w, isc, K, HW);
+    rgb_dgrad_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, w, isc, wscale, K, HW);
     return te::launch_status("te_rgb_dgrad_f32");
 }
 

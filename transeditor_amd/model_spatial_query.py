@@ -28,6 +28,7 @@ from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
 from .op.linear import linear_fused
 from .op.modconv import modconv
+from .op.style import demod
 
 CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm,
                        512: 32 * cm, 1024: 16 * cm}     # :473-483
@@ -101,20 +102,20 @@ class EqualConv2d(nn.Module):                                                   
         """`act_bias` (extension used by ConvLayer): fuse '+ act_bias' and the scaled leaky-ReLU that follows.
         The four configurations the discriminator uses run on the MI355X convolution kernels (same family as the
         generator, no modulation); anything else falls back to the library convolution."""
-        w = self.weight * self.scale
+        w, ws = self.weight, self.scale
         k, cfg = self.weight.shape[2], (self.weight.shape[2], self.stride, self.padding)
         act = act_bias is not None
         bias = act_bias if act else self.bias
         if input.is_cuda and input.dtype == torch.float32:
             if cfg == (3, 1, 1):
-                return modconv(input, w, None, None, bias, act, '3x3')
+                return modconv(input, w, None, None, bias, act, '3x3', ws)
             if cfg == (1, 1, 0):
-                return modconv(input, w, None, None, bias, act, '1x1')
+                return modconv(input, w, None, None, bias, act, '1x1', ws)
             if cfg == (3, 2, 0) and input.shape[2] % 2 == 1 and input.shape[3] % 2 == 1:
-                return modconv(input, w, None, None, bias, act, 'down')
+                return modconv(input, w, None, None, bias, act, 'down', ws)
             if cfg == (1, 2, 0):
-                return modconv(input[:, :, ::2, ::2].contiguous(), w, None, None, bias, act, '1x1')
-        out = F.conv2d(input, w, bias=self.bias, stride=self.stride, padding=self.padding)
+                return modconv(input[:, :, ::2, ::2].contiguous(), w, None, None, bias, act, '1x1', ws)
+        out = F.conv2d(input, w * ws, bias=self.bias, stride=self.stride, padding=self.padding)
         return fused_leaky_relu(out, act_bias) if act else out
 
     def __repr__(self):
@@ -184,21 +185,20 @@ class ModulatedConv2d(nn.Module):                                               
         return 'up' if self.upsample else ('3x3' if self.kernel_size == 3 else '1x1')
 
     def scales(self, style):
-        """(w, s, d): shared scaled weight [Co,Ci,k,k], style scale [B,Ci], demodulation [B,Co] or None.
-        d[b,co] = rsqrt(sum_ci s^2 * sum_k w^2 + eps)  ==  :300-304 without the B weight copies."""
+        """(w, s, d): shared UNSCALED weight [Co,Ci,k,k] (the kernels apply self.scale), style scale [B,Ci],
+        demodulation [B,Co] or None.  d[b,co] = rsqrt(sum_ci s^2 * sum_k (scale w)^2 + eps)  ==  :300-304 without the B
+        weight copies, one launch (op/style.py)."""
         s = self.modulation(style)
-        w = self.weight[0] * self.scale
-        d = None
-        if self.demodulate:
-            d = torch.rsqrt(s.pow(2) @ w.pow(2).sum(dim=(2, 3)).t() + self.eps)
+        w = self.weight.view(self.weight.shape[1:])
+        d = demod(w, s, self.scale, self.eps) if self.demodulate else None
         return w, s, d
 
     def forward(self, input, style, bias=None, act=False):
         """`bias`/`act` (extensions used by StyledConv / ToRGB) fuse '+ bias' and the scaled leaky-ReLU."""
         w, s, d = self.scales(style)
         if not self.upsample:
-            return modconv(input, w, s, d, bias, act, self.kind)
-        out = modconv(input, w, s, d, None, False, 'up')
+            return modconv(input, w, s, d, bias, act, self.kind, self.scale)
+        out = modconv(input, w, s, d, None, False, 'up', self.scale)
         if act:
             return blur_bias_act(out, self.blur.kernel, bias, self.blur.pad)
         out = self.blur(out)
@@ -393,14 +393,17 @@ class Generator(nn.Module):                                                     
 
         batch = spatialcode.shape[0]
         out = spatialcode.permute(0, 2, 1).reshape(batch, 512, 4, 4)                 # :699  P code IS the 4x4 map
-        out = self.conv1(out, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        # per-layer styles latent[:, i]: one contiguous copy + one unbind, so the backward is a single stack instead of
+        # a zero-fill + add of the whole latent per layer
+        lat = latent.contiguous().unbind(1)
+        out = self.conv1(out, lat[0], noise=noise[0])
+        skip = self.to_rgb1(out, lat[1])
         i = 1
         for conv_up, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                  self.to_rgbs):
-            out = conv_up(out, latent[:, i], noise=n1)
-            out = conv(out, latent[:, i + 1], noise=n2)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = conv_up(out, lat[i], noise=n1)
+            out = conv(out, lat[i + 1], noise=n2)
+            skip = to_rgb(out, lat[i + 2], skip)
             i += 2
         image = skip
 

@@ -40,7 +40,7 @@ class _Linear(Function):
         N, K = weight.shape
         x2 = _rows(x, K)
         res2 = None if residual is None else residual.reshape(-1, N).contiguous()
-        y, pre = _lib.small_gemm(x2.shape[0], N, K, x2, x2.stride(0), 1, weight.contiguous(), 1, K, bias, res2, alpha, beta,
+        y, pre, _ = _lib.small_gemm(x2.shape[0], N, K, x2, x2.stride(0), 1, weight.contiguous(), 1, K, bias, res2, alpha, beta,
                                  _ACT[act], want_pre=(act == 'gelu'))
         ctx.save_for_backward(x, weight, bias, residual, pre if act == 'gelu' else (y if act == 'lrelu' else None))
         ctx.cfg = (alpha, beta, act)
@@ -69,11 +69,18 @@ class _Linear(Function):
         gx = gw = gb = None
         if need[0]:     # dx[R,K] = alpha * g[R,N] W[N,K]
             gx = _lib.small_gemm(R, K, N, g, N, 1, weight.contiguous(), K, 1, alpha=alpha)[0].reshape(x.shape)
-        if need[1]:     # dW[N,K] = alpha * g^T[N,R] x[R,K]
+        want_b = bias is not None and need[2]
+        if need[1]:     # dW[N,K] = alpha * g^T[N,R] x[R,K];  db = beta * row sums of g^T come out of the same launch
             x2 = _rows(x, K)
-            gw = _lib.small_gemm(N, K, R, g, 1, N, x2, x2.stride(0), 1, alpha=alpha)[0]
-        if bias is not None and need[2]:
-            gb = g.sum(0) * beta
+            if R <= MAX_K:
+                gw, _, gb = _lib.small_gemm(N, K, R, g, 1, N, x2, x2.stride(0), 1, alpha=alpha,
+                                            rowsum_scale=beta if want_b else None)
+            else:       # tall reductions (adjust_style: 8192 rows): library GEMM with split-K
+                gw = torch.mm(g.t(), x2 if x2.is_contiguous() else x2.contiguous())
+                gw = gw * alpha if alpha != 1.0 else gw
+        if want_b and gb is None:
+            gb = g.sum(0)
+            gb = gb * beta if beta != 1.0 else gb
         return gx, gw, gb, g_res, None, None, None
 
 

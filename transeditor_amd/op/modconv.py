@@ -43,20 +43,20 @@ def _lowres_hw(kind, is_output, t):
     return H, W
 
 
-def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0):
+def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0):
     H, W = _lowres_hw(kind, False, x)
-    return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
+    return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, wscale), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
 
 
-def _dgrad_raw(g, w, kind, isc=None, osc=None):
+def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0):
     """data gradient: g is shaped like the conv OUTPUT; returns a tensor shaped like the conv input.
     isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci])."""
     H, W = _lowres_hw(kind, True, g)
     if kind == 'up':       # adjoint of the transposed conv = strided conv
-        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP), _lib.CONV_S2, w.shape[1], H, W, isc, osc)
+        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP, wscale), _lib.CONV_S2, w.shape[1], H, W, isc, osc)
     if kind == 'down':     # adjoint of the strided conv = transposed conv
-        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP), _lib.CONV_T2, w.shape[1], H, W, isc, osc)
-    return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_DGRAD), _KIND[kind], w.shape[1], H, W, isc, osc)
+        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP, wscale), _lib.CONV_T2, w.shape[1], H, W, isc, osc)
+    return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_DGRAD, wscale), _KIND[kind], w.shape[1], H, W, isc, osc)
 
 
 def _wgrad_raw(g, x, kind):
@@ -126,8 +126,10 @@ def conv_core(x, w, kind='3x3'):
     return _ConvFwd.apply(x, w, kind)
 
 
-def _composite(x, w, isc, osc, bias, act, kind):
+def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
     """The same function as the fused kernel, built from any-order differentiable pieces."""
+    if wscale != 1.0:
+        w = w * wscale
     if isc is not None:
         x = x * isc[:, :, None, None]
     y = conv_core(x, w, kind)
@@ -142,24 +144,24 @@ def _composite(x, w, isc, osc, bias, act, kind):
 
 class _ModConvFused(Function):
     @staticmethod
-    def forward(ctx, x, w, isc, osc, bias, act, kind):
+    def forward(ctx, x, w, isc, osc, bias, act, kind, wscale):
         # ToRGB (1x1 to 3 channels, no demodulation / activation) is HBM-bound: dedicated streaming kernels
         ctx.rgb = (kind == '1x1' and osc is None and not act
                    and _lib.rgb_supported(w.shape[0], w.shape[1], x.shape[2] * x.shape[3]))
         if ctx.rgb:
-            out = _lib.rgb_fwd(x, w.reshape(w.shape[0], w.shape[1]), isc, bias)
+            out = _lib.rgb_fwd(x, w.reshape(w.shape[0], w.shape[1]), isc, bias, wscale)
             ctx.save_for_backward(x, w, isc, osc, bias, None)
-            ctx.act, ctx.kind = act, kind
+            ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
             return out
-        out = _fwd_raw(x, w, kind, isc, osc, bias, 3 if act else 0)
+        out = _fwd_raw(x, w, kind, isc, osc, bias, 3 if act else 0, wscale)
         ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
-        ctx.act, ctx.kind = act, kind
+        ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, w, isc, osc, bias, out = ctx.saved_tensors
-        act, kind = ctx.act, ctx.kind
+        act, kind, wscale = ctx.act, ctx.kind, ctx.wscale
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():
             # double backward requested: differentiate the composite built from the closed trio
@@ -168,11 +170,11 @@ class _ModConvFused(Function):
             # while everything stays connected to the original tensors for the next differentiation.
             with torch.enable_grad():
                 al = [None if t is None else t.view_as(t) for t in (x, w, isc, osc, bias)]
-                y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind)
+                y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind, wscale)
                 ins = [t for t, n in zip(al, need[:5]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
             return tuple(next(gs) if (n and t is not None) else None
-                         for t, n in zip(al, need[:5])) + (None, None)
+                         for t, n in zip(al, need[:5])) + (None, None, None)
         g = g.contiguous()
         g_bias = None
         if act:
@@ -180,26 +182,30 @@ class _ModConvFused(Function):
         elif bias is not None and need[4]:
             g_bias = g.sum(dim=(0, 2, 3))
         if ctx.rgb:
-            gx = _lib.rgb_dgrad(g, w.reshape(w.shape[0], w.shape[1]), isc, x.shape[1]) if need[0] else None
+            gx = _lib.rgb_dgrad(g, w.reshape(w.shape[0], w.shape[1]), isc, x.shape[1], wscale) if need[0] else None
         else:
-            gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc) if need[0] else None
+            gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc, wscale=wscale) if need[0] else None
         gw = gisc = gosc = None
         if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
             slabs = _lib.rgb_wgrad_slabs(g, x) if ctx.rgb else _wgrad_raw(g, x, kind)
             if kind == 'down':
                 if isc is not None or osc is not None:
                     raise RuntimeError("kind 'down' carries no style modulation (discriminator path)")
-                return gx, (_slab_sum(slabs, kind).reshape(w.shape) if need[1] else None), None, None, g_bias, None, None
-            gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), 1.0, isc, osc,
+                gw = _slab_sum(slabs, kind).reshape(w.shape) if need[1] else None
+                if gw is not None and wscale != 1.0:
+                    gw = gw * wscale
+                return gx, gw, None, None, g_bias, None, None, None
+            gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), wscale, isc, osc,
                                                want_w=need[1], want_isc=need[2] and isc is not None,
                                                want_osc=need[3] and osc is not None)
             if gw is not None:
                 gw = gw.reshape(w.shape)
-        return gx, gw, gisc, gosc, g_bias, None, None
+        return gx, gw, gisc, gosc, g_bias, None, None, None
 
 
-def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3'):
-    """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, w) + bias[co] )  — fused kernels."""
+def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1.0):
+    """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, wscale * w) + bias[co] )  — fused kernels.
+    `wscale` is the equalised-lr constant: the parameter is consumed as stored, its gradient comes back scaled."""
     isc = isc.contiguous() if isc is not None else None
     osc = osc.contiguous() if osc is not None else None
-    return _ModConvFused.apply(x, w, isc, osc, bias, act, kind)
+    return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale))
