@@ -31,6 +31,16 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 ev = prof.key_averages(group_by_input_shape=True, group_by_stack_n=4)
 rows = [e for e in ev if e.device_time_total > 0 or e.self_device_time_total > 0]
 rows.sort(key=lambda e: -e.count)
-for e in rows[:70]:
-    st = ' <- '.join(s.split('/')[-1] for s in e.stack[:3]) if e.stack else ''
-    print(f'{e.count:5d} {e.self_device_time_total:9.0f}us {e.key[:38]:38s} {str(e.input_shapes)[:70]:70s} {st[:150]}')
+import re
+print('---- aten / autograd ops that launch work (count, self device us, op, shapes)')
+for e in rows:
+    if e.key.startswith(('void ', '(anonymous', 'Cijk', 'Memcpy', 'Memset', '__amd')) or 'evaluate_function' in e.key:
+        continue
+    if e.self_device_time_total <= 0:
+        continue
+    print(f'{e.count:5d} {e.self_device_time_total:9.0f}us {e.key[:40]:40s} {str(e.input_shapes)[:110]}')
+print('---- kernels')
+for e in rows:
+    if e.key.startswith(('void ', '(anonymous', 'Cijk', 'Memcpy', 'Memset', '__amd')):
+        k = re.sub(r'at::native::|\(anonymous namespace\)::|void ', '', e.key)
+        print(f'{e.count:5d} {e.self_device_time_total:9.0f}us {k[:150]}')

@@ -557,6 +557,111 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
     }
 }
 
+// One pass over the slabs for all three gradients (3x3 kinds, Co % 16 == 0, Ci % 32 == 0).  A block of 2 waves owns a
+// 16 co x 32 ci tile (x 9 taps); thread (row r = tid / 8, l8 = tid % 8) owns the 36 consecutive floats of 4 input
+// channels x 9 taps of row r, so the tap sums stay in registers, the reduction over ci (-> gosc) is 3 lane exchanges
+// inside an 8-lane group and the reduction over co (-> gisc) 3 exchanges across the wave's 8 rows plus one LDS hop
+// between the two waves.  gw accumulates in registers over the samples (plain stores, no atomics); two samples are
+// in flight per iteration to hide the load latency of the short per-thread streams.
+constexpr int FROWS = 16, FTHREADS = FROWS * 8;
+
+struct FusedCtx {
+    float* gisc; float* gosc; const float* isc; const float* osc;
+    int Co, Ci, co, cib, ci0, l8, lane, wid, tid;
+};
+
+__device__ __forceinline__ void fused_consume(const FusedCtx& c, int b, const f32x4 (&u)[9], const f32x4 (&wv)[9],
+                                              f32x4 (&acc)[9], float* red) {
+    float is[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) is[k] = c.isc ? c.isc[(size_t)b * c.Ci + c.ci0 + k] : 1.f;
+    const float os = c.osc ? c.osc[(size_t)b * c.Co + c.co] : 1.f;
+    float pi[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 36; ++j) {
+        const int k = j / 9;
+        const float uv = u[j >> 2][j & 3];
+        pi[k] += uv * wv[j >> 2][j & 3];
+        acc[j >> 2][j & 3] += uv * (is[k] * os);
+    }
+    if (c.gosc) {
+        float po = (pi[0] * is[0] + pi[1] * is[1]) + (pi[2] * is[2] + pi[3] * is[3]);
+        po += __shfl_xor(po, 1, 64);
+        po += __shfl_xor(po, 2, 64);
+        po += __shfl_xor(po, 4, 64);
+        if (c.l8 == 0) atomicAdd(c.gosc + (size_t)b * c.Co + c.co, po);
+    }
+    if (c.gisc) {
+        float* rb = red + (b & 1) * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = pi[k] * os;
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (c.lane < 8) rb[c.wid * 32 + c.l8 * 4 + k] = v;
+        }
+        __syncthreads();                   // one barrier per sample: the buffer alternates with b
+        if (c.tid < 32) atomicAdd(c.gisc + (size_t)b * c.Ci + c.cib + c.tid, rb[c.tid] + rb[32 + c.tid]);
+    }
+}
+
+__global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __restrict__ gw, float* __restrict__ gisc,
+                                                                      float* __restrict__ gosc, const float* __restrict__ slabs,
+                                                                      const float* __restrict__ w, float wscale,
+                                                                      const float* __restrict__ isc, const float* __restrict__ osc,
+                                                                      int B, int S, int Co, int Ci) {
+    __shared__ float red[2 * 64];
+    FusedCtx c;
+    c.gisc = gisc; c.gosc = gosc; c.isc = isc; c.osc = osc; c.Co = Co; c.Ci = Ci;
+    c.tid = threadIdx.x; c.l8 = c.tid & 7; c.lane = c.tid & 63; c.wid = c.tid >> 6;
+    c.co = blockIdx.y * FROWS + (c.tid >> 3); c.cib = blockIdx.x * 32; c.ci0 = c.cib + c.l8 * 4;
+    const size_t E = (size_t)Co * Ci * 9;
+    const size_t off = ((size_t)c.co * Ci + c.ci0) * 9;
+    f32x4 wv[9], acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        wv[i] = *reinterpret_cast<const f32x4*>(w + off + 4 * i) * wscale;
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int b = 0;
+    for (; b + 1 < B; b += 2) {
+        f32x4 u0[9], u1[9];
+        const float* p0 = slabs + (size_t)b * S * E + off;
+        const float* p1 = p0 + (size_t)S * E;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u0[i] = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u1[i] = *reinterpret_cast<const f32x4*>(p1 + 4 * i);
+        for (int s = 1; s < S; ++s) {
+            const float* q0 = p0 + (size_t)s * E;
+            const float* q1 = p1 + (size_t)s * E;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) u0[i] += *reinterpret_cast<const f32x4*>(q0 + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) u1[i] += *reinterpret_cast<const f32x4*>(q1 + 4 * i);
+        }
+        fused_consume(c, b, u0, wv, acc, red);
+        fused_consume(c, b + 1, u1, wv, acc, red);
+    }
+    if (b < B) {
+        f32x4 u0[9];
+        const float* p0 = slabs + (size_t)b * S * E + off;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u0[i] = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
+        for (int s = 1; s < S; ++s) {
+            const float* q0 = p0 + (size_t)s * E;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) u0[i] += *reinterpret_cast<const f32x4*>(q0 + 4 * i);
+        }
+        fused_consume(c, b, u0, wv, acc, red);
+    }
+    if (gw) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(gw + off + 4 * i) = acc[i] * wscale;
+    }
+}
+
 }  // namespace
 
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
@@ -595,6 +700,12 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
     TE_REQUIRE(slabs && w, TE_ERR_NULL, "te_wgrad_reduce_f32: NULL pointer");
     TE_REQUIRE(B > 0 && S > 0 && Co > 0 && Ci > 0 && (taps == 1 || taps == 9), TE_ERR_SHAPE, "te_wgrad_reduce_f32: bad dims");
     hipStream_t s = (hipStream_t)stream_;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gw);
+    if (taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && (al & 15) == 0 && Co / FROWS <= 65535) {      // single-pass path
+        dim3 grid((unsigned)(Ci / 32), (unsigned)(Co / FROWS));
+        wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        return te::launch_status("te_wgrad_reduce_f32");
+    }
     if (gw) {
         const int64_t E = (int64_t)Co * Ci * taps;
         const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0;
