@@ -74,28 +74,33 @@ __global__ __launch_bounds__(256) void demod_bwd_w_kernel(float* __restrict__ gw
     }
 }
 
-// grid (ceil(Ci/128), B): gs[b, ci]
-__global__ __launch_bounds__(128) void demod_bwd_s_kernel(float* __restrict__ gs, const float* __restrict__ gd,
+// grid (ceil(Ci/64), B), 256 threads: lane -> ci, the 4 waves split Co and combine through LDS
+__global__ __launch_bounds__(256) void demod_bwd_s_kernel(float* __restrict__ gs, const float* __restrict__ gd,
                                                           const float* __restrict__ d, const float* __restrict__ wsq,
                                                           const float* __restrict__ s, int B, int Co, int Ci) {
-    extern __shared__ float uu[];                         // [Co]
-    const int b = blockIdx.y, tid = threadIdx.x, ci = blockIdx.x * 128 + tid;
-    for (int co = tid; co < Co; co += 128) {
+    extern __shared__ float uu[];                         // [Co] + [4][64]
+    float* part = uu + Co;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ci = min(blockIdx.x * 64 + lane, Ci - 1);
+    for (int co = tid; co < Co; co += 256) {
         const float dv = d[(size_t)b * Co + co];
         uu[co] = -0.5f * gd[(size_t)b * Co + co] * dv * dv * dv;
     }
     __syncthreads();
-    if (ci >= Ci) return;
+    const int cq = (Co + 3) / 4, c0 = wid * cq, c1 = min(Co, c0 + cq);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int co = 0;
-    for (; co + 3 < Co; co += 4) {
+    int co = c0;
+    for (; co + 3 < c1; co += 4) {
         a0 += uu[co] * wsq[(size_t)co * Ci + ci];
         a1 += uu[co + 1] * wsq[(size_t)(co + 1) * Ci + ci];
         a2 += uu[co + 2] * wsq[(size_t)(co + 2) * Ci + ci];
         a3 += uu[co + 3] * wsq[(size_t)(co + 3) * Ci + ci];
     }
-    for (; co < Co; ++co) a0 += uu[co] * wsq[(size_t)co * Ci + ci];
-    gs[(size_t)b * Ci + ci] = 2.f * s[(size_t)b * Ci + ci] * ((a0 + a1) + (a2 + a3));
+    for (; co < c1; ++co) a0 += uu[co] * wsq[(size_t)co * Ci + ci];
+    part[wid * 64 + lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wid == 0 && blockIdx.x * 64 + lane < Ci)
+        gs[(size_t)b * Ci + ci] = 2.f * s[(size_t)b * Ci + ci] * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
 }
 
 }  // namespace
@@ -117,8 +122,8 @@ extern "C" int te_demod_bwd_f32(float* gw, float* gs, const float* gd, const flo
     hipStream_t st = (hipStream_t)stream_;
     if (gw) demod_bwd_w_kernel<<<Co, 256, 0, st>>>(gw, gd, d, w, s, wscale, B, Co, Ci, T);
     if (gs) {
-        dim3 grid((unsigned)te::cdiv(Ci, 128), (unsigned)B);
-        demod_bwd_s_kernel<<<grid, 128, sizeof(float) * Co, st>>>(gs, gd, d, wsq, s, B, Co, Ci);
+        dim3 grid((unsigned)te::cdiv(Ci, 64), (unsigned)B);
+        demod_bwd_s_kernel<<<grid, 256, sizeof(float) * (Co + 256), st>>>(gs, gd, d, wsq, s, B, Co, Ci);
     }
     return te::launch_status("te_demod_bwd_f32");
 }

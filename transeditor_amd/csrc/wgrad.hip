@@ -557,6 +557,35 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
     }
 }
 
+// taps == 1 with <= 4 output channels (ToRGB): block (ci chunk, b); a thread owns one input channel of one sample, sums
+// its slabs, writes gisc[b,ci] directly (it sees every output channel) and adds its share of gw.
+__global__ __launch_bounds__(RTHREADS) void wgrad_reduce_few_kernel(float* __restrict__ gw, float* __restrict__ gisc,
+                                                                    const float* __restrict__ slabs, const float* __restrict__ w,
+                                                                    float wscale, const float* __restrict__ isc, int B, int S,
+                                                                    int Co, int Ci) {
+    const int ci = blockIdx.x * RTHREADS + threadIdx.x, b = blockIdx.y;
+    if (ci >= Ci) return;
+    const size_t E = (size_t)Co * Ci;
+    const float* sp = slabs + (size_t)b * S * E + ci;
+    float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Co) u[o] += sp[(size_t)s * E + (size_t)o * Ci];
+    }
+    const float is = isc ? isc[(size_t)b * Ci + ci] : 1.f;
+    float gi = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o < Co) {
+            gi += u[o] * w[(size_t)o * Ci + ci];
+            if (gw) atomicAdd(gw + (size_t)o * Ci + ci, u[o] * is * wscale);
+        }
+    }
+    if (gisc) gisc[(size_t)b * Ci + ci] = gi * wscale;
+}
+
 // One pass over the slabs for all three gradients (3x3 kinds, Co % 16 == 0, Ci % 32 == 0).  A block of 2 waves owns a
 // 16 co x 32 ci tile (x 9 taps); thread (row r = tid / 8, l8 = tid % 8) owns the 36 consecutive floats of 4 input
 // channels x 9 taps of row r, so the tap sums stay in registers, the reduction over ci (-> gosc) is 3 lane exchanges
@@ -704,6 +733,15 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
     if (taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && (al & 15) == 0 && Co / FROWS <= 65535) {      // single-pass path
         dim3 grid((unsigned)(Ci / 32), (unsigned)(Co / FROWS));
         wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        return te::launch_status("te_wgrad_reduce_f32");
+    }
+    if (taps == 1 && Co <= 4 && !gosc && !osc) {                                                   // ToRGB
+        if (gw) {
+            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * Ci, s);
+            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)B);
+        wgrad_reduce_few_kernel<<<grid, RTHREADS, 0, s>>>(gw, gisc, slabs, w, wscale, isc, B, S, Co, Ci);
         return te::launch_status("te_wgrad_reduce_f32");
     }
     if (gw) {
