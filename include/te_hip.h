@@ -153,6 +153,19 @@ int te_attn_bwd_f32(float* gq, float* gk, float* gv, const float* go, const floa
                     int G, int M, int L, int D, te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K2b  backward of "blur -> + bias -> leaky-ReLU * sqrt(2)" (the upsampling StyledConv tail, model_spatial_query.py:321 +
+ * :401; reference backward = fused_bias_act_kernel.cu grad pass, then upfirdn2d with flipped taps) in ONE pass:
+ *   gpre = g * (ref > 0 ? scale : alpha * scale)      ref = saved forward output, g / ref: [major, in_h, in_w]
+ *   gx   = upfirdn2d(gpre, k, up = down = 1, pads)    k = the already flipped 4x4 taps, pads >= 0
+ *   partial[plane][tile] = sum of gpre over the part of the plane the tile owns (bias gradient = sum over planes of the
+ *   same channel and over tiles); te_blur_actgrad_tiles gives the tile count per plane.
+ */
+int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1);
+int te_blur_actgrad_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major, int in_h,
+                        int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
+                        te_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * G2/A2  small dense layers (reference: EqualLinear.forward, model_spatial_query.py:213-221 — F.linear on
  * weight * scale with bias * lr_mul, optional activation).  One fused launch on fp32 MFMA:
  *     C[i,j] = act( alpha * sum_k A(i,k) * B(k,j) + beta * bias[j] ) + residual[i,j]      C, residual, pre: [I,J] row-major

@@ -98,16 +98,20 @@ def test_upfirdn2d_tiled_vs_oracle(shape, gain, up, down, pad):
     assert rel_err(gg, O.upfirdn2d(v, k, up, down, pad)) < OP_TOL
 
 
-def test_blur_bias_act_fused_vs_oracle():
+@pytest.mark.parametrize('shape,pad,taps', [((2, 6, 33, 33), (1, 1), (1, 3, 3, 1)), ((1, 3, 129, 129), (1, 1), (1, 2, 3, 5)),
+                                            ((2, 5, 17, 70), (2, 1), (1, 2, 3, 5)), ((3, 2, 40, 200), (2, 2), (4, 3, 2, 1))])
+def test_blur_bias_act_fused_vs_oracle(shape, pad, taps):
+    """forward (FIR + bias + lrelu epilogue) and the one-pass backward (lrelu gradient in the adjoint FIR's staging,
+    bias gradient from per-tile partial sums), multi-tile planes and asymmetric taps included."""
     from transeditor_amd.op.fir_act import blur_bias_act
-    k = O.fir_kernel((1, 3, 3, 1), 4.0)
-    x = synth.normal((2, 6, 33, 33), 'fa.x').requires_grad_(True)
-    b = synth.normal((6,), 'fa.b').requires_grad_(True)
-    y_ref = O.fused_leaky_relu(O.upfirdn2d(x, k, pad=(1, 1)), b)
+    k = O.fir_kernel(taps, 4.0)
+    x = synth.normal(shape, 'fa.x').requires_grad_(True)
+    b = synth.normal((shape[1],), 'fa.b').requires_grad_(True)
+    y_ref = O.fused_leaky_relu(O.upfirdn2d(x, k, pad=pad), b)
     w = synth.normal(tuple(y_ref.shape), 'fa.w')
     gx_ref, gb_ref = torch.autograd.grad((y_ref * w).sum(), (x, b))
     xd, bd = x.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
-    y = blur_bias_act(xd, k.to(DEV), bd, (1, 1))
+    y = blur_bias_act(xd, k.to(DEV), bd, pad)
     assert rel_err(y, y_ref) < OP_TOL
     gx, gb = torch.autograd.grad((y * w.to(DEV)).sum(), (xd, bd))
     assert rel_err(gx, gx_ref) < OP_TOL and rel_err(gb, gb_ref) < SUM_TOL

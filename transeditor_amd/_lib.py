@@ -36,6 +36,8 @@ _SIGNATURES = {
     'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
     'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'te_blur_actgrad_tiles': (C.c_int, [_I] * 8),
+    'te_blur_actgrad_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
     'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
@@ -125,6 +127,22 @@ def upfirdn2d_raw(x, k, up, down, pad, bias=None, act=0, alpha=0.2, scale=1.0):
                                   bias.numel() if bias is not None else 1, act, alpha, scale, _stream()),
            'te_upfirdn2d_f32')
     return out
+
+
+def blur_actgrad(g, ref, k_flipped, pad, alpha, scale):
+    """backward of blur + bias + lrelu in one pass: returns (gx, gbias).  g / ref [B,C,H,W]; pad = (px0, px1, py0, py1)."""
+    g, ref = g.contiguous(), ref.contiguous()
+    B, Cn, H, W = g.shape
+    kh, kw = k_flipped.shape
+    px0, px1, py0, py1 = pad
+    tiles = lib().te_blur_actgrad_tiles(H, W, kh, kw, px0, px1, py0, py1)
+    if tiles <= 0:
+        raise RuntimeError(f'te_blur_actgrad_tiles failed ({tiles})')
+    gx = torch.empty(B, Cn, H + py0 + py1 - kh + 1, W + px0 + px1 - kw + 1, device=g.device, dtype=g.dtype)
+    partial = torch.empty(B, Cn, tiles, device=g.device, dtype=g.dtype)
+    _check(lib().te_blur_actgrad_f32(_ptr(gx), _ptr(partial), _ptr(g), _ptr(ref), _ptr(k_flipped.contiguous()), B * Cn, H, W,
+                                     kh, kw, px0, px1, py0, py1, alpha, scale, _stream()), 'te_blur_actgrad_f32')
+    return gx, partial.sum(dim=(0, 2))
 
 
 # --------------------------------------------------------------------------------------------- F1

@@ -27,7 +27,9 @@ struct FirParams {
     float alpha, scale;
 };
 
+template <bool AG = false>
 __device__ __forceinline__ float epilogue(float v, const float* b, int ch, const FirParams& p) {
+    if constexpr (AG) return v;          // alpha / scale belong to the prologue in this mode
     if (b) v += b[ch];
     if (p.act == 3) v = v > 0.f ? v : v * p.alpha;
     return v * p.scale;
@@ -35,10 +37,15 @@ __device__ __forceinline__ float epilogue(float v, const float* b, int ch, const
 
 constexpr int TOH = 16, TOW = 64;
 
-template <int UP, int DOWN, int KH, int KW>
+// AG ("activation gradient" prologue, used by the backward of the fused blur + bias + leaky-ReLU): the staged value is
+// x * (ref > 0 ? scale : alpha * scale) with ref the saved forward output, and every block also emits the sum of the
+// staged elements it OWNS (first TOH x TOW of its input tile; the last tile of a row / column owns its halo too), i.e.
+// the bias-gradient partial of its plane, to partial[plane][tile] (no atomics; the caller adds them up).
+template <int UP, int DOWN, int KH, int KW, bool AG = false>
 __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                        const float* __restrict__ k, const float* __restrict__ b,
-                                                       const FirParams p) {
+                                                       const FirParams p, const float* __restrict__ ref = nullptr,
+                                                       float* __restrict__ partial = nullptr) {
     constexpr int TIH = ((TOH - 1) * DOWN + KH - 1) / UP + 1;
     constexpr int TIW = ((TOW - 1) * DOWN + KW - 1) / UP + 1;
     constexpr int TIWP = (TIW + 3) & ~3;  // row stride, multiple of 4 floats
@@ -46,6 +53,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     static_assert(KH % UP == 0 && KW % UP == 0, "taps must split evenly over the upsampling phases");
     __shared__ __attribute__((aligned(16))) float sx[TIH * TIWP + 4];
     __shared__ float sk[KH * KW];
+    __shared__ float sred[4];
 
     // flipped taps: registers for UP == 1 (compile-time indices), LDS when the phase selects them at run time
     float kf[KH][KW];
@@ -76,6 +84,30 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             const float v = xin[ok ? (size_t)gy * p.in_w + gx : 0];
             stage[r] = ok ? v : 0.f;
         }
+        if constexpr (AG) {
+            const float* rin = ref + (size_t)mj * p.in_h * p.in_w;
+            float rv[NLD];
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) {
+                const int e = threadIdx.x + 256 * r;
+                const int ry = e / TIW, rx = e - ry * TIW;
+                const int gy = iy0 + ry, gx = ix0 + rx;
+                const bool ok = e < TIH * TIW && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w;
+                rv[r] = rin[ok ? (size_t)gy * p.in_w + gx : 0];
+            }
+            float own = 0.f;
+            const bool last_y = blockIdx.y == gridDim.y - 1, last_x = blockIdx.x == gridDim.x - 1;
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) {
+                const int e = threadIdx.x + 256 * r;
+                const int ry = e / TIW, rx = e - ry * TIW;
+                stage[r] *= rv[r] > 0.f ? p.scale : p.alpha * p.scale;
+                if ((ry < TOH || last_y) && (rx < TOW || last_x)) own += stage[r];     // stage is 0 outside the image
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) own += __shfl_down(own, o, 64);
+            if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = own;
+        }
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
             const int e = threadIdx.x + 256 * r;
@@ -83,6 +115,11 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             if (e < TIH * TIW) sx[ry * TIWP + rx] = stage[r];
         }
         __syncthreads();
+        if constexpr (AG) {
+            if (threadIdx.x == 0)
+                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                    (sred[0] + sred[1]) + (sred[2] + sred[3]);
+        }
         const int oy = oy0 + ty;
         if (oy < p.out_h) {
             float res[4];
@@ -129,14 +166,14 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             const int ch = b ? (int)(mj % p.size_b) : 0;
             if ((p.out_w & 3) == 0 && ox0 + tx + 3 < p.out_w) {      // rows 16-byte aligned: one 16-byte store per lane
                 float4 v;
-                v.x = epilogue(res[0], b, ch, p); v.y = epilogue(res[1], b, ch, p);
-                v.z = epilogue(res[2], b, ch, p); v.w = epilogue(res[3], b, ch, p);
+                v.x = epilogue<AG>(res[0], b, ch, p); v.y = epilogue<AG>(res[1], b, ch, p);
+                v.z = epilogue<AG>(res[2], b, ch, p); v.w = epilogue<AG>(res[3], b, ch, p);
                 *reinterpret_cast<float4*>(orow + ox0 + tx) = v;
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ox = ox0 + tx + q;
-                    if (ox < p.out_w) orow[ox] = epilogue(res[q], b, ch, p);
+                    if (ox < p.out_w) orow[ox] = epilogue<AG>(res[q], b, ch, p);
                 }
             }
         }
@@ -178,6 +215,35 @@ void launch_tile(float* out, const float* x, const float* k, const float* b, con
 }
 
 }  // namespace
+
+extern "C" int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1) {
+    const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
+    if (oh <= 0 || ow <= 0) return TE_ERR_SHAPE;
+    return (int)(te::cdiv(ow, TOW) * te::cdiv(oh, TOH));
+}
+
+extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major,
+                                   int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                   float alpha, float scale, te_stream_t stream_) {
+    TE_REQUIRE(gx && partial && g && ref && k, TE_ERR_NULL, "te_blur_actgrad_f32: NULL pointer");
+    TE_REQUIRE(major >= 0 && in_h > 0 && in_w > 0, TE_ERR_SHAPE, "te_blur_actgrad_f32: bad dims");
+    TE_REQUIRE(kh == 4 && kw == 4, TE_ERR_UNSUPPORTED, "te_blur_actgrad_f32: 4x4 taps only");
+    TE_REQUIRE(pad_x0 >= 0 && pad_x1 >= 0 && pad_y0 >= 0 && pad_y1 >= 0, TE_ERR_UNSUPPORTED,
+               "te_blur_actgrad_f32: pads must be >= 0 (every input element has to be staged by some tile)");
+    FirParams p;
+    p.in_h = in_h; p.in_w = in_w;
+    p.out_h = in_h + pad_y0 + pad_y1 - kh + 1;
+    p.out_w = in_w + pad_x0 + pad_x1 - kw + 1;
+    TE_REQUIRE(p.out_h > 0 && p.out_w > 0, TE_ERR_SHAPE, "te_blur_actgrad_f32: empty output");
+    p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.minor = 1; p.major = major;
+    p.size_b = 1; p.act = 0; p.alpha = alpha; p.scale = scale;
+    if (major == 0) return 0;
+    TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_actgrad_f32: too many planes");
+    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)std::min<int64_t>(major, 32768));
+    fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
+    return te::launch_status("te_blur_actgrad_f32");
+}
 
 extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, int in_h, int in_w, int minor,
                                 int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

@@ -28,6 +28,7 @@ class _AttnCore(Function):
         o, sim = _lib.attn_fwd(q, k, v, scale, groups)
         ctx.save_for_backward(q, k, v, sim)
         ctx.scale, ctx.groups = scale, groups
+        ctx.set_materialize_grads(False)      # an unused `similarity` output must not cost a zero-fill per block
         return o, sim
 
     @staticmethod

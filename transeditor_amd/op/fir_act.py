@@ -11,7 +11,7 @@ from torch.autograd import Function
 
 from .. import _lib
 from .fused_act import fused_leaky_relu
-from .upfirdn2d import upfirdn2d, _geometry
+from .upfirdn2d import upfirdn2d, _geometry, flipped_taps
 
 
 class _BlurBiasAct(Function):
@@ -34,10 +34,14 @@ class _BlurBiasAct(Function):
                 y = fused_leaky_relu(upfirdn2d(xa, kernel, pad=pad), ba)
                 gx, gb = torch.autograd.grad(y, (xa, ba), g, create_graph=True, allow_unused=True)
             return gx, None, gb, None
-        gpre, gb = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=True)
         pad4 = (pad[0], pad[1], pad[0], pad[1])
         _, g_pad = _geometry(x.shape[2:], kernel.shape, (1, 1), (1, 1), pad4)
-        gx = _lib.upfirdn2d_raw(gpre, torch.flip(kernel, [0, 1]).contiguous(), (1, 1), (1, 1), g_pad)
+        if tuple(kernel.shape) == (4, 4) and min(g_pad) >= 0:
+            # activation gradient applied while the adjoint FIR stages its input tile; bias gradient from per-tile sums
+            gx, gb = _lib.blur_actgrad(g, out, flipped_taps(kernel), g_pad, 0.2, 2 ** 0.5)
+        else:
+            gpre, gb = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=True)
+            gx = _lib.upfirdn2d_raw(gpre, flipped_taps(kernel), (1, 1), (1, 1), g_pad)
         return gx, None, gb, None
 
 

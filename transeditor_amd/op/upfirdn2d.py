@@ -21,6 +21,21 @@ def _geometry(in_hw, k_hw, up, down, pad):
     return (oh, ow), g_pad
 
 
+_FLIPPED = {}
+
+
+def flipped_taps(kernel):
+    """torch.flip(kernel, [0, 1]) memoised per FIR buffer (a constant of the module): the adjoint passes would
+    otherwise launch one flip kernel per layer per step.  The entry keeps the source tensor alive, so its id stays valid."""
+    ent = _FLIPPED.get(id(kernel))
+    if ent is None or ent[0] is not kernel or ent[1] != kernel._version:
+        if len(_FLIPPED) > 256:
+            _FLIPPED.clear()
+        ent = (kernel, kernel._version, torch.flip(kernel, [0, 1]).contiguous())
+        _FLIPPED[id(kernel)] = ent
+    return ent[2]
+
+
 class _UpFirDnAdjoint(Function):
     @staticmethod
     def forward(ctx, grad_output, kernel, kernel_flipped, up, down, pad, g_pad, in_hw):
@@ -41,7 +56,7 @@ class _UpFirDn(Function):
     @staticmethod
     def forward(ctx, input, kernel, up, down, pad):
         _, g_pad = _geometry(input.shape[2:], kernel.shape, up, down, pad)
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]).contiguous())
+        ctx.save_for_backward(kernel, flipped_taps(kernel))
         ctx.cfg = (up, down, pad, g_pad, tuple(input.shape[2:]))
         return _lib.upfirdn2d_raw(input, kernel, up, down, pad)
 
