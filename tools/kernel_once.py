@@ -40,6 +40,8 @@ def main():
         _lib.upfirdn2d_raw(t, k, (1, 1), (1, 1), (1, 1, 1, 1), bias=bias, act=3, scale=2 ** 0.5)   # blur + bias + act
     for _ in range(REP):
         _lib.bias_act_bwd(x, y, 0.2, 2 ** 0.5)
+    for _ in range(REP):
+        _lib.blur_actgrad(x, y, k, (1, 3, 1, 3), 0.2, 2 ** 0.5)                       # backward of blur + bias + act, one pass
     wr = torch.randn(3, 128, device=DEV)
     for _ in range(REP):
         r = _lib.rgb_fwd(x, wr, isc, bias[:3].contiguous())

@@ -15,7 +15,9 @@ ALG = {
     'conv_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wgrad_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'fir_tile_kernel<1, 1, 4, 4, true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),
     'fir_tile_kernel<1, 1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
+    'wgrad_reduce_fused': dict(flops=0, bytes=16 * 16 * 128 * 128 * 9 * 4),
     'bias_act_bwd_rows': dict(flops=0, bytes=3 * 16 * 128 * 256 * 256 * 4),
     'rgb_fwd': dict(flops=0, bytes=16 * 131 * 256 * 256 * 4),
     'rgb_dgrad': dict(flops=0, bytes=16 * 131 * 256 * 256 * 4),

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             const int s = e / tile_sp, rem = e - s * tile_sp;
             const int ry = rem / g.TIW, rx = rem - ry * g.TIW;
             const int b = b0 + s, gy = oy + ry, gx = ox + rx;
-            loff[r] = s * g.SS + ry * g.TIWP + rx;
+            // S2 keeps even and odd input columns of a row apart ([TW+1 even | TW odd]) so the stride-2 B-fragment
+            // reads below touch consecutive LDS words (32 banks: a stride of 2 words is a 2-way conflict)
+            const int rxl = (KIND == TE_CONV_S2) ? ((rx & 1) ? g.TW + 1 + (rx >> 1) : (rx >> 1)) : rx;
+            loff[r] = s * g.SS + ry * g.TIWP + rxl;
             sb[r] = b < p.B ? b : 0;
             if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
                 goff[r] = (unsigned)s * p.K * plane4 + (unsigned)(gy * p.Wi + gx) * 4u;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         const int s = c >> (g.lgTW + g.lgTH);
         const int ty = (c >> g.lgTW) & (g.TH - 1), tx = c & (g.TW - 1);
         int o;
-        if (KIND == TE_CONV_S2) o = 2 * ty * g.TIWP + 2 * tx;
+        if (KIND == TE_CONV_S2) o = 2 * ty * g.TIWP + tx;
         else if (KIND == TE_CONV_T2) o = (ty + 1) * g.TIWP + tx + 1;
         else o = ty * g.TIWP + tx;
         boff[nb] = s * g.SS + o + half * g.CS;
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 int toff;
                 if (KIND == TE_CONV_1X1) toff = 0;
                 else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? g.TIWP : 0) - (kx == 2 ? 1 : 0);
+                else if (KIND == TE_CONV_S2) toff = ky * g.TIWP + (kx == 1 ? g.TW + 1 : (kx >> 1));
                 else toff = ky * g.TIWP + kx;
                 float a[MBW];
 #pragma unroll
