@@ -46,14 +46,17 @@ constexpr int MPAD = 128;   // packed weights: M padded to a multiple of 128 (bl
 // 32-row M blocks and NBW 32-cell blocks; KC input channels per stage; NSP staging sweeps for the input tile.
 //   TC 0: M >= 96 -> block 128 (M) x 128 cells      TC 1: M ~ 64 -> 64 x 256 cells      TC 2: M <= 32 -> 32 x 256 cells
 // (narrow layers of the 512 / 1024 px generators, ToRGB fallbacks) so the MFMA rows are not padded 2-4x with zeros.
+#ifndef T2KC0
+#define T2KC0 16
+#endif
 template <int KIND, int TC> struct Cfg;
 template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
-template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = 16, NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
 template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
@@ -454,7 +457,7 @@ void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
 template <int KIND, int TC, bool HAS_ISC, bool MS>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168)
-    constexpr bool CAN3 = (KIND == TE_CONV_3X3 && TC == 0 && !MS);
+    constexpr bool CAN3 = (KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS);
     if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2>(a, nblocks, lds_floats, s);
     else launch_o<KIND, TC, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
 }
@@ -481,8 +484,8 @@ int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s)
 inline int tile_class(int M) { return M >= 96 ? 0 : (M >= 48 ? 1 : 2); }
 
 template <int KIND>
-int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_t s) {
-    switch (tile_class(a.M)) {
+int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_t s, int tc) {
+    switch (tc) {
         case 0: return launch_regions_tc<KIND, 0>(a, regions, n, s);
         case 1: return launch_regions_tc<KIND, 1>(a, regions, n, s);
         default: return launch_regions_tc<KIND, 2>(a, regions, n, s);
@@ -518,14 +521,18 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     const bool t2k = (kind == TE_CONV_T2);
-    const int tc = tile_class(M);
-    const int KC = t2k ? 16 : 8;
+    int tc = tile_class(M);
+    // transposed conv on small images (<= 1024 of the 64 x 128 tiles): the 64 x 64 tile class fits 3 waves per SIMD and
+    // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
+    static const bool t2small = !(getenv("TE_T2_SMALL") && atoi(getenv("TE_T2_SMALL")) == 0);
+    if (t2small && t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
+    const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
     // split count comes from the real tile geometry of the main region and is shared by every region launch
     {
         const bool t2 = (kind == TE_CONV_T2);
-        const int ntile = t2 ? 128 : (tc == 0 ? 128 : 256);      // cells per block tile of the chosen tile class
+        const int ntile = t2 ? (tc == 1 ? 64 : 128) : (tc == 0 ? 128 : 256);      // cells per block tile of the chosen tile class
         int rh = H, rw = W;
         if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
         const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
@@ -548,26 +555,26 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
             // (a 128 x 256 block tile, NBW = 4, measured the same 133 TF/s: the kernel sits at the clock-limited peak)
-            rc = launch_regions<TE_CONV_3X3>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_3X3>(a, r, 1, s, tc);
         } break;
         case TE_CONV_1X1: {
             a.Hi = a.Ho = H; a.Wi = a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
-            rc = launch_regions<TE_CONV_1X1>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_1X1>(a, r, 1, s, tc);
         } break;
         case TE_CONV_S2: {
             a.Hi = 2 * H + 1; a.Wi = 2 * W + 1; a.Ho = H; a.Wo = W;
             const int r[1][4] = {{0, 0, H, W}};
-            rc = launch_regions<TE_CONV_S2>(a, r, 1, s);
+            rc = launch_regions<TE_CONV_S2>(a, r, 1, s, tc);
         } break;
         case TE_CONV_T2: {
             a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
             if (W + 1 <= 16 || H + 1 <= 16) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
-                rc = launch_regions<TE_CONV_T2>(a, r, 1, s);
+                rc = launch_regions<TE_CONV_T2>(a, r, 1, s, tc);
             } else {
                 const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row
-                rc = launch_regions<TE_CONV_T2>(a, r, 3, s);
+                rc = launch_regions<TE_CONV_T2>(a, r, 3, s, tc);
             }
         } break;
         default:
