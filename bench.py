@@ -130,12 +130,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU path for the product)'
+    # TE_BENCH_SHARE_GPU=1 (rehearsal of the multi-process path on a 1-GPU box): every rank uses cuda:0 and the
+    # collectives go through gloo instead of RCCL, which refuses two ranks on one device.  Never set by the driver.
+    share = os.environ.get('TE_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', init_method='env://')      # "nccl" == RCCL on ROCm
+        dist.init_process_group('gloo' if share else 'nccl', init_method='env://')      # "nccl" == RCCL on ROCm
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from transeditor_amd.model_spatial_query import Generator
