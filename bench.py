@@ -98,7 +98,7 @@ class KernelTimer:
 
 
 def cpu_baseline(size):
-    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 1, 1 warm-up + 1 timed iteration)."""
+    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 1, 1 warm-up + 10 timed iterations, ~12 s)."""
     from oracle import te_oracle as O
     from transeditor_amd import synth
     from transeditor_amd.model_spatial_query import Generator
@@ -110,7 +110,7 @@ def cpu_baseline(size):
     P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'noises' not in k and 'kernel' not in k
              and not k.startswith('token') else v) for k, v in sd.items()}
     leaves = [v for v in P.values() if v.requires_grad]
-    B, iters = 1, 1
+    B, iters = 1, 10
     times = []
     for it in range(iters + 1):
         z, p = synth.latents(B, 900 + it)
@@ -119,9 +119,15 @@ def cpu_baseline(size):
         torch.autograd.grad(img.sum(), leaves, allow_unused=True)
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / iters
+    model = 'unknown'
+    try:
+        model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except Exception:
+        pass
     return {'value': B / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'CPU oracle (PyTorch fp32 restatement of the reference), generator fwd+bwd {size}x{size}, '
-                      f'batch {B}, 1 warm-up + {iters} timed iterations, {dt:.2f} s/iter'}
+                      f'batch {B}, 1 warm-up + {iters} timed iterations, {dt:.2f} s/iter',
+            'cpu_model': model, 'host_threads': os.cpu_count()}
 
 
 def main():

@@ -79,10 +79,11 @@ class GradSync:
         loss.backward(); sync.all_reduce()  # every step, before optimizer.step()
 
     Parameters are bucketed in REVERSE registration order (the order backward produces their gradients).  A
-    post-accumulate hook copies each fresh gradient into its bucket's flat buffer; when the last gradient of a bucket
-    has arrived the bucket's all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps the rest of the
+    post-accumulate hook counts the gradients of a bucket; when the last one has arrived the bucket is packed into its
+    flat buffer with one multi-tensor copy and its all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps the rest of the
     backward.  `all_reduce()` issues whatever is left (buckets holding parameters that received no gradient, e.g. the
-    unused `noise.weight`s, are completed with zeros), waits, averages and writes the result back into `.grad`.
+    unused `noise.weight`s, are completed with zeros), waits, averages and points every `.grad` at its
+    slice of the bucket (no copy back; the buffers are reused by the next backward, after `.grad` has been reset).
     """
 
     def __init__(self, module, bucket_bytes=32 << 20):
@@ -131,26 +132,32 @@ class GradSync:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, p):
-        bi, off = self._slot[p]
+        bi, _ = self._slot[p]
         if self._work[bi] is not None:                    # bucket already in flight (parameter thought unused): fix up later
             self._late.append(p)
             return
-        self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self._seen[bi].add(p)
         expected = sum(1 for q in self.buckets[bi] if q.requires_grad and q not in self._unused)
         if len(self._seen[bi] - self._unused) >= expected:
             self._launch(bi)
 
-    def _launch(self, bi):
+    def _views(self, bi):
         flat = self._buffer(bi)
-        for p in self.buckets[bi]:
-            if p not in self._seen[bi]:                   # no gradient (unused or frozen): contributes zeros / its grad
-                _, off = self._slot[p]
-                seg = flat[off:off + p.numel()]
-                if p.grad is None:
-                    seg.zero_()
-                else:
-                    seg.copy_(p.grad.reshape(-1))
+        return [flat[self._slot[p][1]:self._slot[p][1] + p.numel()].view_as(p) for p in self.buckets[bi]]
+
+    def _launch(self, bi):
+        """Pack the bucket with ONE multi-tensor copy (not one launch per parameter) and start its all-reduce."""
+        flat = self._buffer(bi)
+        views = self._views(bi)
+        src, dst = [], []
+        for p, v in zip(self.buckets[bi], views):
+            if p.grad is None:                            # no gradient (unused or frozen): contributes zeros
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce(self):
@@ -169,17 +176,10 @@ class GradSync:
         late = set(self._late)
         for bi in active:
             self._work[bi].wait()
-            flat = self._flat[bi]
-            flat.div_(world)
-            for p in self.buckets[bi]:
-                if not p.requires_grad or p in late:
-                    continue
-                _, off = self._slot[p]
-                seg = flat[off:off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = seg.clone()
-                else:
-                    p.grad.copy_(seg)
+            self._flat[bi].div_(world)
+            for p, v in zip(self.buckets[bi], self._views(bi)):
+                if p.requires_grad and p not in late:
+                    p.grad = v                            # the averaged gradient lives in the bucket: no copy back
         for p in self._late:                              # rare: reduce stragglers one by one and stop treating them as unused
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
             p.grad.div_(world)
