@@ -98,8 +98,9 @@ class EqualConv2d(nn.Module):                                                   
         self.stride, self.padding = stride, padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input, act_bias=None):
+    def forward(self, input, act_bias=None, presampled=False):
         """`act_bias` (extension used by ConvLayer): fuse '+ act_bias' and the scaled leaky-ReLU that follows.
+        `presampled` (ConvLayer, 1x1 stride 2 only): the caller already kept every second row / column.
         The four configurations the discriminator uses run on the MI355X convolution kernels (same family as the
         generator, no modulation); anything else falls back to the library convolution."""
         w, ws = self.weight, self.scale
@@ -114,7 +115,10 @@ class EqualConv2d(nn.Module):                                                   
             if cfg == (3, 2, 0) and input.shape[2] % 2 == 1 and input.shape[3] % 2 == 1:
                 return modconv(input, w, None, None, bias, act, 'down', ws)
             if cfg == (1, 2, 0):
-                return modconv(input[:, :, ::2, ::2].contiguous(), w, None, None, bias, act, '1x1', ws)
+                x = input if presampled else input[:, :, ::2, ::2].contiguous()
+                return modconv(x, w, None, None, bias, act, '1x1', ws)
+        if presampled:
+            raise RuntimeError('EqualConv2d(presampled=True) is only meaningful for the 1x1 stride-2 configuration on the GPU')
         out = F.conv2d(input, w * ws, bias=self.bias, stride=self.stride, padding=self.padding)
         return fused_leaky_relu(out, act_bias) if act else out
 
@@ -437,9 +441,23 @@ class ConvLayer(nn.Sequential):                                                 
         """Same sequence as nn.Sequential, with EqualConv2d -> FusedLeakyReLU fused into the conv epilogue."""
         mods = list(self)
         i = 0
+        pres = False
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, Blur) and isinstance(nxt, EqualConv2d) and nxt.weight.shape[2] == 1 and nxt.stride == 2
+                    and nxt.padding == 0 and input.is_cuda and input.dtype == torch.float32):
+                # skip branch of ResBlock: blur, then a 1x1 conv that reads every second pixel -> let the FIR pass
+                # produce only those pixels (same taps and pads, down = 2): a quarter of the writes, no strided copy
+                input = upfirdn2d(input, m.kernel, down=2, pad=m.pad)
+                pres = True
+                i += 1
+                continue
+            if pres:
+                input = m(input, presampled=True)
+                pres = False
+                i += 1
+                continue
             if (isinstance(m, EqualConv2d) and isinstance(nxt, FusedLeakyReLU) and nxt.bias is not None
                     and m.bias is None and nxt.negative_slope == 0.2 and abs(nxt.scale - 2 ** 0.5) < 1e-12):
                 input = m(input, act_bias=nxt.bias)
