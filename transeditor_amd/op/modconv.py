@@ -24,11 +24,43 @@ that follows in the reference, model_spatial_query.py:318-321, is a separate upf
 pad 0 over a (2H+1)x(2W+1) input -> HxW: the discriminator's blurred downsampling conv, :744-768; it is the
 adjoint kernel pair of 'up').
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 
 from .. import _lib
 from .fused_act import fused_leaky_relu
+
+# Hints for the regulariser steps (R1, path length), which differentiate twice.  Both are optional: without them the
+# fused Function recomputes its forward through the differentiable pieces when its backward turns out to be recorded.
+_STATE = {'second_order': False, 'skip_w': False}
+
+
+@contextlib.contextmanager
+def second_order():
+    """Forward passes inside this context are built from the any-order differentiable pieces right away (the caller knows
+    a create_graph backward follows), which saves the forward recomputation inside the recorded backward."""
+    old = _STATE['second_order']
+    _STATE['second_order'] = True
+    try:
+        yield
+    finally:
+        _STATE['second_order'] = old
+
+
+@contextlib.contextmanager
+def no_weight_grads():
+    """Around `autograd.grad(..., inputs=<activations / latents>, create_graph=True)`: the first-order weight gradients
+    of the convolutions are not among the requested inputs, so their correlation passes are skipped (autograd cannot tell
+    a Python Function which of its outputs are consumed).  Do NOT use around a backward that accumulates into weights."""
+    old = _STATE['skip_w']
+    _STATE['skip_w'] = True
+    try:
+        yield
+    finally:
+        _STATE['skip_w'] = old
+
 
 _KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2, 'down': _lib.CONV_S2}
 
@@ -85,7 +117,7 @@ class _ConvFwd(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = _ConvDgrad.apply(gy, w, ctx.kind) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2]) if ctx.needs_input_grad[1] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2]) if (ctx.needs_input_grad[1] and not _STATE['skip_w']) else None
         return gx, gw, None
 
 
@@ -171,6 +203,8 @@ class _ModConvFused(Function):
             with torch.enable_grad():
                 al = [None if t is None else t.view_as(t) for t in (x, w, isc, osc, bias)]
                 y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind, wscale)
+                if _STATE['skip_w']:
+                    need = (need[0], False) + tuple(need[2:])
                 ins = [t for t, n in zip(al, need[:5]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
             return tuple(next(gs) if (n and t is not None) else None
@@ -206,6 +240,8 @@ class _ModConvFused(Function):
 def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1.0):
     """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, wscale * w) + bias[co] )  — fused kernels.
     `wscale` is the equalised-lr constant: the parameter is consumed as stored, its gradient comes back scaled."""
+    if _STATE['second_order'] and torch.is_grad_enabled():
+        return _composite(x, w, isc, osc, bias, act, kind, float(wscale))
     isc = isc.contiguous() if isc is not None else None
     osc = osc.contiguous() if osc is not None else None
     return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale))

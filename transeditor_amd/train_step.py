@@ -21,6 +21,7 @@ from torch import autograd, optim
 from torch.nn import functional as F
 
 from .model_spatial_query import Discriminator, Generator
+from .op.modconv import no_weight_grads, second_order
 from .utils import distributed as D
 from .utils.sample import prepare_noise_new, prepare_param
 
@@ -39,7 +40,8 @@ def d_logistic_loss(real_pred, fake_pred):                                   # :
 
 
 def d_r1_loss(real_pred, real_img):                                          # :77-83
-    grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    with no_weight_grads():                                                  # only d/d(real_img) is requested here
+        grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 
@@ -49,7 +51,8 @@ def g_nonsaturating_loss(fake_pred):                                         # :
 
 def g_path_regularize(fake_img, latents, mean_path_length, noise, decay=0.01):   # :92-105 (noise = randn_like(img))
     noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
-    grad, = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
+    with no_weight_grads():                                                  # only d/d(latents) is requested here
+        grad, = autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
     path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
     path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
     path_penalty = (path_lengths - path_mean).pow(2).mean()
@@ -128,7 +131,8 @@ class TrainStep:
     def r1_step(self, real_img):
         Dn, a = self.discriminator, self.args
         real_img = real_img.detach().requires_grad_(True)
-        real_pred = Dn(real_img)
+        with second_order():
+            real_pred = Dn(real_img)
         r1_loss = d_r1_loss(real_pred, real_img)
         Dn.zero_grad()
         (a.r1 / 2 * r1_loss * a.d_reg_every + 0 * real_pred[0]).backward()
@@ -153,7 +157,8 @@ class TrainStep:
         G, a = self.generator, self.args
         n = max(1, a.batch // a.path_batch_shrink)
         noise, param = self.sampler.latents(n)
-        fake_img, latents, _ = G(noise, param, return_latents=True)
+        with second_order():
+            fake_img, latents, _ = G(noise, param, return_latents=True)
         path_loss, self.mean_path_length, path_lengths = g_path_regularize(
             fake_img, latents, self.mean_path_length, self.sampler.randn_like(fake_img))
         G.zero_grad()
