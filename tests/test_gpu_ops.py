@@ -182,7 +182,7 @@ def test_conv_trio_second_order(kind):
 
 
 @pytest.mark.parametrize('kind', ['3x3', '1x1', 'up'])
-@pytest.mark.parametrize('shape', [(3, 6, 5, 7, 7), (2, 72, 136, 20, 33), (16, 128, 64, 4, 4)])
+@pytest.mark.parametrize('shape', [(3, 6, 5, 7, 7), (2, 72, 136, 20, 33), (16, 128, 64, 4, 4), (2, 32, 32, 64, 64)])
 @pytest.mark.parametrize('act', [False, True])
 def test_modconv_fused_kernel_vs_composite(kind, shape, act):
     """fused kernel (scales + bias + lrelu in the prologue/epilogue, slab-based backward) vs the plain math."""
@@ -210,7 +210,7 @@ def test_modconv_fused_kernel_vs_composite(kind, shape, act):
         assert rel_err(a, b) < SUM_TOL, name
 
 
-@pytest.mark.parametrize('shape', [(2, 128, 16, 16), (3, 40, 6, 6), (2, 512, 4, 4), (2, 24, 5, 5), (2, 128, 64, 64)])
+@pytest.mark.parametrize('shape', [(2, 128, 16, 16), (3, 40, 6, 6), (2, 512, 4, 4), (2, 24, 5, 5), (2, 128, 64, 64), (2, 32, 96, 96)])
 def test_torgb_streaming_kernels(shape):
     """ToRGB path (1x1 -> 3 channels, style scale + bias): dedicated streaming kernels when H*W % 4 == 0 and K <= 512,
     MFMA 1x1 kernel otherwise; forward, dx, dW, ds, dbias against plain torch."""

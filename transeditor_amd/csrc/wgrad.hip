@@ -567,9 +567,10 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_few_kernel(float* __res
     if (ci >= Ci) return;
     const size_t E = (size_t)Co * Ci;
     const float* sp = slabs + (size_t)b * S * E + ci;
+    const int s0 = (int)((int64_t)S * blockIdx.z / gridDim.z), s1 = (int)((int64_t)S * (blockIdx.z + 1) / gridDim.z);
     float u[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int s = 0; s < S; ++s) {
+    for (int s = s0; s < s1; ++s) {
 #pragma unroll
         for (int o = 0; o < 4; ++o)
             if (o < Co) u[o] += sp[(size_t)s * E + (size_t)o * Ci];
@@ -583,7 +584,10 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_few_kernel(float* __res
             if (gw) atomicAdd(gw + (size_t)o * Ci + ci, u[o] * is * wscale);
         }
     }
-    if (gisc) gisc[(size_t)b * Ci + ci] = gi * wscale;
+    if (gisc) {
+        if (gridDim.z > 1) atomicAdd(gisc + (size_t)b * Ci + ci, gi * wscale);     // gisc is zero-filled by the caller
+        else gisc[(size_t)b * Ci + ci] = gi * wscale;
+    }
 }
 
 // One pass over the slabs for all three gradients (3x3 kinds, Co % 16 == 0, Ci % 32 == 0).  A block of 2 waves owns a
@@ -640,6 +644,9 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
                                                                       const float* __restrict__ w, float wscale,
                                                                       const float* __restrict__ isc, const float* __restrict__ osc,
                                                                       int B, int S, int Co, int Ci) {
+    // blockIdx.z splits the slab chunks of every sample (narrow layers: a 32 x 32 weight has 2 tiles but hundreds of
+    // chunks); all three outputs are linear in the slab sums, so the parts combine with atomics (outputs zero-filled)
+    const int s0 = (int)((int64_t)S * blockIdx.z / gridDim.z), s1 = (int)((int64_t)S * (blockIdx.z + 1) / gridDim.z);
     __shared__ float red[2 * 64];
     FusedCtx c;
     c.gisc = gisc; c.gosc = gosc; c.isc = isc; c.osc = osc; c.Co = Co; c.Ci = Ci;
@@ -656,13 +663,13 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
     int b = 0;
     for (; b + 1 < B; b += 2) {
         f32x4 u0[9], u1[9];
-        const float* p0 = slabs + (size_t)b * S * E + off;
+        const float* p0 = slabs + ((size_t)b * S + s0) * E + off;
         const float* p1 = p0 + (size_t)S * E;
 #pragma unroll
         for (int i = 0; i < 9; ++i) u0[i] = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
 #pragma unroll
         for (int i = 0; i < 9; ++i) u1[i] = *reinterpret_cast<const f32x4*>(p1 + 4 * i);
-        for (int s = 1; s < S; ++s) {
+        for (int s = 1; s < s1 - s0; ++s) {
             const float* q0 = p0 + (size_t)s * E;
             const float* q1 = p1 + (size_t)s * E;
 #pragma unroll
@@ -675,10 +682,10 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
     }
     if (b < B) {
         f32x4 u0[9];
-        const float* p0 = slabs + (size_t)b * S * E + off;
+        const float* p0 = slabs + ((size_t)b * S + s0) * E + off;
 #pragma unroll
         for (int i = 0; i < 9; ++i) u0[i] = *reinterpret_cast<const f32x4*>(p0 + 4 * i);
-        for (int s = 1; s < S; ++s) {
+        for (int s = 1; s < s1 - s0; ++s) {
             const float* q0 = p0 + (size_t)s * E;
 #pragma unroll
             for (int i = 0; i < 9; ++i) u0[i] += *reinterpret_cast<const f32x4*>(q0 + 4 * i);
@@ -687,7 +694,15 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
     }
     if (gw) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(gw + off + 4 * i) = acc[i] * wscale;
+        for (int i = 0; i < 9; ++i) {
+            const f32x4 v = acc[i] * wscale;
+            if (gridDim.z > 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(gw + off + 4 * i + q, v[q]);
+            } else {
+                *reinterpret_cast<f32x4*>(gw + off + 4 * i) = v;
+            }
+        }
     }
 }
 
@@ -731,7 +746,14 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
     hipStream_t s = (hipStream_t)stream_;
     const uintptr_t al = reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gw);
     if (taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && (al & 15) == 0 && Co / FROWS <= 65535) {      // single-pass path
-        dim3 grid((unsigned)(Ci / 32), (unsigned)(Co / FROWS));
+        const int tiles = (Ci / 32) * (Co / FROWS);
+        int nz = 1;
+        if (tiles < te::kNumCU / 4 && S >= 8) nz = (int)std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, tiles));
+        if (gw && nz > 1) {
+            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * Ci * 9, s);
+            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        dim3 grid((unsigned)(Ci / 32), (unsigned)(Co / FROWS), (unsigned)nz);
         wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
         return te::launch_status("te_wgrad_reduce_f32");
     }
@@ -740,7 +762,9 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const fl
             hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * Ci, s);
             if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
         }
-        dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)B);
+        // few, long per-thread streams when the image is large (S up to a few hundred): split them over blockIdx.z
+        const int nzf = (int)std::max<int64_t>(1, std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, (int64_t)te::cdiv(Ci, RTHREADS) * B)));
+        dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)B, (unsigned)nzf);
         wgrad_reduce_few_kernel<<<grid, RTHREADS, 0, s>>>(gw, gisc, slabs, w, wscale, isc, B, S, Co, Ci);
         return te::launch_status("te_wgrad_reduce_f32");
     }
