@@ -182,7 +182,8 @@ def test_conv_trio_second_order(kind):
 
 
 @pytest.mark.parametrize('kind', ['3x3', '1x1', 'up'])
-@pytest.mark.parametrize('shape', [(3, 6, 5, 7, 7), (2, 72, 136, 20, 33), (16, 128, 64, 4, 4), (2, 32, 32, 64, 64)])
+@pytest.mark.parametrize('shape', [(3, 6, 5, 7, 7), (2, 72, 136, 20, 33), (16, 128, 64, 4, 4), (2, 32, 32, 64, 64),
+                                   (2, 32, 64, 16, 16), (2, 64, 48, 16, 16)])
 @pytest.mark.parametrize('act', [False, True])
 def test_modconv_fused_kernel_vs_composite(kind, shape, act):
     """fused kernel (scales + bias + lrelu in the prologue/epilogue, slab-based backward) vs the plain math."""

@@ -97,9 +97,24 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Narrow layers (4-wave tile only): when a side of the block tile has a single valid 32-channel block (32- / 48-channel
+    // layers of the 512 / 1024 px generator tail, or the last block of a 96-channel side), the waves that would multiply
+    // zero padding take a share of the staged cells instead (K split 2 or 4 ways) and the partial tiles are combined
+    // through LDS before the slab is written.
+    int pb = wp, qb = wq, kw = 0, kstride = 1, ngrp = 1, grp = 0;
+    if constexpr (NWP == 2) {
+        const int nPB = (min(PCH, pC - pc0) + 31) >> 5, nQB = (min(QCH, qC - qc0) + 31) >> 5;
+        const int kp = (nPB >= 2) ? 1 : 2, kq = (nQB >= 2) ? 1 : 2;
+        pb = (nPB >= 2) ? wp : 0;
+        qb = (nQB >= 2) ? wq : 0;
+        kstride = kp * kq;
+        kw = ((nPB >= 2) ? 0 : wp) * kq + ((nQB >= 2) ? 0 : wq);
+        ngrp = 4 / kstride;
+        grp = (nPB >= 2) ? ((nQB >= 2) ? wid : wp) : ((nQB >= 2) ? wq : 0);
+    }
     // lane bases inside the LDS tiles: g is the A operand, x the B operand
-    const int a_ch = (GSHIFT ? wq : wp) * 32 + l31;     // co of this lane inside the block tile
-    const int b_ch = (GSHIFT ? wp : wq) * 32 + l31;     // ci of this lane inside the block tile
+    const int a_ch = (GSHIFT ? qb : pb) * 32 + l31;     // co of this lane inside the block tile
+    const int b_ch = (GSHIFT ? pb : qb) * 32 + l31;     // ci of this lane inside the block tile
     const float* g_l = (GSHIFT ? ql : pl) + a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half);
     const float* x_l = (GSHIFT ? pl : ql) + b_ch * (GSHIFT ? p.PS : p.QS) + half;
 
@@ -308,21 +323,22 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
             return (KIND == TE_CONV_T2) ? 2 * cy * p.QW + 2 * cx : cy * p.QW + cx;
         };
         {
-            const int sh = pos_shift(0);
+            const int k0 = min(kw, nks - 1);
+            const int sh = pos_shift(k0);
             if (!GSHIFT) {
-                a_c[0] = g_l[0];
+                a_c[0] = g_l[2 * k0];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b_c[t] = x_l[sh + ((NT == 1) ? 0 : (t / 3) * p.QW + (t % 3))];
             } else {
-                b_c[0] = x_l[0];
+                b_c[0] = x_l[2 * k0];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) a_c[t] = g_l[sh + (t / 3) * p.QW + (t % 3)];
             }
         }
 #pragma unroll 2
-        for (int ks = 0; ks < nks; ++ks) {
+        for (int ks = kw; ks < nks; ks += kstride) {
             float a_n[GSHIFT ? NT : 1], b_n[GSHIFT ? 1 : NT];
-            const int kn = (ks + 1 < nks) ? ks + 1 : ks;          // last step re-reads itself (harmless)
+            const int kn = (ks + kstride < nks) ? ks + kstride : ks;          // last step re-reads itself (harmless)
             const int sh = pos_shift(kn);
             if (!GSHIFT) {
                 a_n[0] = g_l[2 * kn];
@@ -346,12 +362,36 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
         }
     }
 
+    if constexpr (NWP == 2) {
+        if (kstride > 1) {        // block-uniform: combine the K-split partial tiles, one round per extra share
+            float* red = smem + (size_t)grp * (NT * 16 * 64);
+            for (int rnd = 1; rnd < kstride; ++rnd) {
+                __syncthreads();
+                if (kw == rnd) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+                }
+                __syncthreads();
+                if (kw == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
+                }
+            }
+            if (kw != 0) return;
+        }
+    }
+    (void)ngrp;
+
     // ---- write the slab tile: rows = co, cols = ci;  slab[b][s][co][ci][tap]
     float* sl = p.slabs + ((size_t)b * p.S + s_chunk) * p.Co * p.Ci * NT;
     const int ci = ci0 + b_ch;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (GSHIFT ? wq : wp) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + (GSHIFT ? qb : pb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < p.Co && ci < p.Ci) {
             float* dst = sl + ((size_t)co * p.Ci + ci) * NT;
 #pragma unroll
@@ -407,7 +447,8 @@ inline int pick_nwp(int Co, int Ci) { return (wgrad_nwp() == 2 || (Co <= 64 && C
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
-    const size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
+    size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
+    if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
