@@ -179,9 +179,12 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                     }
                 }
                 if (KIND == TE_CONV_3X3) {
-                    unsigned it = tid;
-                    const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
-                    if (chl < QCH) ql[chl * p.QS + (rem >> 1) * p.QW + ((rem & 1) ? p.QW - 1 : 0)] = qreg[4 * NQ4];
+#pragma unroll
+                    for (int e = 0; e < 512 / NTHREADS; ++e) {        // the QCH * QH * 2 = 512 halo columns
+                        unsigned it = tid + NTHREADS * e;
+                        const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
+                        if (chl < QCH) ql[chl * p.QS + (rem >> 1) * p.QW + ((rem & 1) ? p.QW - 1 : 0)] = qreg[4 * NQ4 + e];
+                    }
                 }
             } else {
 #pragma unroll
@@ -272,11 +275,14 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                         for (int j = 0; j < 4; ++j) qreg[4 * r + j] = v[j];
                     }
                     if (KIND == TE_CONV_3X3) {     // the two halo columns of every (channel, row)
-                        unsigned it = tid;
-                        const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
-                        const int y = qy0 + (int)(rem >> 1), xx = (rem & 1) ? tx0 + p.TW : tx0 - 1, ch = qc0 + (int)chl;
-                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
-                        qreg[4 * NQ4] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+#pragma unroll
+                        for (int e = 0; e < 512 / NTHREADS; ++e) {
+                            unsigned it = tid + NTHREADS * e;
+                            const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
+                            const int y = qy0 + (int)(rem >> 1), xx = (rem & 1) ? tx0 + p.TW : tx0 - 1, ch = qc0 + (int)chl;
+                            const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
+                            qreg[4 * NQ4 + e] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+                        }
                     }
                 } else {
 #pragma unroll
@@ -436,8 +442,8 @@ bool fill_geometry(WgArgs& a) {
     a.magic_q16 = magic((unsigned)(a.QH * 16));
     a.magic_q1 = magic((unsigned)a.QH);
     // the 16-byte staging path needs full 32-cell rows whose global rows are 16 B aligned, and its one edge pass
-    // (QCH * QH * 2 scalars) must fit a single sweep of the block
-    a.vec = (pick_nwp(a.Co, a.Ci) == 4 && a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
+    // (QCH * QH * 2 = 512 scalars at the full 64-cell tile) takes 512 / NTHREADS sweeps of the block
+    a.vec = (a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
              (((uintptr_t)a.g | (uintptr_t)a.x) & 15) == 0) ? 1 : 0;
     return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
 }
