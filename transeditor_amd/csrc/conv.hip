@@ -51,7 +51,7 @@ constexpr int MPAD = 128;   // packed weights: M padded to a multiple of 128 (bl
 #endif
 template <int KIND, int TC> struct Cfg;
 template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
@@ -532,7 +532,7 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     // split count comes from the real tile geometry of the main region and is shared by every region launch
     {
         const bool t2 = (kind == TE_CONV_T2);
-        const int ntile = t2 ? (tc == 1 ? 64 : 128) : (tc == 0 ? 128 : 256);      // cells per block tile of the chosen tile class
+        const int ntile = t2 ? (tc == 1 ? 64 : 128) : ((tc == 0 || (kind == TE_CONV_S2 && tc == 1)) ? 128 : 256);      // cells per block tile of the chosen tile class
         int rh = H, rw = W;
         if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
         const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
