@@ -99,7 +99,8 @@ int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_p
                              int ksize, te_stream_t stream);
 
 /* `H`,`W` are ALWAYS the low-resolution size (the H,W of the table above).  isc [B,K], osc [B,M],
- * bias [M] may be NULL.  act: 0 linear, 3 lrelu(0.2)*sqrt(2) (applied after osc and bias). */
+ * bias [M] may be NULL.  act: 0 linear, 3 lrelu(0.2)*sqrt(2), 4 lrelu(0.2) with gain 1 (a residual branch that folds the
+ * 1/sqrt(2) of `(out + skip) / sqrt(2)`, model_spatial_query.py:796) — applied after osc and bias. */
 int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
                 const float* bias, int act, int kind, int B, int K, int M, int H, int W,
                 te_stream_t stream);

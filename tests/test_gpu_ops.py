@@ -284,6 +284,24 @@ def test_demod_kernels(shape):
     assert rel_err(got[3][0], ref[3][0].float()) < 1e-4 and rel_err(got[3][1], ref[3][1].float()) < 1e-4
 
 
+@pytest.mark.parametrize('kind', ['3x3', 'down'])
+def test_conv_fused_activation_gain_one(kind):
+    """act code 4: leaky-ReLU with gain 1 in the conv epilogue (ResBlock folds its 1/sqrt(2) into the branches)."""
+    from transeditor_amd.op.modconv import modconv
+    B, K, M, H, W = 2, 24, 40, 8, 8
+    x = synth.normal((B, K, *_in_hw(kind, H, W)), 'g1.x').requires_grad_(True)
+    w = (synth.normal((M, K, 3, 3), 'g1.w') / math.sqrt(K * 9)).requires_grad_(True)
+    bias = synth.normal((M,), 'g1.b').requires_grad_(True)
+    y_ref = F.leaky_relu(_ref_conv(kind, x, w * 0.8) + bias[None, :, None, None], 0.2)
+    gy = synth.normal(tuple(y_ref.shape), 'g1.g')
+    ref = torch.autograd.grad((y_ref * gy).sum(), (x, w, bias))
+    d = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, bias)]
+    y = modconv(d[0], d[1], None, None, d[2], 1.0, kind, 0.8)
+    assert rel_err(y, y_ref) < OP_TOL
+    for a, b in zip(torch.autograd.grad((y * gy.to(DEV)).sum(), d), ref):
+        assert rel_err(a, b) < SUM_TOL
+
+
 # ------------------------------------------------------------------------------------------------ F1 module
 @pytest.mark.parametrize('name', ['plain3', 'up3', 'rgb1', 'plain3_wide', 'up3_wide'])
 def test_modulated_conv2d_module_golden(golden, name):

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                     }
                 } else if (!IS_T2) {
                     float v = acc[mb][nb][r] * sc[r] + bi[r];
-                    if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+                    if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
                     if (ok) obase[(size_t)ci * p.Wo + cj] = v;
                 } else {
                     // the two column phases of a cell are adjacent outputs: one 8-byte store per row phase (rows are 2W+1
@@ -322,9 +322,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                         const int Y = 2 * ci + a2, X = 2 * cj;
                         float v0 = acc[mb][nb * 4 + 2 * a2][r] * sc[r] + bi[r];
                         float v1 = acc[mb][nb * 4 + 2 * a2 + 1][r] * sc[r] + bi[r];
-                        if (p.act == 3) {
-                            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * 1.4142135623730951f;
-                            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * 1.4142135623730951f;
+                        if (p.act >= 3) {
+                            const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
+                            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * gain;
+                            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * gain;
                         }
                         if (ok && Y < p.Ho) {
                             float* dst = obase + (size_t)Y * p.Wo + X;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ 
         float v = out[e];
         if (osc) v *= osc[bm];
         if (bias) v += bias[bm % M];
-        if (act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+        if (act >= 3) v = (v > 0.f ? v : v * 0.2f) * (act == 3 ? 1.4142135623730951f : 1.f);
         out[e] = v;
     }
 }
@@ -515,7 +516,7 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
                            const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
     TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
-    TE_REQUIRE(act == 0 || act == 3, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0 or 3");
+    TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
     hipStream_t s = (hipStream_t)stream_;
     ConvArgs a{};
     a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;

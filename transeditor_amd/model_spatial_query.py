@@ -18,6 +18,7 @@ There is no CPU path: the ops raise if libte_hip.so is missing or tensors are no
 File:line citations refer to the reference's model_spatial_query.py.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -98,15 +99,23 @@ class EqualConv2d(nn.Module):                                                   
         self.stride, self.padding = stride, padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input, act_bias=None, presampled=False):
+    def forward(self, input, act_bias=None, presampled=False, gain=1.0):
         """`act_bias` (extension used by ConvLayer): fuse '+ act_bias' and the scaled leaky-ReLU that follows.
         `presampled` (ConvLayer, 1x1 stride 2 only): the caller already kept every second row / column.
+        `gain` (ResBlock): constant output factor folded into the weights (no activation) or the leaky-ReLU gain.
         The four configurations the discriminator uses run on the MI355X convolution kernels (same family as the
         generator, no modulation); anything else falls back to the library convolution."""
         w, ws = self.weight, self.scale
         k, cfg = self.weight.shape[2], (self.weight.shape[2], self.stride, self.padding)
         act = act_bias is not None
         bias = act_bias if act else self.bias
+        if gain != 1.0:
+            if act:
+                act = math.sqrt(2) * gain                 # lrelu(conv + b) * sqrt(2) * gain: the gain of the fused activation
+            elif bias is None:
+                ws = ws * gain
+            else:
+                return self.forward(input, act_bias, presampled) * gain
         if input.is_cuda and input.dtype == torch.float32:
             if cfg == (3, 1, 1):
                 return modconv(input, w, None, None, bias, act, '3x3', ws)
@@ -120,7 +129,7 @@ class EqualConv2d(nn.Module):                                                   
         if presampled:
             raise RuntimeError('EqualConv2d(presampled=True) is only meaningful for the 1x1 stride-2 configuration on the GPU')
         out = F.conv2d(input, w * ws, bias=self.bias, stride=self.stride, padding=self.padding)
-        return fused_leaky_relu(out, act_bias) if act else out
+        return fused_leaky_relu(out, act_bias, 0.2, math.sqrt(2) if act is True else act) if act else out
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},'
@@ -437,11 +446,16 @@ class ConvLayer(nn.Sequential):                                                 
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
-    def forward(self, input):
-        """Same sequence as nn.Sequential, with EqualConv2d -> FusedLeakyReLU fused into the conv epilogue."""
+    def forward(self, input, gain=1.0):
+        """Same sequence as nn.Sequential, with EqualConv2d -> FusedLeakyReLU fused into the conv epilogue.  `gain`
+        (ResBlock) is a constant factor on the layer output, folded into its last convolution when that is the last op."""
         mods = list(self)
         i = 0
         pres = False
+        last_conv = max((j for j, m in enumerate(mods) if isinstance(m, EqualConv2d)), default=-1)
+        fold = gain != 1.0 and last_conv >= 0 and (last_conv == len(mods) - 1 or (
+            last_conv == len(mods) - 2 and isinstance(mods[-1], FusedLeakyReLU) and mods[-1].bias is not None
+            and mods[last_conv].bias is None and mods[-1].negative_slope == 0.2 and abs(mods[-1].scale - 2 ** 0.5) < 1e-12))
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
@@ -453,19 +467,23 @@ class ConvLayer(nn.Sequential):                                                 
                 pres = True
                 i += 1
                 continue
+            g_here = gain if (fold and i == last_conv) else 1.0
             if pres:
-                input = m(input, presampled=True)
+                input = m(input, presampled=True, gain=g_here)
                 pres = False
                 i += 1
                 continue
             if (isinstance(m, EqualConv2d) and isinstance(nxt, FusedLeakyReLU) and nxt.bias is not None
                     and m.bias is None and nxt.negative_slope == 0.2 and abs(nxt.scale - 2 ** 0.5) < 1e-12):
-                input = m(input, act_bias=nxt.bias)
+                input = m(input, act_bias=nxt.bias, gain=g_here)
                 i += 2
+            elif isinstance(m, EqualConv2d):
+                input = m(input, gain=g_here)
+                i += 1
             else:
                 input = m(input)
                 i += 1
-        return input
+        return input if (fold or gain == 1.0) else input * gain
 
 
 class ResBlock(nn.Module):                                                           # :780-798
@@ -477,7 +495,9 @@ class ResBlock(nn.Module):                                                      
                               activate=False)
 
     def forward(self, input):
-        return (self.conv2(self.conv1(input)) + self.skip(input)) / math.sqrt(2)
+        # (conv2 + skip) / sqrt(2) (:796) with the constant folded into the two branches' last convolutions
+        g = 1 / math.sqrt(2)
+        return self.conv2(self.conv1(input), gain=g) + self.skip(input, gain=g)
 
 
 class Discriminator(nn.Module):                                                      # :801-859

@@ -65,6 +65,25 @@ def no_weight_grads():
 _KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2, 'down': _lib.CONV_S2}
 
 
+_SQRT2 = 2 ** 0.5
+
+
+def _act_gain(act):
+    """`act` is False, True (the reference's lrelu * sqrt(2)) or the gain itself (sqrt(2) or 1.0)."""
+    return _SQRT2 if act is True else float(act)
+
+
+def _act_code(act):
+    if not act:
+        return 0
+    g = _act_gain(act)
+    if abs(g - _SQRT2) < 1e-6:
+        return 3
+    if abs(g - 1.0) < 1e-6:
+        return 4
+    raise RuntimeError(f'modconv: leaky-ReLU gain {g} is not one the kernels fuse (sqrt(2) or 1)')
+
+
 def _lowres_hw(kind, is_output, t):
     """low-resolution (H, W) of the problem from the conv input (is_output=False) or output (True)."""
     H, W = t.shape[2], t.shape[3]
@@ -168,7 +187,7 @@ def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
     if osc is not None:
         y = y * osc[:, :, None, None]
     if act:
-        return fused_leaky_relu(y, bias)
+        return fused_leaky_relu(y, bias, 0.2, _act_gain(act))
     if bias is not None:
         y = y + bias[None, :, None, None]
     return y
@@ -185,7 +204,7 @@ class _ModConvFused(Function):
             ctx.save_for_backward(x, w, isc, osc, bias, None)
             ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
             return out
-        out = _fwd_raw(x, w, kind, isc, osc, bias, 3 if act else 0, wscale)
+        out = _fwd_raw(x, w, kind, isc, osc, bias, _act_code(act), wscale)
         ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
         ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
         return out
@@ -212,7 +231,7 @@ class _ModConvFused(Function):
         g = g.contiguous()
         g_bias = None
         if act:
-            g, g_bias = _lib.bias_act_bwd(g, out, 0.2, 2 ** 0.5, want_bias=bias is not None)
+            g, g_bias = _lib.bias_act_bwd(g, out, 0.2, _act_gain(act), want_bias=bias is not None)
         elif bias is not None and need[4]:
             g_bias = g.sum(dim=(0, 2, 3))
         if ctx.rgb:
@@ -239,6 +258,7 @@ class _ModConvFused(Function):
 
 def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1.0):
     """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, wscale * w) + bias[co] )  — fused kernels.
+    `act`: False, True (gain sqrt(2), the reference's FusedLeakyReLU) or the gain itself (sqrt(2) or 1.0).
     `wscale` is the equalised-lr constant: the parameter is consumed as stored, its gradient comes back scaled."""
     if _STATE['second_order'] and torch.is_grad_enabled():
         return _composite(x, w, isc, osc, bias, act, kind, float(wscale))
