@@ -68,13 +68,15 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     const int ix0 = fdiv(mid_x0, UP), iy0 = fdiv(mid_y0, UP);
     const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
 
-    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+    // A block walks several planes (blockIdx.z stride) with a register prefetch: the tile of the next plane is loaded
+    // while the current one is filtered out of LDS, so the global-load latency is paid once per block, not per plane.
+    constexpr int NLD = (TIH * TIW + 255) / 256;
+    float stage[NLD];
+    float rv[AG ? NLD : 1];
+    // all loads of a tile are issued back to back (clamped address + select: no branch, so the NLD global loads of a
+    // lane are in flight together instead of one latency after the other)
+    auto fetch = [&](int64_t mj) {
         const float* xin = x + (size_t)mj * p.in_h * p.in_w;
-        __syncthreads();
-        // all loads of the tile are issued before the first LDS write (clamped address + select: no branch, so the
-        // NLD global loads of a lane are in flight together instead of one latency after the other)
-        constexpr int NLD = (TIH * TIW + 255) / 256;
-        float stage[NLD];
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
             const int e = threadIdx.x + 256 * r;
@@ -86,7 +88,6 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
         }
         if constexpr (AG) {
             const float* rin = ref + (size_t)mj * p.in_h * p.in_w;
-            float rv[NLD];
 #pragma unroll
             for (int r = 0; r < NLD; ++r) {
                 const int e = threadIdx.x + 256 * r;
@@ -95,6 +96,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
                 const bool ok = e < TIH * TIW && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w;
                 rv[r] = rin[ok ? (size_t)gy * p.in_w + gx : 0];
             }
+        }
+    };
+    if ((int64_t)blockIdx.z < p.major) fetch(blockIdx.z);
+
+    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+        __syncthreads();                 // the previous plane's filter pass is done with sx / sred
+        if constexpr (AG) {
             float own = 0.f;
             const bool last_y = blockIdx.y == gridDim.y - 1, last_x = blockIdx.x == gridDim.x - 1;
 #pragma unroll
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             if (e < TIH * TIW) sx[ry * TIWP + rx] = stage[r];
         }
         __syncthreads();
+        if (mj + gridDim.z < p.major) fetch(mj + gridDim.z);       // in flight during the filter pass below
         if constexpr (AG) {
             if (threadIdx.x == 0)
                 partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
@@ -164,11 +173,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             }
             float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
             const int ch = b ? (int)(mj % p.size_b) : 0;
-            if ((p.out_w & 3) == 0 && ox0 + tx + 3 < p.out_w) {      // rows 16-byte aligned: one 16-byte store per lane
-                float4 v;
-                v.x = epilogue<AG>(res[0], b, ch, p); v.y = epilogue<AG>(res[1], b, ch, p);
-                v.z = epilogue<AG>(res[2], b, ch, p); v.w = epilogue<AG>(res[3], b, ch, p);
-                *reinterpret_cast<float4*>(orow + ox0 + tx) = v;
+            if (ox0 + tx + 3 < p.out_w) {      // one 16-byte store per lane; rows of odd width (257, 129, ...) are only
+                                               // 4-byte aligned, which global dwordx4 stores accept
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                f32x4u v;
+                v[0] = epilogue<AG>(res[0], b, ch, p); v[1] = epilogue<AG>(res[1], b, ch, p);
+                v[2] = epilogue<AG>(res[2], b, ch, p); v[3] = epilogue<AG>(res[3], b, ch, p);
+                *reinterpret_cast<f32x4u*>(orow + ox0 + tx) = v;
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -207,10 +218,15 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(float* __restrict__ out
     }
 }
 
+// blocks along z: enough blocks to fill the chip (~24 per CU), the remaining planes are walked inside the block
+inline int64_t fir_planes_z(int64_t major, int64_t tiles) {
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(major, 32768), te::cdiv(6144, tiles)));
+}
+
 template <int UP, int DOWN, int KH, int KW>
 void launch_tile(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s) {
-    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH),
-              (unsigned)std::min<int64_t>(p.major, 32768));
+    const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
+    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(p.major, tiles));
     fir_tile_kernel<UP, DOWN, KH, KW><<<grid, 256, 0, s>>>(out, x, k, b, p);
 }
 
@@ -240,7 +256,8 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
     p.size_b = 1; p.act = 0; p.alpha = alpha; p.scale = scale;
     if (major == 0) return 0;
     TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_actgrad_f32: too many planes");
-    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)std::min<int64_t>(major, 32768));
+    const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
+    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(major, tiles));
     fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
     return te::launch_status("te_blur_actgrad_f32");
 }
