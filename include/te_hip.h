@@ -178,6 +178,17 @@ int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, cons
                       float* arowsum, float rs_scale, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
                       int64_t sbj, float alpha, float beta, int act, te_stream_t stream);
 
+/* G2  the token-wise mapping loops (reference: Generator.forward, model_spatial_query.py:626-646 — for each of the 16
+ * tokens its own EqualLinear + fused leaky-ReLU, 64 launches + 32 slice copies) as ONE launch: the same kernel batched
+ * over blockIdx.z.  Operand z uses a + z*za, c + z*zc (uniform element strides) and either b + z*zb / bias + z*zbias or,
+ * when the per-token parameters are separate allocations, b + b_tab[z] / bias + bias_tab[z] (host arrays of nz <= 16
+ * element offsets, NULL for the uniform form).  C(i,j) = c[i*sci + j*scj], so the result can be written straight into the
+ * [B, tokens, D] or [B, D, tokens] layout the next stage reads.  No pre / residual / row sums in this form. */
+int te_small_gemm_batched_f32(float* c, const float* a, const float* b, const float* bias, int nz, int64_t za, int64_t zc,
+                              int64_t zb, int64_t zbias, const int64_t* b_tab, const int64_t* bias_tab, int I, int J, int K,
+                              int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, int64_t sci, int64_t scj, float alpha,
+                              float beta, int act, te_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * M1  demodulation coefficients (reference: ModulatedConv2d.forward, model_spatial_query.py:300-304 —
  * rsqrt(sum (scale * W * style)^2 + 1e-8) over B materialised weight copies).  Shared-weight form:

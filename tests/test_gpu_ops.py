@@ -421,3 +421,31 @@ def test_linear_fused_strided_rows():
     gy = torch.randn(16, 64, generator=g).cuda()
     for a_, b_ in zip(torch.autograd.grad(y, (lat, w), gy), torch.autograd.grad(y_ref, (lat, w), gy)):
         assert rel_err(a_, b_) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ G2 token-wise mapping
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,D,Cn,T', [(16, 512, 16, 16), (3, 96, 8, 5), (33, 64, 16, 16)])
+def test_token_mlp_batched_launch(B, D, Cn, T):
+    """one launch for the T per-token EqualLinear + fused lrelu layers (model_spatial_query.py:626-646): values, every
+    gradient and the recorded backward against the per-token torch expression in fp64 / fp32."""
+    from transeditor_amd.op.token_mlp import _torch_expr, token_mlp
+    g = torch.Generator().manual_seed(B * 100 + D)
+    x = torch.randn(B, D, Cn, generator=g).cuda().requires_grad_(True)
+    ws = [(torch.randn(D, D, generator=g) / 0.01).cuda().requires_grad_(True) for _ in range(T)]
+    bs = [torch.randn(D, generator=g).cuda().requires_grad_(True) for _ in range(T)]
+    scale, lr_mul = 0.01 / math.sqrt(D), 0.01
+    y = token_mlp(x, ws, bs, scale, lr_mul)
+    ref = torch.stack([F.leaky_relu(F.linear(x[:, :, t].double(), ws[t].double() * scale, bs[t].double() * lr_mul), 0.2)
+                       * math.sqrt(2) for t in range(T)], 1)
+    assert tuple(y.shape) == (B, T, D) and rel_err(y, ref.float()) < 1e-5
+    gy = torch.randn(B, T, D, generator=g).cuda()
+    got = torch.autograd.grad(y, [x] + ws + bs, gy)
+    want = torch.autograd.grad(ref, [x] + ws + bs, gy.double())
+    for a_, b_ in zip(got, want):
+        assert rel_err(a_, b_.float()) < 2e-5
+    gx, = torch.autograd.grad(token_mlp(x, ws, bs, scale, lr_mul), x, gy, create_graph=True)
+    gx_ref, = torch.autograd.grad(_torch_expr(x, ws, bs, scale, lr_mul), x, gy, create_graph=True)
+    a_, = torch.autograd.grad(gx.square().sum(), ws[0])
+    b_, = torch.autograd.grad(gx_ref.square().sum(), ws[0])
+    assert rel_err(a_, b_) < 1e-4

@@ -39,6 +39,8 @@ _SIGNATURES = {
     'te_blur_actgrad_tiles': (C.c_int, [_I] * 8),
     'te_blur_actgrad_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
+    'te_small_gemm_batched_f32': (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L,
+                                             _F, _F, _I, _P]),
     'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
@@ -244,6 +246,21 @@ def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alph
                                    rowsum_scale if rowsum_scale is not None else 0.0, I, J, K, sai, sak, sbk, sbj, alpha,
                                    beta, act, _stream()), 'te_small_gemm_f32')
     return c, pre, rs
+
+
+def small_gemm_batched(c, a, b, bias, nz, za, zc, I, J, K, sai, sak, sbk, sbj, sci, scj, zb=0, zbias=0, b_tab=None,
+                       bias_tab=None, alpha=1.0, beta=1.0, act=0):
+    """nz GEMMs in one launch (see te_hip.h); c is written in place through (zc, sci, scj).  b_tab / bias_tab: lists of
+    element offsets relative to b / bias for separately allocated per-z operands."""
+    for t in (c, a, b):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
+    bt = (C.c_int64 * nz)(*b_tab) if b_tab is not None else None
+    bit = (C.c_int64 * nz)(*bias_tab) if bias_tab is not None else None
+    _check(lib().te_small_gemm_batched_f32(c.data_ptr(), a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                           nz, za, zc, zb, zbias, bt, bit, I, J, K, sai, sak, sbk, sbj, sci, scj, alpha, beta,
+                                           act, _stream()), 'te_small_gemm_batched_f32')
+    return c
 
 
 # --------------------------------------------------------------------------------------------- M1

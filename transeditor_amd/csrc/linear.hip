@@ -27,8 +27,14 @@ struct LinArgs {
     float rs_scale;
     int I, J, K;
     int64_t sai, sak, sbk, sbj;   // element strides: A(i,k) = a[i*sai + k*sak], B(k,j) = b[k*sbk + j*sbj]
+    int64_t sci, scj;             // C(i,j) = c[i*sci + j*scj]  (pre / residual use the same addressing)
     float alpha, beta;
     int act;                 // 0 none, 1 GELU (erf), 3 leaky-ReLU(0.2) * sqrt(2)
+    // batch over blockIdx.z (the 16 per-token layers of a mapping network in one launch): uniform element strides for
+    // a / c, and either a uniform stride or a per-z offset table (separately allocated parameters) for b / bias
+    int64_t za, zc, zb, zbias;
+    int use_tab;
+    int64_t b_tab[16], bias_tab[16];
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -44,8 +50,11 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
     const int l31 = lane & 31, half = lane >> 5;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int ia = min(i0 + l31, p.I - 1), jb = min(j0 + l31, p.J - 1);     // clamped: padded rows / columns are never stored
-    const float* ap = p.a + (int64_t)ia * p.sai;
-    const float* bp = p.b + (int64_t)jb * p.sbj;
+    const int z = blockIdx.z;
+    const float* ap = p.a + z * p.za + (int64_t)ia * p.sai;
+    const float* bp = p.b + (p.use_tab ? p.b_tab[z] : z * p.zb) + (int64_t)jb * p.sbj;
+    const float* biasp = p.bias ? p.bias + (p.use_tab ? p.bias_tab[z] : z * p.zbias) : nullptr;
+    float* cp = p.c + z * p.zc;
     // this wave's K range (multiples of 8 so the float4 path stays aligned)
     const int kq = ((p.K + 8 * NW - 1) / (8 * NW)) * 8;
     const int kb = wid * kq, ke = min(p.K, kb + kq);
@@ -93,13 +102,13 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
         for (int w = 0; w < NW; ++w) v += red[w][e];
         if (i < p.I && j < p.J) {
             v *= p.alpha;
-            if (p.bias) v += p.bias[j] * p.beta;
-            const int64_t o = (int64_t)i * p.J + j;
+            if (biasp) v += biasp[j] * p.beta;
+            const int64_t o = (int64_t)i * p.sci + (int64_t)j * p.scj;
             if (p.pre) p.pre[o] = v;
             if (p.act == 1) v = gelu_erf(v);
             else if (p.act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
             if (p.residual) v += p.residual[o];
-            p.c[o] = v;
+            cp[o] = v;
         }
     }
     if (p.arowsum && blockIdx.x == 0) {          // uniform branch; the tile partials are consumed, reuse the LDS
@@ -125,20 +134,15 @@ void launch_nw(const LinArgs& p, bool av, bool bv, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias,
-                                 const float* residual, float* arowsum, float rs_scale, int I, int J, int K,
-                                 int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, float alpha, float beta, int act,
-                                 te_stream_t stream_) {
-    TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_f32: NULL pointer");
-    TE_REQUIRE(I > 0 && J > 0 && K > 0, TE_ERR_SHAPE, "te_small_gemm_f32: bad dims");
-    TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_f32: act must be 0, 1 or 3");
-    LinArgs p{c, pre, a, b, bias, residual, arowsum, rs_scale, I, J, K, sai, sak, sbk, sbj, alpha, beta, act};
-    const bool av = sak == 1 && sai % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
-    const bool bv = sbk == 1 && sbj % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
-    dim3 grid((unsigned)te::cdiv(J, 32), (unsigned)te::cdiv(I, 32));
-    hipStream_t s = (hipStream_t)stream_;
+static int launch_small_gemm(LinArgs& p, int nz, hipStream_t s) {
+    const bool av = p.sak == 1 && p.sai % 4 == 0 && p.za % 4 == 0 && (reinterpret_cast<uintptr_t>(p.a) & 15) == 0;
+    bool bv = p.sbk == 1 && p.sbj % 4 == 0 && p.zb % 4 == 0 && (reinterpret_cast<uintptr_t>(p.b) & 15) == 0;
+    if (p.use_tab)
+        for (int z = 0; z < nz; ++z) bv = bv && p.b_tab[z] % 4 == 0;
+    dim3 grid((unsigned)te::cdiv(p.J, 32), (unsigned)te::cdiv(p.I, 32), (unsigned)nz);
     // waves per tile: a wave's K slice <= 64 where possible, and more waves when the grid alone cannot fill the chip
-    const int64_t tiles = (int64_t)grid.x * grid.y;
+    const int64_t tiles = (int64_t)grid.x * grid.y * grid.z;
+    const int K = p.K;
     int nw = K > 256 ? 8 : (K > 64 ? 4 : (K > 16 ? 2 : 1));
     if (K >= 512 && (K > 512 || tiles < 2 * te::kNumCU)) nw = 16;
     if (nw == 16) launch_nw<16>(p, av, bv, grid, s);
@@ -146,5 +150,43 @@ extern "C" int te_small_gemm_f32(float* c, float* pre, const float* a, const flo
     else if (nw == 4) launch_nw<4>(p, av, bv, grid, s);
     else if (nw == 2) launch_nw<2>(p, av, bv, grid, s);
     else launch_nw<1>(p, av, bv, grid, s);
+    return 0;
+}
+
+extern "C" int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias,
+                                 const float* residual, float* arowsum, float rs_scale, int I, int J, int K,
+                                 int64_t sai, int64_t sak, int64_t sbk, int64_t sbj, float alpha, float beta, int act,
+                                 te_stream_t stream_) {
+    TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_f32: NULL pointer");
+    TE_REQUIRE(I > 0 && J > 0 && K > 0, TE_ERR_SHAPE, "te_small_gemm_f32: bad dims");
+    TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_f32: act must be 0, 1 or 3");
+    LinArgs p{};
+    p.c = c; p.pre = pre; p.a = a; p.b = b; p.bias = bias; p.residual = residual; p.arowsum = arowsum; p.rs_scale = rs_scale;
+    p.I = I; p.J = J; p.K = K; p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj; p.sci = J; p.scj = 1;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    launch_small_gemm(p, 1, (hipStream_t)stream_);
     return te::launch_status("te_small_gemm_f32");
+}
+
+extern "C" int te_small_gemm_batched_f32(float* c, const float* a, const float* b, const float* bias, int nz, int64_t za,
+                                         int64_t zc, int64_t zb, int64_t zbias, const int64_t* b_tab,
+                                         const int64_t* bias_tab, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
+                                         int64_t sbj, int64_t sci, int64_t scj, float alpha, float beta, int act,
+                                         te_stream_t stream_) {
+    TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_batched_f32: NULL pointer");
+    TE_REQUIRE(I > 0 && J > 0 && K > 0 && nz > 0, TE_ERR_SHAPE, "te_small_gemm_batched_f32: bad dims");
+    TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_batched_f32: act must be 0, 1 or 3");
+    TE_REQUIRE(!b_tab || nz <= 16, TE_ERR_UNSUPPORTED, "te_small_gemm_batched_f32: at most 16 table entries per launch");
+    TE_REQUIRE(!b_tab || !bias || bias_tab, TE_ERR_NULL, "te_small_gemm_batched_f32: bias_tab missing");
+    LinArgs p{};
+    p.c = c; p.a = a; p.b = b; p.bias = bias;
+    p.I = I; p.J = J; p.K = K; p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj; p.sci = sci; p.scj = scj;
+    p.alpha = alpha; p.beta = beta; p.act = act;
+    p.za = za; p.zc = zc; p.zb = zb; p.zbias = zbias;
+    if (b_tab) {
+        p.use_tab = 1;
+        for (int z = 0; z < nz; ++z) { p.b_tab[z] = b_tab[z]; p.bias_tab[z] = bias_tab ? bias_tab[z] : 0; }
+    }
+    launch_small_gemm(p, nz, (hipStream_t)stream_);
+    return te::launch_status("te_small_gemm_batched_f32");
 }

@@ -30,6 +30,7 @@ from .op.fir_act import blur_bias_act
 from .op.linear import linear_fused
 from .op.modconv import modconv
 from .op.style import demod
+from .op.token_mlp import token_mlp
 
 CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm,
                        512: 32 * cm, 1024: 16 * cm}     # :473-483
@@ -346,16 +347,13 @@ class Generator(nn.Module):                                                     
         return noises
 
     def _map_tokens(self, net, codes, n_map):
-        """:626-646 — PixelNorm, then token i through its own EqualLinear + fused lrelu; all tokens in one
-        batched GEMM and one bias/activation launch.  codes [B, D, C] -> [B, D, C] (tokens >= n_map stay 0)."""
+        """:626-646 — PixelNorm, then token i through its own EqualLinear + fused lrelu: all tokens of a network in one
+        batched launch (op/token_mlp.py).  codes [B, D, C] -> [B, D, C] (tokens >= n_map stay 0)."""
         B, D, Cn = codes.shape
         x = net[0](codes)
         lins = [net[i + 1] for i in range(n_map)]
-        W = torch.stack([l.weight for l in lins]) * lins[0].scale                   # [T, out, in]
-        bias = torch.cat([l.bias for l in lins]) * lins[0].lr_mul                   # [T*out]
-        y = torch.bmm(x[:, :, :n_map].permute(2, 0, 1), W.transpose(1, 2))          # [T, B, out]
-        y = fused_leaky_relu(y.permute(1, 0, 2).reshape(B, n_map * D), bias)
-        out = y.view(B, n_map, D).permute(0, 2, 1)
+        y = token_mlp(x, [l.weight for l in lins], [l.bias for l in lins], lins[0].scale, lins[0].lr_mul)   # [B, T, D]
+        out = y.permute(0, 2, 1)
         if n_map < Cn:
             out = torch.cat([out, out.new_zeros(B, D, Cn - n_map)], dim=2)
         return out
