@@ -195,12 +195,13 @@ int te_small_gemm_batched_f32(float* c, const float* a, const float* b, const fl
  *   wsq[co,ci] = wscale^2 sum_t w[co,ci,t]^2            (output, kept for the backward)
  *   d[b,co]    = rsqrt(sum_ci s[b,ci]^2 wsq[co,ci] + eps)
  * backward, u = -gd d^3 / 2:  gw[co,ci,t] = 2 wscale^2 w sum_b u[b,co] s[b,ci]^2,  gs[b,ci] = 2 s sum_co u[b,co] wsq[co,ci]
- * (gw / gs may be NULL; B <= 64 in the backward).  w [Co,Ci,T], s [B,Ci], d / gd [B,Co].
+ * (gw / gs may be NULL; B <= 64 in the backward).  w [Co,Ci,T], s [B,Ci], d / gd [B,Co].  accumulate != 0: the results are
+ * ADDED to gw / gs (which then hold the convolution's own dW / d style from te_wgrad_reduce_f32).
  */
 int te_demod_fwd_f32(float* d, float* wsq, const float* w, const float* s, float wscale, float eps, int B, int Co, int Ci,
                      int T, te_stream_t stream);
 int te_demod_bwd_f32(float* gw, float* gs, const float* gd, const float* d, const float* w, const float* wsq,
-                     const float* s, float wscale, int B, int Co, int Ci, int T, te_stream_t stream);
+                     const float* s, float wscale, int B, int Co, int Ci, int T, int accumulate, te_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ _SIGNATURES = {
     'te_small_gemm_batched_f32': (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L,
                                              _F, _F, _I, _P]),
     'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
-    'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+    'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
 }
@@ -275,13 +275,17 @@ def demod_fwd(w, s, wscale, eps):
     return d, wsq
 
 
-def demod_bwd(gd, d, w, wsq, s, wscale, want_w=True, want_s=True):
+def demod_bwd(gd, d, w, wsq, s, wscale, want_w=True, want_s=True, into=None):
+    """into = (gw, gs): accumulate into these existing gradients (either may be None) instead of allocating new ones."""
     Co, Ci, T = w.shape
     B = s.shape[0]
-    gw = torch.empty_like(w) if want_w else None
-    gs = torch.empty_like(s) if want_s else None
+    if into is not None:
+        gw, gs = into
+    else:
+        gw = torch.empty_like(w) if want_w else None
+        gs = torch.empty_like(s) if want_s else None
     _check(lib().te_demod_bwd_f32(_ptr(gw), _ptr(gs), _ptr(gd.contiguous()), _ptr(d), _ptr(w), _ptr(wsq), _ptr(s), wscale,
-                                  B, Co, Ci, T, _stream()), 'te_demod_bwd_f32')
+                                  B, Co, Ci, T, 1 if into is not None else 0, _stream()), 'te_demod_bwd_f32')
     return gw, gs
 
 

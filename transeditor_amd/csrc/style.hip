@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(float* __restrict__ d, f
 __global__ __launch_bounds__(256) void demod_bwd_w_kernel(float* __restrict__ gw, const float* __restrict__ gd,
                                                           const float* __restrict__ d, const float* __restrict__ w,
                                                           const float* __restrict__ s, float wscale, int B, int Co, int Ci,
-                                                          int T) {
+                                                          int T, int acc) {
     __shared__ float u[BMAX];
     const int co = blockIdx.x, tid = threadIdx.x;
     if (tid < B) {
@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void demod_bwd_w_kernel(float* __restrict__ gw
         }
         q *= c2;
         const size_t o = ((size_t)co * Ci + ci) * T;
-        for (int t = 0; t < T; ++t) gw[o + t] = w[o + t] * q;
+        for (int t = 0; t < T; ++t) gw[o + t] = (acc ? gw[o + t] : 0.f) + w[o + t] * q;
     }
 }
 
 // grid (ceil(Ci/64), B), 256 threads: lane -> ci, the 4 waves split Co and combine through LDS
 __global__ __launch_bounds__(256) void demod_bwd_s_kernel(float* __restrict__ gs, const float* __restrict__ gd,
                                                           const float* __restrict__ d, const float* __restrict__ wsq,
-                                                          const float* __restrict__ s, int B, int Co, int Ci) {
+                                                          const float* __restrict__ s, int B, int Co, int Ci, int acc) {
     extern __shared__ float uu[];                         // [Co] + [4][64]
     float* part = uu + Co;
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void demod_bwd_s_kernel(float* __restrict__ gs
     for (; co < c1; ++co) a0 += uu[co] * wsq[(size_t)co * Ci + ci];
     part[wid * 64 + lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wid == 0 && blockIdx.x * 64 + lane < Ci)
-        gs[(size_t)b * Ci + ci] = 2.f * s[(size_t)b * Ci + ci] * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+    if (wid == 0 && blockIdx.x * 64 + lane < Ci) {
+        const size_t o = (size_t)b * Ci + ci;
+        gs[o] = (acc ? gs[o] : 0.f) + 2.f * s[o] * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+    }
 }
 
 }  // namespace
@@ -115,15 +117,15 @@ extern "C" int te_demod_fwd_f32(float* d, float* wsq, const float* w, const floa
 }
 
 extern "C" int te_demod_bwd_f32(float* gw, float* gs, const float* gd, const float* d, const float* w, const float* wsq,
-                                const float* s, float wscale, int B, int Co, int Ci, int T, te_stream_t stream_) {
+                                const float* s, float wscale, int B, int Co, int Ci, int T, int accumulate, te_stream_t stream_) {
     TE_REQUIRE(gd && d && w && wsq && s, TE_ERR_NULL, "te_demod_bwd_f32: NULL pointer");
     TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && T > 0, TE_ERR_SHAPE, "te_demod_bwd_f32: bad dims");
     TE_REQUIRE(B <= BMAX && Co <= 8192, TE_ERR_UNSUPPORTED, "te_demod_bwd_f32: B <= 64, Co <= 8192");
     hipStream_t st = (hipStream_t)stream_;
-    if (gw) demod_bwd_w_kernel<<<Co, 256, 0, st>>>(gw, gd, d, w, s, wscale, B, Co, Ci, T);
+    if (gw) demod_bwd_w_kernel<<<Co, 256, 0, st>>>(gw, gd, d, w, s, wscale, B, Co, Ci, T, accumulate);
     if (gs) {
         dim3 grid((unsigned)te::cdiv(Ci, 64), (unsigned)B);
-        demod_bwd_s_kernel<<<grid, 256, sizeof(float) * (Co + 256), st>>>(gs, gd, d, wsq, s, B, Co, Ci);
+        demod_bwd_s_kernel<<<grid, 256, sizeof(float) * (Co + 256), st>>>(gs, gd, d, wsq, s, B, Co, Ci, accumulate);
     }
     return te::launch_status("te_demod_bwd_f32");
 }

@@ -209,10 +209,12 @@ class ModulatedConv2d(nn.Module):                                               
 
     def forward(self, input, style, bias=None, act=False):
         """`bias`/`act` (extensions used by StyledConv / ToRGB) fuse '+ bias' and the scaled leaky-ReLU."""
-        w, s, d = self.scales(style)
+        s = self.modulation(style)
+        w = self.weight.view(self.weight.shape[1:])
+        eps = self.eps if self.demodulate else None          # demodulation is computed inside the modconv node
         if not self.upsample:
-            return modconv(input, w, s, d, bias, act, self.kind, self.scale)
-        out = modconv(input, w, s, d, None, False, 'up', self.scale)
+            return modconv(input, w, s, None, bias, act, self.kind, self.scale, demod_eps=eps)
+        out = modconv(input, w, s, None, None, False, 'up', self.scale, demod_eps=eps)
         if act:
             return blur_bias_act(out, self.blur.kernel, bias, self.blur.pad)
         out = self.blur(out)

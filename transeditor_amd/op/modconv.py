@@ -195,7 +195,14 @@ def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
 
 class _ModConvFused(Function):
     @staticmethod
-    def forward(ctx, x, w, isc, osc, bias, act, kind, wscale):
+    def forward(ctx, x, w, isc, osc, bias, act, kind, wscale, demod_eps):
+        # demod_eps != None: osc is the demodulation coefficient of (w, isc), computed here (te_demod_fwd_f32) and
+        # differentiated here (its dW / d style are accumulated into the convolution's own in the backward)
+        ctx.demod = None
+        if demod_eps is not None:
+            w3 = w.reshape(w.shape[0], w.shape[1], -1)
+            osc, wsq = _lib.demod_fwd(w3, isc, wscale, demod_eps)
+            ctx.demod = (demod_eps, wsq)
         # ToRGB (1x1 to 3 channels, no demodulation / activation) is HBM-bound: dedicated streaming kernels
         ctx.rgb = (kind == '1x1' and osc is None and not act
                    and _lib.rgb_supported(w.shape[0], w.shape[1], x.shape[2] * x.shape[3]))
@@ -221,13 +228,17 @@ class _ModConvFused(Function):
             # while everything stays connected to the original tensors for the next differentiation.
             with torch.enable_grad():
                 al = [None if t is None else t.view_as(t) for t in (x, w, isc, osc, bias)]
+                if ctx.demod is not None:          # osc is a function of (w, isc) inside this node
+                    from .style import demod as _demod
+                    al[3] = _demod(al[1], al[2], wscale, ctx.demod[0])
+                    need = tuple(need[:3]) + (False,) + tuple(need[4:])
                 y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind, wscale)
                 if _STATE['skip_w']:
                     need = (need[0], False) + tuple(need[2:])
                 ins = [t for t, n in zip(al, need[:5]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
             return tuple(next(gs) if (n and t is not None) else None
-                         for t, n in zip(al, need[:5])) + (None, None, None)
+                         for t, n in zip(al, need[:5])) + (None, None, None, None)
         g = g.contiguous()
         g_bias = None
         if act:
@@ -247,21 +258,37 @@ class _ModConvFused(Function):
                 gw = _slab_sum(slabs, kind).reshape(w.shape) if need[1] else None
                 if gw is not None and wscale != 1.0:
                     gw = gw * wscale
-                return gx, gw, None, None, g_bias, None, None, None
-            gw, gisc, gosc = _lib.wgrad_reduce(slabs, w.reshape(w.shape[0], w.shape[1], -1), wscale, isc, osc,
+                return gx, gw, None, None, g_bias, None, None, None, None
+            w3 = w.reshape(w.shape[0], w.shape[1], -1)
+            dm = ctx.demod is not None
+            gw, gisc, gosc = _lib.wgrad_reduce(slabs, w3, wscale, isc, osc,
                                                want_w=need[1], want_isc=need[2] and isc is not None,
-                                               want_osc=need[3] and osc is not None)
+                                               want_osc=(need[3] or dm) and osc is not None)
+            if dm:       # chain through d = demod(w, isc): its dW / d style are added to gw / gisc in place
+                if gw is not None or gisc is not None:
+                    _lib.demod_bwd(gosc, osc, w3, ctx.demod[1], isc, wscale, into=(gw, gisc))
+                gosc = None
             if gw is not None:
                 gw = gw.reshape(w.shape)
-        return gx, gw, gisc, gosc, g_bias, None, None, None
+        return gx, gw, gisc, gosc, g_bias, None, None, None, None
 
 
-def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1.0):
+def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1.0, demod_eps=None):
     """out = [lrelu*sqrt2]( osc[b,co] * conv(isc[b,ci] * x, wscale * w) + bias[co] )  — fused kernels.
     `act`: False, True (gain sqrt(2), the reference's FusedLeakyReLU) or the gain itself (sqrt(2) or 1.0).
+    `demod_eps` (instead of `osc`): osc = rsqrt(sum (wscale w isc)^2 + eps), the StyleGAN2 demodulation
+    (model_spatial_query.py:300-304), evaluated and differentiated inside the same autograd node.
     `wscale` is the equalised-lr constant: the parameter is consumed as stored, its gradient comes back scaled."""
+    if demod_eps is not None and (osc is not None or isc is None or isc.shape[0] > 64 or w.shape[1] > 8192):
+        if osc is not None or isc is None:
+            raise RuntimeError('modconv: demod_eps needs isc and excludes an explicit osc')
+        from .style import demod as _demod
+        osc, demod_eps = _demod(w, isc, float(wscale), demod_eps), None      # shapes the demod kernels do not cover
     if _STATE['second_order'] and torch.is_grad_enabled():
+        if demod_eps is not None:
+            from .style import demod as _demod
+            osc = _demod(w, isc, float(wscale), demod_eps)
         return _composite(x, w, isc, osc, bias, act, kind, float(wscale))
     isc = isc.contiguous() if isc is not None else None
     osc = osc.contiguous() if osc is not None else None
-    return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale))
+    return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
