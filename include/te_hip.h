@@ -97,6 +97,9 @@ int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
                              int ksize, te_stream_t stream);
+/* two layouts of the same weight in one launch (a training forward packs the data-gradient layout along) */
+int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, int kind_b, const float* w, float wscale, int Co, int Ci,
+                              int ksize, te_stream_t stream);
 
 /* `H`,`W` are ALWAYS the low-resolution size (the H,W of the table above).  isc [B,K], osc [B,M],
  * bias [M] may be NULL.  act: 0 linear, 3 lrelu(0.2)*sqrt(2), 4 lrelu(0.2) with gain 1 (a residual branch that folds the

@@ -27,6 +27,7 @@ _SIGNATURES = {
                                    _P, _L, _I, _F, _F, _P]),
     'te_conv_packed_numel': (C.c_int64, [_I, _I, _I, _I]),
     'te_conv_pack_weights_f32': (C.c_int, [_P, _P, _F, _I, _I, _I, _I, _P]),
+    'te_conv_pack_weights2_f32': (C.c_int, [_P, _I, _P, _I, _P, _F, _I, _I, _I, _P]),
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -159,6 +160,17 @@ def conv_pack(w, kind_pack, wscale=1.0):
     return wp
 
 
+def conv_pack2(w, kind_a, kind_b, wscale=1.0):
+    """both packed layouts of w in one launch -> (wp_a, wp_b)"""
+    w = w.contiguous()
+    Co, Ci, ks, _ = w.shape
+    wa = torch.empty(lib().te_conv_packed_numel(kind_a, Co, Ci, ks), device=w.device, dtype=w.dtype)
+    wb = torch.empty(lib().te_conv_packed_numel(kind_b, Co, Ci, ks), device=w.device, dtype=w.dtype)
+    _check(lib().te_conv_pack_weights2_f32(_ptr(wa), kind_a, _ptr(wb), kind_b, _ptr(w), wscale, Co, Ci, ks, _stream()),
+           'te_conv_pack_weights2_f32')
+    return wa, wb
+
+
 def conv_out_shape(kind, B, M, H, W):
     if kind == CONV_T2:
         return (B, M, 2 * H + 1, 2 * W + 1)
@@ -191,8 +203,14 @@ def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc
     B, S, Co, Ci, taps = slabs.shape
     dev, dt = slabs.device, slabs.dtype
     gw = torch.empty(Co, Ci, taps, device=dev, dtype=dt) if want_w else None
-    gisc = torch.zeros(B, Ci, device=dev, dtype=dt) if want_isc else None
-    gosc = torch.zeros(B, Co, device=dev, dtype=dt) if want_osc else None
+    gisc = gosc = None
+    if want_isc and want_osc:           # one zero fill for both accumulators
+        z = torch.zeros(B * (Ci + Co), device=dev, dtype=dt)
+        gisc, gosc = z[:B * Ci].view(B, Ci), z[B * Ci:].view(B, Co)
+    elif want_isc:
+        gisc = torch.zeros(B, Ci, device=dev, dtype=dt)
+    elif want_osc:
+        gosc = torch.zeros(B, Co, device=dev, dtype=dt)
     _check(lib().te_wgrad_reduce_f32(_ptr(gw), _ptr(gisc), _ptr(gosc), _ptr(slabs), _ptr(w.contiguous()), wscale,
                                      _ptr(isc), _ptr(osc), B, S, Co, Ci, taps, _stream()), 'te_wgrad_reduce_f32')
     return gw, gisc, gosc

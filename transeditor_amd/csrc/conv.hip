@@ -374,6 +374,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(float* __restrict__ w
     }
 }
 
+// forward and data-gradient layouts of the same weight in one launch (the backward of a layer needs the second one)
+__global__ __launch_bounds__(256) void pack_weights2_kernel(float* __restrict__ wpa, float* __restrict__ wpb,
+                                                            const float* __restrict__ w, float wscale, int kinda, int kindb,
+                                                            int Ci, int ntap, int Ka, int Ma, int Kpa, int Mpa, int Kb, int Mb,
+                                                            int Kpb, int Mpb) {
+    const int64_t ta = (int64_t)ntap * Kpa * Mpa, total = ta + (int64_t)ntap * Kpb * Mpb;
+    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += (int64_t)gridDim.x * 256) {
+        const bool second = e0 >= ta;
+        const int64_t e = second ? e0 - ta : e0;
+        const int kind = second ? kindb : kinda, K = second ? Kb : Ka, M = second ? Mb : Ma, Kp = second ? Kpb : Kpa,
+                  Mp = second ? Mpb : Mpa;
+        const int m = (int)(e % Mp);
+        const int k = (int)((e / Mp) % Kp);
+        const int tap = (int)(e / ((int64_t)Mp * Kp));
+        float v = 0.f;
+        if (m < M && k < K) {
+            if (kind == TE_PACK_FWD) v = w[((size_t)m * Ci + k) * ntap + tap];
+            else if (kind == TE_PACK_DGRAD) v = w[((size_t)k * Ci + m) * ntap + (ntap - 1 - tap)];
+            else v = w[((size_t)k * Ci + m) * ntap + tap];
+        }
+        (second ? wpb : wpa)[e] = v * wscale;
+    }
+}
+
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int pow2ceil(int v) { return 1 << ilog2(v); }
 inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
@@ -510,6 +534,19 @@ extern "C" int te_conv_pack_weights_f32(float* wp, const float* w, float wscale,
     const int grid = (int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8);
     pack_weights_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(wp, w, wscale, kind_pack, Co, Ci, d.ntap, d.K, d.M, d.Kp, d.Mp);
     return te::launch_status("te_conv_pack_weights_f32");
+}
+
+extern "C" int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, int kind_b, const float* w, float wscale, int Co,
+                                         int Ci, int ksize, te_stream_t stream_) {
+    TE_REQUIRE(wp_a && wp_b && w, TE_ERR_NULL, "te_conv_pack_weights2_f32: NULL pointer");
+    TE_REQUIRE(Co > 0 && Ci > 0 && (ksize == 1 || ksize == 3), TE_ERR_SHAPE, "te_conv_pack_weights2_f32: bad dims");
+    TE_REQUIRE(kind_a >= 0 && kind_a <= 2 && kind_b >= 0 && kind_b <= 2, TE_ERR_UNSUPPORTED, "te_conv_pack_weights2_f32: bad kind");
+    const PackDims a = pack_dims(kind_a, Co, Ci, ksize), b = pack_dims(kind_b, Co, Ci, ksize);
+    const int64_t total = (int64_t)a.ntap * a.Kp * a.Mp + (int64_t)b.ntap * b.Kp * b.Mp;
+    const int grid = (int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8);
+    pack_weights2_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(wp_a, wp_b, w, wscale, kind_a, kind_b, Ci, a.ntap, a.K, a.M, a.Kp,
+                                                                a.Mp, b.K, b.M, b.Kp, b.Mp);
+    return te::launch_status("te_conv_pack_weights2_f32");
 }
 
 extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,

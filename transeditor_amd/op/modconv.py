@@ -94,20 +94,30 @@ def _lowres_hw(kind, is_output, t):
     return H, W
 
 
-def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0):
+def _bwd_pack_kind(kind):
+    return _lib.PACK_SWAP if kind in ('up', 'down') else _lib.PACK_DGRAD
+
+
+def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0, with_bwd_pack=False):
+    """with_bwd_pack: also return the data-gradient packing of w (one launch packs both layouts)."""
     H, W = _lowres_hw(kind, False, x)
+    if with_bwd_pack:
+        wp, wpb = _lib.conv_pack2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
+        return _lib.conv(x, wp, _KIND[kind], w.shape[0], H, W, isc, osc, bias, act), wpb
     return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, wscale), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
 
 
-def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0):
+def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
     """data gradient: g is shaped like the conv OUTPUT; returns a tensor shaped like the conv input.
-    isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci])."""
+    isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci]).  wp: w already packed for it."""
     H, W = _lowres_hw(kind, True, g)
+    if wp is None:
+        wp = _lib.conv_pack(w, _bwd_pack_kind(kind), wscale)
     if kind == 'up':       # adjoint of the transposed conv = strided conv
-        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP, wscale), _lib.CONV_S2, w.shape[1], H, W, isc, osc)
+        return _lib.conv(g, wp, _lib.CONV_S2, w.shape[1], H, W, isc, osc)
     if kind == 'down':     # adjoint of the strided conv = transposed conv
-        return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_SWAP, wscale), _lib.CONV_T2, w.shape[1], H, W, isc, osc)
-    return _lib.conv(g, _lib.conv_pack(w, _lib.PACK_DGRAD, wscale), _KIND[kind], w.shape[1], H, W, isc, osc)
+        return _lib.conv(g, wp, _lib.CONV_T2, w.shape[1], H, W, isc, osc)
+    return _lib.conv(g, wp, _KIND[kind], w.shape[1], H, W, isc, osc)
 
 
 def _wgrad_raw(g, x, kind):
@@ -211,7 +221,11 @@ class _ModConvFused(Function):
             ctx.save_for_backward(x, w, isc, osc, bias, None)
             ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
             return out
-        out = _fwd_raw(x, w, kind, isc, osc, bias, _act_code(act), wscale)
+        ctx.wp_bwd = None
+        if ctx.needs_input_grad[0]:         # a backward will want dx: pack the data-gradient layout in the same launch
+            out, ctx.wp_bwd = _fwd_raw(x, w, kind, isc, osc, bias, _act_code(act), wscale, with_bwd_pack=True)
+        else:
+            out = _fwd_raw(x, w, kind, isc, osc, bias, _act_code(act), wscale)
         ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
         ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
         return out
@@ -248,7 +262,7 @@ class _ModConvFused(Function):
         if ctx.rgb:
             gx = _lib.rgb_dgrad(g, w.reshape(w.shape[0], w.shape[1]), isc, x.shape[1], wscale) if need[0] else None
         else:
-            gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc, wscale=wscale) if need[0] else None
+            gx = _dgrad_raw(g, w, kind, isc=osc, osc=isc, wscale=wscale, wp=ctx.wp_bwd) if need[0] else None
         gw = gisc = gosc = None
         if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
             slabs = _lib.rgb_wgrad_slabs(g, x) if ctx.rgb else _wgrad_raw(g, x, kind)
