@@ -181,6 +181,13 @@ int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, cons
                       float* arowsum, float rs_scale, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
                       int64_t sbj, float alpha, float beta, int act, te_stream_t stream);
 
+/* A2  parameter-free layer norm over whole samples (reference: AttentionBlock.forward, model_spatial_query.py:924 / 931,
+ * F.layer_norm(x, x.size()[1:]), eps 1e-5): x / y / g / gx are [R, N] rows; stats [R, 2] = (mean, rstd) saved for the
+ * backward  gx = rstd * (g - mean(g) - y * mean(g * y)).  N % 4 == 0, N <= 16384, 16-byte aligned rows. */
+int te_layer_norm_supported(int64_t R, int N);
+int te_layer_norm_fwd_f32(float* y, float* stats, const float* x, int64_t R, int N, float eps, te_stream_t stream);
+int te_layer_norm_bwd_f32(float* gx, const float* g, const float* y, const float* stats, int64_t R, int N, te_stream_t stream);
+
 /* G2  the token-wise mapping loops (reference: Generator.forward, model_spatial_query.py:626-646 — for each of the 16
  * tokens its own EqualLinear + fused leaky-ReLU, 64 launches + 32 slice copies) as ONE launch: the same kernel batched
  * over blockIdx.z.  Operand z uses a + z*za, c + z*zc (uniform element strides) and either b + z*zb / bias + z*zbias or,

@@ -449,3 +449,26 @@ def test_token_mlp_batched_launch(B, D, Cn, T):
     a_, = torch.autograd.grad(gx.square().sum(), ws[0])
     b_, = torch.autograd.grad(gx_ref.square().sum(), ws[0])
     assert rel_err(a_, b_) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ A2 sample-wise layer norm
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(16, 16, 512), (16, 16, 528), (3, 5, 12), (2, 4, 4096)])
+def test_sample_layer_norm_kernels(shape):
+    """F.layer_norm(x, x.size()[1:]) of the attention blocks (model_spatial_query.py:924/931): forward, backward and the
+    recorded backward against torch (fp64 for the first-order quantities)."""
+    from transeditor_amd.op.layernorm import sample_layer_norm
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 2 + 0.3).cuda().requires_grad_(True)
+    gy = torch.randn(*shape, generator=g).cuda()
+    y = sample_layer_norm(x)
+    ref = F.layer_norm(x.double(), shape[1:], eps=1e-5)
+    assert rel_err(y, ref.float()) < 1e-5
+    gx, = torch.autograd.grad(y, x, gy)
+    gx_ref, = torch.autograd.grad(ref, x, gy.double())
+    assert rel_err(gx, gx_ref.float()) < 2e-5
+    a_, = torch.autograd.grad(sample_layer_norm(x), x, gy, create_graph=True)
+    b_, = torch.autograd.grad(F.layer_norm(x, shape[1:], eps=1e-5), x, gy, create_graph=True)
+    ga, = torch.autograd.grad(a_.square().sum(), x)
+    gb, = torch.autograd.grad(b_.square().sum(), x)
+    assert rel_err(ga, gb) < 1e-4

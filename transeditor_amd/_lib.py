@@ -42,6 +42,9 @@ _SIGNATURES = {
     'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
     'te_small_gemm_batched_f32': (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L,
                                              _F, _F, _I, _P]),
+    'te_layer_norm_supported': (C.c_int, [_L, _I]),
+    'te_layer_norm_fwd_f32': (C.c_int, [_P, _P, _P, _L, _I, _F, _P]),
+    'te_layer_norm_bwd_f32': (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
     'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
@@ -279,6 +282,26 @@ def small_gemm_batched(c, a, b, bias, nz, za, zc, I, J, K, sai, sak, sbk, sbj, s
                                            nz, za, zc, zb, zbias, bt, bit, I, J, K, sai, sak, sbk, sbj, sci, scj, alpha, beta,
                                            act, _stream()), 'te_small_gemm_batched_f32')
     return c
+
+
+def layer_norm_supported(R, N):
+    return bool(lib().te_layer_norm_supported(R, N))
+
+
+def layer_norm_fwd(x2, eps):
+    """x2 [R, N] contiguous -> (y [R, N], stats [R, 2])"""
+    R, N = x2.shape
+    y = torch.empty_like(x2)
+    stats = torch.empty(R, 2, device=x2.device, dtype=x2.dtype)
+    _check(lib().te_layer_norm_fwd_f32(_ptr(y), _ptr(stats), _ptr(x2), R, N, eps, _stream()), 'te_layer_norm_fwd_f32')
+    return y, stats
+
+
+def layer_norm_bwd(g2, y2, stats):
+    R, N = y2.shape
+    gx = torch.empty_like(y2)
+    _check(lib().te_layer_norm_bwd_f32(_ptr(gx), _ptr(g2), _ptr(y2), _ptr(stats), R, N, _stream()), 'te_layer_norm_bwd_f32')
+    return gx
 
 
 # --------------------------------------------------------------------------------------------- M1

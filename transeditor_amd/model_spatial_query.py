@@ -27,6 +27,7 @@ from torch.nn import functional as F
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
+from .op.layernorm import sample_layer_norm
 from .op.linear import linear_fused
 from .op.modconv import modconv
 from .op.style import demod
@@ -563,8 +564,8 @@ class AttentionBlock(nn.Module):                                                
 
     def forward(self, x, op_param, return_similarity=False):
         skip = self.proj(x) if self.out_dim != self.in_dim else x
-        a = self.atten(F.layer_norm(x, x.size()[1:]), op_param, return_similarity=return_similarity, residual=skip)
+        a = self.atten(sample_layer_norm(x), op_param, return_similarity=return_similarity, residual=skip)
         x, similarity = a if return_similarity else (a, None)           # x = skip + attention (:926-930)
-        h = self.mlp[0](F.layer_norm(x, x.size()[1:]), act='gelu')      # Linear + GELU, then Linear + skip (:932-934)
+        h = self.mlp[0](sample_layer_norm(x), act='gelu')      # Linear + GELU, then Linear + skip (:932-934)
         x = self.mlp[2](h, residual=x)
         return (x, similarity) if return_similarity else x
