@@ -188,6 +188,13 @@ int te_layer_norm_supported(int64_t R, int N);
 int te_layer_norm_fwd_f32(float* y, float* stats, const float* x, int64_t R, int N, float eps, te_stream_t stream);
 int te_layer_norm_bwd_f32(float* gx, const float* g, const float* y, const float* stats, int64_t R, int N, te_stream_t stream);
 
+/* G1  PixelNorm over the channel axis of the [B, D, C] latent codes (reference: PixelNorm.forward, model_spatial_query.py:
+ * 80-81, pixel_norm_op_dim = 1): y = x * rsqrt(mean_d x^2 + eps); r [B, C] = the factor, saved for the backward
+ * gx = r * (g - y * mean_d(g * y)).  C must divide 256. */
+int te_pixel_norm_supported(int64_t B, int D, int C);
+int te_pixel_norm_fwd_f32(float* y, float* r, const float* x, int64_t B, int D, int C, float eps, te_stream_t stream);
+int te_pixel_norm_bwd_f32(float* gx, const float* g, const float* y, const float* r, int64_t B, int D, int C, te_stream_t stream);
+
 /* G2  the token-wise mapping loops (reference: Generator.forward, model_spatial_query.py:626-646 — for each of the 16
  * tokens its own EqualLinear + fused leaky-ReLU, 64 launches + 32 slice copies) as ONE launch: the same kernel batched
  * over blockIdx.z.  Operand z uses a + z*za, c + z*zc (uniform element strides) and either b + z*zb / bias + z*zbias or,

@@ -472,3 +472,22 @@ def test_sample_layer_norm_kernels(shape):
     ga, = torch.autograd.grad(a_.square().sum(), x)
     gb, = torch.autograd.grad(b_.square().sum(), x)
     assert rel_err(ga, gb) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,dim', [((16, 512, 16), 1), ((3, 40, 8), 1), ((4, 512, 16), 2), ((2, 7, 5), 1)])
+def test_pixel_norm_kernels(shape, dim):
+    """PixelNorm (model_spatial_query.py:80-81): kernel path for [B, D, C] / dim 1, torch expression otherwise."""
+    from transeditor_amd.op.layernorm import _pixel_norm_expr, pixel_norm
+    g = torch.Generator().manual_seed(sum(shape) + dim)
+    x = torch.randn(*shape, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(*shape, generator=g).cuda()
+    y = pixel_norm(x, dim)
+    ref = _pixel_norm_expr(x.double(), dim)
+    assert rel_err(y, ref.float()) < 1e-5
+    gx, = torch.autograd.grad(y, x, gy)
+    gx_ref, = torch.autograd.grad(ref, x, gy.double())
+    assert rel_err(gx, gx_ref.float()) < 2e-5
+    a_, = torch.autograd.grad(pixel_norm(x, dim), x, gy, create_graph=True)
+    b_, = torch.autograd.grad(_pixel_norm_expr(x, dim), x, gy, create_graph=True)
+    assert rel_err(torch.autograd.grad(a_.square().sum(), x)[0], torch.autograd.grad(b_.square().sum(), x)[0]) < 1e-4

@@ -45,6 +45,9 @@ _SIGNATURES = {
     'te_layer_norm_supported': (C.c_int, [_L, _I]),
     'te_layer_norm_fwd_f32': (C.c_int, [_P, _P, _P, _L, _I, _F, _P]),
     'te_layer_norm_bwd_f32': (C.c_int, [_P, _P, _P, _P, _L, _I, _P]),
+    'te_pixel_norm_supported': (C.c_int, [_L, _I, _I]),
+    'te_pixel_norm_fwd_f32': (C.c_int, [_P, _P, _P, _L, _I, _I, _F, _P]),
+    'te_pixel_norm_bwd_f32': (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P]),
     'te_demod_fwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
@@ -301,6 +304,26 @@ def layer_norm_bwd(g2, y2, stats):
     R, N = y2.shape
     gx = torch.empty_like(y2)
     _check(lib().te_layer_norm_bwd_f32(_ptr(gx), _ptr(g2), _ptr(y2), _ptr(stats), R, N, _stream()), 'te_layer_norm_bwd_f32')
+    return gx
+
+
+def pixel_norm_supported(B, D, Cn):
+    return bool(lib().te_pixel_norm_supported(B, D, Cn))
+
+
+def pixel_norm_fwd(x, eps):
+    """x [B, D, C] contiguous -> (y, r [B, C])"""
+    B, D, Cn = x.shape
+    y = torch.empty_like(x)
+    r = torch.empty(B, Cn, device=x.device, dtype=x.dtype)
+    _check(lib().te_pixel_norm_fwd_f32(_ptr(y), _ptr(r), _ptr(x), B, D, Cn, eps, _stream()), 'te_pixel_norm_fwd_f32')
+    return y, r
+
+
+def pixel_norm_bwd(g, y, r):
+    B, D, Cn = y.shape
+    gx = torch.empty_like(y)
+    _check(lib().te_pixel_norm_bwd_f32(_ptr(gx), _ptr(g), _ptr(y), _ptr(r), B, D, Cn, _stream()), 'te_pixel_norm_bwd_f32')
     return gx
 
 

@@ -112,3 +112,76 @@ extern "C" int te_layer_norm_bwd_f32(float* gx, const float* g, const float* y, 
     layer_norm_bwd_kernel<<<(unsigned)R, LN_THREADS, 0, (hipStream_t)stream_>>>(gx, g, y, stats, N);
     return te::launch_status("te_layer_norm_bwd_f32");
 }
+
+// G1: PixelNorm over the channel axis of the [B, D, C] latent codes (reference: PixelNorm.forward,
+// model_spatial_query.py:80-81 with pixel_norm_op_dim = 1):  y[b,d,c] = x[b,d,c] * rsqrt(mean_d x[b,d,c]^2 + 1e-8).
+// One block per sample; thread (group = tid / C, c = tid % C) strides over d, C must divide 256.
+//   backward: gx = r * (g - y * mean_d(g * y)),  r[b,c] saved by the forward
+namespace {
+
+__global__ __launch_bounds__(256) void pixel_norm_fwd_kernel(float* __restrict__ y, float* __restrict__ r,
+                                                             const float* __restrict__ x, int D, int C, float eps) {
+    __shared__ float part[256];
+    __shared__ float rs[256];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid % C, grp = tid / C, ng = 256 / C;
+    const float* xb = x + (size_t)b * D * C;
+    float s = 0.f;
+    for (int d = grp; d < D; d += ng) { const float v = xb[d * C + c]; s += v * v; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int gI = 0; gI < ng; ++gI) t += part[gI * C + tid];
+        const float rv = rsqrtf(t / (float)D + eps);
+        rs[tid] = rv;
+        r[(size_t)b * C + tid] = rv;
+    }
+    __syncthreads();
+    const float rv = rs[c];
+    float* yb = y + (size_t)b * D * C;
+    for (int d = grp; d < D; d += ng) yb[d * C + c] = xb[d * C + c] * rv;
+}
+
+__global__ __launch_bounds__(256) void pixel_norm_bwd_kernel(float* __restrict__ gx, const float* __restrict__ g,
+                                                             const float* __restrict__ y, const float* __restrict__ r, int D,
+                                                             int C) {
+    __shared__ float part[256];
+    __shared__ float ms[256];
+    const int b = blockIdx.x, tid = threadIdx.x, c = tid % C, grp = tid / C, ng = 256 / C;
+    const float* gb = g + (size_t)b * D * C;
+    const float* yb = y + (size_t)b * D * C;
+    float s = 0.f;
+    for (int d = grp; d < D; d += ng) s += gb[d * C + c] * yb[d * C + c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+        for (int gI = 0; gI < ng; ++gI) t += part[gI * C + tid];
+        ms[tid] = t / (float)D;
+    }
+    __syncthreads();
+    const float m = ms[c], rv = r[(size_t)b * C + c];
+    float* ob = gx + (size_t)b * D * C;
+    for (int d = grp; d < D; d += ng) ob[d * C + c] = rv * (gb[d * C + c] - yb[d * C + c] * m);
+}
+
+inline bool pn_ok(int64_t B, int D, int C) { return B > 0 && B <= 0x7FFFFFFF && D > 0 && C > 0 && C <= 256 && 256 % C == 0; }
+
+}  // namespace
+
+extern "C" int te_pixel_norm_supported(int64_t B, int D, int C) { return pn_ok(B, D, C) ? 1 : 0; }
+
+extern "C" int te_pixel_norm_fwd_f32(float* y, float* r, const float* x, int64_t B, int D, int C, float eps, te_stream_t stream_) {
+    TE_REQUIRE(y && r && x, TE_ERR_NULL, "te_pixel_norm_fwd_f32: NULL pointer");
+    TE_REQUIRE(pn_ok(B, D, C), TE_ERR_UNSUPPORTED, "te_pixel_norm_fwd_f32: C must divide 256");
+    pixel_norm_fwd_kernel<<<(unsigned)B, 256, 0, (hipStream_t)stream_>>>(y, r, x, D, C, eps);
+    return te::launch_status("te_pixel_norm_fwd_f32");
+}
+
+extern "C" int te_pixel_norm_bwd_f32(float* gx, const float* g, const float* y, const float* r, int64_t B, int D, int C,
+                                     te_stream_t stream_) {
+    TE_REQUIRE(gx && g && y && r, TE_ERR_NULL, "te_pixel_norm_bwd_f32: NULL pointer");
+    TE_REQUIRE(pn_ok(B, D, C), TE_ERR_UNSUPPORTED, "te_pixel_norm_bwd_f32: C must divide 256");
+    pixel_norm_bwd_kernel<<<(unsigned)B, 256, 0, (hipStream_t)stream_>>>(gx, g, y, r, D, C);
+    return te::launch_status("te_pixel_norm_bwd_f32");
+}

@@ -27,7 +27,7 @@ from torch.nn import functional as F
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
-from .op.layernorm import sample_layer_norm
+from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused
 from .op.modconv import modconv
 from .op.style import demod
@@ -43,7 +43,7 @@ class PixelNorm(nn.Module):
         self.pixel_norm_op_dim = pixel_norm_op_dim
 
     def forward(self, input):                                                        # :80-81
-        return input * torch.rsqrt(input.pow(2).mean(dim=self.pixel_norm_op_dim, keepdim=True) + 1e-8)
+        return pixel_norm(input, self.pixel_norm_op_dim)
 
 
 def make_kernel(k):                                                                  # :84-92

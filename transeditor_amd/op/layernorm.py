@@ -39,3 +39,35 @@ def sample_layer_norm(x):
             raise RuntimeError('te_hip: expected an fp32 tensor on the GPU (no CPU path exists)')
         return F.layer_norm(x, x.shape[1:], eps=EPS)
     return _SampleLayerNorm.apply(x)
+
+
+def _pixel_norm_expr(x, dim):
+    return x * torch.rsqrt(x.pow(2).mean(dim=dim, keepdim=True) + 1e-8)
+
+
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        y, r = _lib.pixel_norm_fwd(xc, 1e-8)
+        ctx.save_for_backward(x, y, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, r = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            with torch.enable_grad():
+                xa = x.view_as(x)
+                gx, = torch.autograd.grad(_pixel_norm_expr(xa, 1), xa, g, create_graph=True)
+            return gx
+        return _lib.pixel_norm_bwd(g.contiguous(), y, r)
+
+
+def pixel_norm(x, dim):
+    """PixelNorm.forward (model_spatial_query.py:80-81); the kernel covers the configuration every script uses
+    (3-D codes [B, D, C], dim = 1), anything else is the torch expression."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and dim == 1
+            and _lib.pixel_norm_supported(x.shape[0], x.shape[1], x.shape[2])):
+        return _PixelNorm.apply(x)
+    return _pixel_norm_expr(x, dim)
