@@ -59,6 +59,21 @@ def test_product_path_fails_loudly_on_cpu(libpath):
         upfirdn2d(torch.randn(1, 1, 8, 8), torch.ones(4, 4) / 16, pad=(1, 1))
     with pytest.raises(RuntimeError, match='GPU'):
         modconv(torch.randn(1, 8, 4, 4), torch.randn(8, 8, 3, 3))
+    # the dense / normalisation ops of the mapping and attention stack have no CPU route either
+    from transeditor_amd.op.layernorm import pixel_norm, sample_layer_norm
+    from transeditor_amd.op.linear import linear_fused
+    from transeditor_amd.op.style import demod
+    from transeditor_amd.op.token_mlp import token_mlp
+    with pytest.raises(RuntimeError, match='GPU'):
+        linear_fused(torch.randn(4, 8), torch.randn(6, 8), torch.zeros(6))
+    with pytest.raises(RuntimeError, match='GPU'):
+        sample_layer_norm(torch.randn(2, 4, 8))
+    with pytest.raises(RuntimeError, match='GPU'):
+        pixel_norm(torch.randn(2, 8, 4), 1)
+    with pytest.raises(RuntimeError, match='GPU'):
+        token_mlp(torch.randn(2, 8, 4), [torch.randn(8, 8)] * 4, [torch.zeros(8)] * 4, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match='GPU'):
+        demod(torch.randn(8, 8, 3, 3), torch.randn(2, 8), 1.0)
 
 
 def test_product_does_not_import_oracle():

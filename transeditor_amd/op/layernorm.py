@@ -67,7 +67,9 @@ class _PixelNorm(Function):
 def pixel_norm(x, dim):
     """PixelNorm.forward (model_spatial_query.py:80-81); the kernel covers the configuration every script uses
     (3-D codes [B, D, C], dim = 1), anything else is the torch expression."""
-    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and dim == 1
+    if not x.is_cuda:
+        raise RuntimeError('te_hip: expected an fp32 tensor on the GPU (no CPU path exists)')
+    if (x.dtype == torch.float32 and x.dim() == 3 and dim == 1
             and _lib.pixel_norm_supported(x.shape[0], x.shape[1], x.shape[2])):
         return _PixelNorm.apply(x)
     return _pixel_norm_expr(x, dim)
