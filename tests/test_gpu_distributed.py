@@ -1,0 +1,97 @@
+"""Data-parallel generator step with two processes on ONE GPU (gloo carries the collectives, since RCCL refuses two
+ranks on one device): the hook-driven, bucketed gradient exchange of `GradSync` on device tensors, driven by the real
+HIP backward (its hooks fire on the autograd thread while kernels are in flight), against the single-process gradient of
+the global batch.  This is SURVEY §8(e)'s exchange step; the 8-GPU RCCL run itself belongs to the driver."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+SIZE, TOKEN, PER_RANK = 32, 8, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build():
+    from transeditor_amd import synth
+    from transeditor_amd.model_spatial_query import Generator
+    G = Generator(SIZE, 512, 512, TOKEN, n_trans=2, pixel_norm_op_dim=1)
+    sd = G.state_dict()
+    synth.fill_state_dict(sd, 77, 0.01)
+    G.load_state_dict(sd)
+    return G.cuda()
+
+
+def _loss(G, z, p, w, denom):
+    img = G(z, p)[0]
+    return (img * w).sum() / denom
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from transeditor_amd import synth
+    from transeditor_amd.utils import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        G = _build()
+        D.broadcast_module(G)
+        sync = D.GradSync(G, bucket_bytes=8 << 20)           # several buckets -> launches interleave with the backward
+        assert len(sync.buckets) > 2
+        z, p = synth.latents(world * PER_RANK, 5)
+        w = synth.normal((world * PER_RANK, 3, SIZE, SIZE), 'ddp.w', 3)
+        sl = slice(rank * PER_RANK, (rank + 1) * PER_RANK)
+        out = []
+        for step in range(2):                                 # step 0 learns the unused noise.weight set, step 1 overlaps
+            for prm in G.parameters():
+                prm.grad = None
+            _loss(G, z[sl].cuda(), p[sl].cuda(), w[sl].cuda(), PER_RANK).backward()
+            if step == 1:
+                assert any(wk is not None for wk in sync._work), 'no bucket was launched from the backward hooks'
+            sync.all_reduce()
+            out = {n: prm.grad.detach().cpu().numpy() for n, prm in G.named_parameters() if prm.grad is not None}
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_matches_global_batch():
+    from transeditor_amd import synth
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    # single process, global batch, mean over ranks of the per-rank losses == sum / (world * PER_RANK)
+    G = _build()
+    z, p = synth.latents(world * PER_RANK, 5)
+    w = synth.normal((world * PER_RANK, 3, SIZE, SIZE), 'ddp.w', 3)
+    _loss(G, z.cuda(), p.cuda(), w.cuda(), world * PER_RANK).backward()
+    ref = {n: prm.grad.detach().cpu().numpy() for n, prm in G.named_parameters() if prm.grad is not None}
+    assert set(ref) <= set(res[0]) and set(res[0]) == set(res[1])
+    import numpy as np
+    gmax = max(float(np.abs(r).max()) for r in ref.values())
+    for n, r in ref.items():
+        # gradients that are zero in exact arithmetic (the key bias: softmax is shift-invariant) are pure rounding noise
+        scale = max(float(np.abs(r).max()), 1e-4 * gmax)
+        assert float(np.abs(res[0][n] - res[1][n]).max()) == 0.0, n            # both ranks hold the same reduced tensor
+        assert float(np.abs(res[0][n] - r).max()) / scale < 2e-4, n
+    # parameters that never receive a gradient (noise.weight) come back as zeros on every rank
+    for n in set(res[0]) - set(ref):
+        assert float(np.abs(res[0][n]).max()) == 0.0, n
