@@ -162,3 +162,37 @@ def test_train_step_losses_match_oracle_on_cpu():
     assert torch.allclose(m1.weight, 0.9 * w1 + 0.1 * w2)
     args = T.default_args(size=64)
     assert args.token == 10 and args.d_reg_every == 16 and args.g_reg_every == 4
+
+
+def test_modconv_host_argument_logic():
+    """activation-gain codes and the demodulation argument contract are decided on the host, before any launch"""
+    from transeditor_amd.op import modconv as M
+    assert M._act_code(False) == 0 and M._act_code(True) == 3 and M._act_code(2 ** 0.5) == 3 and M._act_code(1.0) == 4
+    assert M._act_code(2 ** 0.5 * (1 / 2 ** 0.5)) == 4                       # ResBlock: sqrt(2) * 1/sqrt(2)
+    with pytest.raises(RuntimeError, match='gain'):
+        M._act_code(0.5)
+    x, w = torch.randn(1, 8, 4, 4), torch.randn(8, 8, 3, 3)
+    with pytest.raises(RuntimeError, match='demod_eps'):
+        M.modconv(x, w, isc=torch.ones(1, 8), osc=torch.ones(1, 8), demod_eps=1e-8)
+    with pytest.raises(RuntimeError, match='demod_eps'):
+        M.modconv(x, w, demod_eps=1e-8)                                       # demodulation without a style scale
+    assert M._bwd_pack_kind('up') == M._bwd_pack_kind('down') != M._bwd_pack_kind('3x3')
+    with M.second_order(), M.no_weight_grads():
+        assert M._STATE == {'second_order': True, 'skip_w': True}
+    assert M._STATE == {'second_order': False, 'skip_w': False}
+
+
+def test_upfirdn2d_geometry_matches_reference_formulas():
+    """output size and adjoint pads (utils/op/upfirdn2d.py:101-112) for the five configurations the model uses"""
+    from transeditor_amd.op.upfirdn2d import _geometry
+    # blur pad (1,1) on 257 -> 256, its adjoint pads (1,3): 256 -> 257
+    (oh, ow), g_pad = _geometry((257, 257), (4, 4), (1, 1), (1, 1), (1, 1, 1, 1))
+    assert (oh, ow) == (256, 256) and g_pad == (2, 2, 2, 2)
+    (oh, ow), _ = _geometry((256, 256), (4, 4), (1, 1), (1, 1), g_pad)
+    assert (oh, ow) == (257, 257)
+    # ToRGB skip upsample: up 2, pad (2,1): 128 -> 256; adjoint is down 2
+    (oh, ow), g_pad = _geometry((128, 128), (4, 4), (2, 2), (1, 1), (2, 1, 2, 1))
+    assert (oh, ow) == (256, 256) and g_pad == (1, 1, 1, 1)
+    # discriminator blur pad (2,2) before the stride-2 3x3: 256 -> 257; skip branch blur (1,1) with down 2: 256 -> 128
+    assert _geometry((256, 256), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2))[0] == (257, 257)
+    assert _geometry((256, 256), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1))[0] == (128, 128)
