@@ -1,19 +1,32 @@
-"""Benchmark of the TransEditor generator hot path on MI355X.
+"""Benchmark of the TransEditor hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 16 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic batch: FFHQ-256 generator forward + backward
-(BASELINE.json configs[1]: batch 16 per GPU, num_trans=8, fp32), latents already resident in HBM.  With
-N > 1 every rank runs its own batch (weak scaling, data parallel) and the step includes the gradient
-all-reduce over RCCL/xGMI (the only exchange step of the path).  Rank 0 prints ONE JSON line.
+Default workload = BASELINE.json's metric: the FFHQ-256 full G+D training iteration at batch 16 per GPU
+(configs[2] at N = 1, configs[3] at N > 1; reference train_spatial_query.py:166-294): D step, lazy R1 every 16
+iterations, G step, lazy path-length regulariser every 4 (double backward), Adam, EMA.  One "step" = one such
+iteration over one synthetic batch already resident in HBM.  The timed window starts at iteration index 0, so the
+lazy regularisers fire at i % 16 == 0 and i % 4 == 0 inside the K timed steps (K a multiple of 16 reproduces the
+cadence exactly; other K over-represent them, never under-represent).  With N > 1 every rank runs its own batch (weak
+scaling, data parallel) and every backward ends in the bucketed gradient all-reduce over RCCL/xGMI.  Rank 0 prints
+ONE JSON line.
 
-Extra objects in the JSON:
-  roofline      dominant kernel class (fp32-MFMA implicit-GEMM convolutions): ALGORITHMIC FLOPs of its launches
-                in the timed region / their summed duration, measured live with HIP events on the launch stream.
-  cpu_baseline  the CPU oracle (oracle/te_oracle.py, a port of the reference's algorithm) timed on this box's
-                host cores on a bounded sample (rank 0, N=1 only).
+Objects in the JSON beside the driver contract:
+  roofline      dominant kernel class = the fp32-MFMA implicit-GEMM convolutions (forward / data-gradient /
+                weight-gradient of every 3x3 kind, G and D): ALGORITHMIC FLOPs of those launches in the timed region /
+                their summed duration, measured live with HIP events on the launch stream; `whole_step_frac` prices
+                the SAME algorithmic FLOPs against the whole wall-clock step.
+  substeps      HIP-event time of each sub-step (D / R1 / G / path) and the cadence-weighted ms per iteration.
+  sub_benchmarks  (N = 1) configs[1] generator fwd+bwd at batch 16 and configs[4] FFHQ-1024 generator fwd+bwd at
+                batch 4, each with its own value and roofline.
+  cpu_baseline  (N = 1) the CPU oracle (oracle/te_oracle.py, a port of the reference's algorithm) running the same
+                training iteration on this box's host cores on a bounded sample.
+  comm          (N > 1) backend, bytes all-reduced per iteration, isolated per-bucket all-reduce time, the exposed
+                communication time (step with exchange - step without) and a bit-identity check of the averaged grads.
+
+`--workload generator` runs only configs[1] (or `--size 1024 --batch 4`: configs[4]) as the headline line.
 """
 import argparse
 import json
@@ -29,19 +42,22 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 (vector == fp32-MFMA), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+METRIC = '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling'
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--workload', choices=['generator', 'train'], default='generator',
-                    help='generator = BASELINE configs[1] (default, the driver contract); train = configs[2]/[3] full G+D step')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 16; 4 at --size 1024)')
+    ap.add_argument('--workload', choices=['train', 'generator'], default='train',
+                    help='train = BASELINE configs[2]/[3], the full G+D iteration (default, = the metric); '
+                         'generator = configs[1] / configs[4] generator fwd+bwd only')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-sub', action='store_true', help='skip the sub-benchmarks (configs[1], configs[4])')
     return ap.parse_args()
 
 
@@ -52,8 +68,12 @@ class KernelTimer:
     def __init__(self):
         self.records = []      # (class, flops, start, end)
         self.enabled = False
+        self.installed = False
 
     def install(self):
+        if self.installed:
+            return
+        self.installed = True
         from transeditor_amd import _lib
         timer = self
         orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
@@ -86,6 +106,9 @@ class KernelTimer:
 
         _lib.conv, _lib.wgrad_slabs = conv, wgrad
 
+    def reset(self):
+        self.records = []
+
     def summary(self):
         agg = {}
         for name, flops, s, e in self.records:
@@ -93,24 +116,184 @@ class KernelTimer:
             a[0] += 1
             a[1] += flops
             a[2] += s.elapsed_time(e) * 1e-3
-        return {k: {'launches': v[0], 'avg_ms': 1e3 * v[2] / v[0], 'tflops': v[1] / v[2] / 1e12, 'total_ms': 1e3 * v[2]}
+        return {k: {'launches': v[0], 'avg_ms': 1e3 * v[2] / v[0], 'tflops': v[1] / v[2] / 1e12, 'total_ms': 1e3 * v[2],
+                    'gflop': v[1] / 1e9}
                 for k, v in agg.items()}
 
+    def roofline(self, wall_s, steps):
+        """roofline object over the MFMA convolution launches recorded since reset()"""
+        ks = self.summary()
+        conv_keys = [k for k in ks if not k.endswith('1x1')]        # 1x1 (3 -> 128 stem of D, skip branches) are not 3x3 GEMMs
+        gflop = sum(ks[k]['gflop'] for k in conv_keys)
+        tms = sum(ks[k]['total_ms'] for k in conv_keys)
+        ach = gflop / tms if tms else 0.0                            # GFLOP / ms == TFLOP/s
+        traffic, note = _pmc_traffic()
+        return {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': note,
+                'kernel': 'conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2, all 3x3 kinds)',
+                'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
+                'algorithmic_gflop_per_step': gflop / steps,
+                'whole_step_tflops': gflop / 1e3 / wall_s if wall_s else None,
+                'whole_step_frac': gflop / 1e3 / wall_s / PEAK_FP32_TFLOPS if wall_s else None,
+                'per_kernel': ks}
 
-def cpu_baseline(size):
-    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 1, 1 warm-up + 10 timed iterations, ~12 s)."""
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_round.sh +
+    tools/pmc_summary.py; counters cannot be collected from inside this process).  Latest round's summary wins."""
+    try:
+        prof = os.path.join(ROOT, 'profiles')
+        cands = sorted(f for f in os.listdir(prof) if f.endswith('_pmc_summary.json'))
+        pm = json.load(open(os.path.join(prof, cands[-1])))
+        k3 = next(v for k, v in pm.items() if k.startswith('conv_mfma_kernel<0'))
+        traffic = (k3['hbm_read_mb'] + k3['hbm_write_mb']) * 1e6
+        note = (f"static, from profiles/{cands[-1]} (PMC pass of the 128->128 @256x256 batch-16 3x3 launch): FETCH_SIZE x2 "
+                f"(gfx950 correction) = {k3['hbm_read_mb']:.0f} MB read + WRITE_SIZE {k3['hbm_write_mb']:.0f} MB written vs "
+                f"{k3['algorithmic_mb']:.0f} MB algorithmic; MFMA utilisation {k3['mfma_util_pct']:.1f} % at {k3['mhz']:.0f} MHz")
+        return traffic, note
+    except Exception:
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_model():
+    try:
+        return next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except Exception:
+        return 'unknown'
+
+
+def _oracle_params(module_sd):
+    P = {}
+    for k, v in module_sd.items():
+        v = v.detach().cpu()
+        trainable = (v.is_floating_point() and 'noises' not in k and 'kernel' not in k and not k.startswith('token'))
+        P[k] = v.clone().requires_grad_(True) if trainable else v
+    return P, [v for v in P.values() if v.requires_grad]
+
+
+def _pick_threads(O, Pg, size):
+    """Thread count for the CPU legs: the fastest of a short sweep on one batch-2 generator forward (all hardware threads
+    oversubscribe the small CPU convolutions badly: 187 s/iter measured in round 1 with 256)."""
+    from transeditor_amd import synth
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cands = sorted({t for t in (16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 32)})
+    z, p = synth.latents(2, 77)
+    best, sweep = None, {}
+    for t in cands:
+        torch.set_num_threads(t)
+        with torch.no_grad():
+            O.generator_forward(Pg, z[:1], p[:1], size)                 # touch
+            t0 = time.perf_counter()
+            O.generator_forward(Pg, z, p, size)
+            dt = time.perf_counter() - t0
+        sweep[t] = round(dt, 3)
+        if best is None or dt < sweep[best]:
+            best = t
+    torch.set_num_threads(best)
+    return best, sweep, ncpu
+
+
+def cpu_baseline_train(size):
+    """The reference's training iteration (train_spatial_query.py:166-294) through the CPU oracle on a bounded sample:
+    batch 2, every sub-step once (D, R1, G, path length on batch 1), Adam included; the iteration time is composed with
+    the lazy-regulariser cadence exactly as the GPU line is:  t = t_D + t_G + t_R1 / 16 + t_path / 4."""
+    from oracle import te_oracle as O
+    from transeditor_amd import synth
+    from transeditor_amd.model_spatial_query import Discriminator, Generator
+    token = 2 * (int(math.log2(size)) - 1)
+    torch.manual_seed(5)
+    Pg, g_leaves = _oracle_params(Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).state_dict())
+    Pd, d_leaves = _oracle_params(Discriminator(size).state_dict())
+    threads, sweep, ncpu = _pick_threads(O, Pg, size)
+    B = 2
+    g_opt = torch.optim.Adam(g_leaves, lr=0.002 * 0.8, betas=(0.0, 0.99 ** 0.8))
+    d_opt = torch.optim.Adam(d_leaves, lr=0.002 * 16 / 17, betas=(0.0, 0.99 ** (16 / 17)))
+    real = torch.randn(B, 3, size, size).clamp(-1, 1)
+    t = {}
+
+    def timed(name, fn):
+        t0 = time.perf_counter()
+        fn()
+        t[name] = time.perf_counter() - t0
+
+    def d_step():
+        z, p = synth.latents(B, 900)
+        with torch.no_grad():
+            fake = O.generator_forward(Pg, z, p, size)[0]
+        loss = O.d_logistic_loss(O.discriminator_forward(Pd, real, size), O.discriminator_forward(Pd, fake, size))
+        d_opt.zero_grad()
+        for v, g in zip(d_leaves, torch.autograd.grad(loss, d_leaves)):
+            v.grad = g
+        d_opt.step()
+
+    def r1_step():
+        r = real.clone().requires_grad_(True)
+        pred = O.discriminator_forward(Pd, r, size)
+        loss = 10.0 / 2 * O.d_r1_loss(pred, r) * 16 + 0 * pred[0]
+        d_opt.zero_grad()
+        for v, g in zip(d_leaves, torch.autograd.grad(loss.sum(), d_leaves, allow_unused=True)):
+            v.grad = g
+        d_opt.step()
+
+    def g_step():
+        z, p = synth.latents(B, 901)
+        fake = O.generator_forward(Pg, z, p, size)[0]
+        for v in d_leaves:
+            v.requires_grad_(False)
+        loss = O.g_nonsaturating_loss(O.discriminator_forward(Pd, fake, size))
+        g_opt.zero_grad()
+        for v, g in zip(g_leaves, torch.autograd.grad(loss, g_leaves, allow_unused=True)):
+            v.grad = g
+        for v in d_leaves:
+            v.requires_grad_(True)
+        g_opt.step()
+
+    def path_step():
+        n = max(1, B // 2)
+        z, p = synth.latents(n, 902)
+        img, lat, _ = O.generator_forward(Pg, z, p, size)
+        noise = torch.randn_like(img) / math.sqrt(size * size)
+        pen, _, _ = O.g_path_regularize(img, lat, 0.0, noise)
+        g_opt.zero_grad()
+        for v, g in zip(g_leaves, torch.autograd.grad(2.0 * 4 * pen + 0 * img[0, 0, 0, 0], g_leaves, allow_unused=True)):
+            v.grad = g
+        g_opt.step()
+
+    timed('d', d_step)
+    timed('r1', r1_step)
+    timed('g', g_step)
+    timed('path', path_step)
+    it = t['d'] + t['g'] + t['r1'] / 16 + t['path'] / 4
+    # per-image cost vs batch: generator forward at batch 2 (the sample) and batch 16 (the config)
+    with torch.no_grad():
+        z, p = synth.latents(16, 903)
+        t0 = time.perf_counter()
+        O.generator_forward(Pg, z[:2], p[:2], size)
+        f2 = (time.perf_counter() - t0) / 2
+        t0 = time.perf_counter()
+        O.generator_forward(Pg, z, p, size)
+        f16 = (time.perf_counter() - t0) / 16
+    return {'value': B / it, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'CPU oracle (PyTorch fp32 restatement of the reference) running ONE FFHQ-{size} G+D training iteration at '
+                      f'batch {B} (config batch is 16): D step {t["d"]:.2f} s, R1 step {t["r1"]:.2f} s, G step {t["g"]:.2f} s, '
+                      f'path-length step (batch 1) {t["path"]:.2f} s, Adam included; iteration = D + G + R1/16 + path/4 = '
+                      f'{it:.2f} s; no warm-up pass (first-touch cost included)',
+            'batch_scaling': {'generator_fwd_s_per_image_batch2': f2, 'generator_fwd_s_per_image_batch16': f16,
+                              'note': 'per-image cost at the config batch relative to the sampled batch'},
+            'thread_sweep_s_generator_fwd_batch2': sweep, 'usable_threads': ncpu,
+            'cpu_model': _cpu_model(), 'host_threads': os.cpu_count()}
+
+
+def cpu_baseline_generator(size):
+    """Oracle generator fwd+bwd on the host cores; bounded sample (batch 2, 1 warm-up + 4 timed iterations)."""
     from oracle import te_oracle as O
     from transeditor_amd import synth
     from transeditor_amd.model_spatial_query import Generator
-    # 256 hardware threads oversubscribe the small CPU convolutions badly (measured 187 s/iter); use a socket's
-    # worth of threads and say so in `cores`
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     token = 2 * (int(math.log2(size)) - 1)
-    sd = Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).state_dict()
-    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'noises' not in k and 'kernel' not in k
-             and not k.startswith('token') else v) for k, v in sd.items()}
-    leaves = [v for v in P.values() if v.requires_grad]
-    B, iters = 1, 10
+    P, leaves = _oracle_params(Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).state_dict())
+    threads, sweep, ncpu = _pick_threads(O, P, size)
+    B, iters = 2, 4
     times = []
     for it in range(iters + 1):
         z, p = synth.latents(B, 900 + it)
@@ -119,15 +302,142 @@ def cpu_baseline(size):
         torch.autograd.grad(img.sum(), leaves, allow_unused=True)
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / iters
-    model = 'unknown'
-    try:
-        model = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
-    except Exception:
-        pass
-    return {'value': B / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': B / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'CPU oracle (PyTorch fp32 restatement of the reference), generator fwd+bwd {size}x{size}, '
                       f'batch {B}, 1 warm-up + {iters} timed iterations, {dt:.2f} s/iter',
-            'cpu_model': model, 'host_threads': os.cpu_count()}
+            'thread_sweep_s_generator_fwd_batch2': sweep, 'usable_threads': ncpu,
+            'cpu_model': _cpu_model(), 'host_threads': os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------------ GPU legs
+def fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(elapsed, world, dev):
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def run_generator(size, B, steps, warmup, dev, world, rank, timer, G=None):
+    """configs[1] / configs[4]: generator forward + backward; returns (elapsed_s, roofline | None)."""
+    from transeditor_amd.model_spatial_query import Generator
+    from transeditor_amd.utils import distributed as D
+    token = 2 * (int(math.log2(size)) - 1)
+    if G is None:
+        torch.manual_seed(1234)                                    # same init on every rank (reference-style randn init)
+        G = Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).to(dev)
+        D.broadcast_module(G)
+    for p in G.parameters():
+        p.requires_grad_(True)
+    sync = D.GradSync(G)
+    params = list(G.parameters())
+    torch.manual_seed(1000 + rank)
+    n_in = steps + warmup
+    zs = [torch.randn(B, 512, 16, device=dev) for _ in range(n_in)]   # resident in HBM before the timed region
+    ps = [torch.randn(B, 512, 16, device=dev) for _ in range(n_in)]
+    wimg = torch.randn(B, 3, size, size, device=dev)
+
+    def step(i):
+        for p in params:
+            p.grad = None
+        img = G(zs[i], ps[i])[0]
+        (img * wimg).sum().backward()
+        sync.all_reduce()                                          # no-op at world == 1
+
+    for i in range(warmup):
+        step(i)
+    fence(world)
+    timer.reset()
+    timer.enabled = timer.installed
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    fence(world)
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    elapsed = max_over_ranks(elapsed, world, dev)
+    roof = timer.roofline(elapsed, steps) if timer.installed else None
+    sync.remove_hooks()
+    for p in params:
+        p.grad = None
+    return elapsed, roof
+
+
+class SubstepClock:
+    """HIP events around the four sub-steps of TrainStep.iteration (wraps the bound methods)."""
+
+    def __init__(self, ts):
+        self.rec = {k: [] for k in ('d', 'r1', 'g', 'path')}
+        self.enabled = False
+        for key, name in (('d', 'd_step'), ('r1', 'r1_step'), ('g', 'g_step'), ('path', 'path_step')):
+            setattr(ts, name, self._wrap(key, getattr(ts, name)))
+
+    def _wrap(self, key, fn):
+        def run(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            self.rec[key].append((s, e))
+            return out
+        return run
+
+    def summary(self, args):
+        ms = {k: (sum(s.elapsed_time(e) for s, e in v) / len(v) if v else None) for k, v in self.rec.items()}
+        out = {f'{k}_ms': v for k, v in ms.items()}
+        out['calls'] = {k: len(v) for k, v in self.rec.items()}
+        if all(v is not None for v in ms.values()):
+            out['cadence_weighted_ms_per_iteration'] = (ms['d'] + ms['g'] + ms['r1'] / args.d_reg_every
+                                                        + ms['path'] / args.g_reg_every)
+            out['note'] = ('GPU time of each sub-step incl. its optimiser step (EMA excluded); cadence-weighted = '
+                           'D + G + R1/16 + path/4, the long-run mean iteration (K = multiple of 16)')
+        return out
+
+
+def grads_checksum(module, world, dev):
+    """Every rank must hold bit-identical averaged gradients after GradSync.all_reduce: compare an integer checksum of
+    the raw gradient bits across ranks (outside the timed region)."""
+    import torch.distributed as dist
+    acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    n = 0
+    for p in module.parameters():
+        if p.grad is not None:
+            acc += p.grad.detach().contiguous().view(torch.int32).to(torch.int64).sum()
+            n += p.grad.numel()
+    allv = [torch.zeros_like(acc) for _ in range(world)]
+    dist.all_gather(allv, acc)
+    vals = [int(v.item()) for v in allv]
+    return {'identical_across_ranks': len(set(vals)) == 1, 'checksum_int64': vals[0], 'elements': n}
+
+
+def isolated_allreduce(sync, dev, reps=5):
+    """event-timed all-reduce of each bucket size on an otherwise idle GPU (outside the timed region)"""
+    import torch.distributed as dist
+    out = []
+    for bucket in sync.buckets:
+        n = sum(p.numel() for p in bucket)
+        buf = torch.zeros(n, device=dev)
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        w = dist.get_world_size()
+        out.append({'bytes': 4 * n, 'ms': ms, 'bus_GBps': 4 * n * 2 * (w - 1) / w / ms / 1e6})
+    return out
 
 
 def main():
@@ -143,141 +453,143 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('gloo' if share else 'nccl', init_method='env://')      # "nccl" == RCCL on ROCm
+        backend = 'gloo' if share else 'nccl'                       # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, init_method='env://')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    from transeditor_amd.model_spatial_query import Generator
-    from transeditor_amd.utils import distributed as D
-
-    size, B = args.size, args.batch
-    token = 2 * (int(math.log2(size)) - 1)
-    torch.manual_seed(1234)                                        # same init on every rank (reference-style randn init)
-    G = Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).to(dev)
-    D.broadcast_module(G)
-    sync = D.GradSync(G)
-    params = [p for p in G.parameters()]
-    torch.manual_seed(1000 + rank)
-    n_in = args.steps + args.warmup
-    zs = [torch.randn(B, 512, 16, device=dev) for _ in range(n_in)]   # resident in HBM before the timed region
-    ps = [torch.randn(B, 512, 16, device=dev) for _ in range(n_in)]
-    wimg = torch.randn(B, 3, size, size, device=dev)
-
+    size = args.size
+    B = args.batch if args.batch is not None else (4 if size >= 1024 else 16)
     timer = KernelTimer()
     if not args.no_kernel_timing:
         timer.install()
+    base = {'metric': METRIC, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
 
-    if args.workload == 'train':
-        # BASELINE configs[2] (N = 1) / configs[3] (N > 1): full train_spatial_query step with lazy R1 (1/16) and
-        # path-length (1/4) regularisers on synthetic "real" images; --steps should be a multiple of 16
-        from transeditor_amd.train_step import TrainStep, default_args
-        targs = default_args(size=size, batch=B)
-        ts = TrainStep(targs, dev, generator=G)
-        reals = [torch.randn(B, 3, size, size, device=dev).clamp(-1, 1) for _ in range(4)]
-        it = [0]
-
-        def train_iter(_):
-            ts.iteration(it[0], reals[it[0] % 4])
-            it[0] += 1
-        for i in range(args.warmup):
-            train_iter(i)
-        it[0] = 0
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            train_iter(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
+    if args.workload == 'generator':
+        elapsed, roof = run_generator(size, B, args.steps, args.warmup, dev, world, rank, timer)
         if rank == 0:
-            print(json.dumps({
-                'metric': '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling',
-                'value': world * B * args.steps / elapsed, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-                'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                'config': {'workload': f'FFHQ-{size} full G+D train step (BASELINE configs[2]/[3]): D step, R1 every 16, G step, '
-                                       f'path-length reg every 4 on batch {B // 2}, Adam, EMA; batch {B}/GPU',
-                           'global_batch': world * B, 'parallelism': f'dp{world}'}}), flush=True)
+            cfg = 'configs[4]' if size >= 1024 else 'configs[1]'
+            out = dict(base, value=world * B * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
+                       config={'workload': f'FFHQ-{size} generator fwd+bwd ONLY (BASELINE {cfg}; NOT the G+D metric), batch '
+                                           f'{B}/GPU, num_trans=8, random-init weights, random latents',
+                               'global_batch': world * B, 'parallelism': f'dp{world}',
+                               'per_gpu_images_per_sec': B * args.steps / elapsed})
+            if roof:
+                out['roofline'] = roof
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline_generator(size)
+            print(json.dumps(out), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
 
-    def step(i):
-        for p in params:
-            p.grad = None
-        img = G(zs[i], ps[i])[0]
-        (img * wimg).sum().backward()
-        sync.all_reduce()                                          # no-op at world == 1
+    # ---------------------------------------------------------------- default: the full G+D training iteration
+    from transeditor_amd.train_step import TrainStep, default_args
+    targs = default_args(size=size, batch=B)
+    torch.manual_seed(1234)                                        # same init on every rank
+    ts = TrainStep(targs, dev)
+    clock = SubstepClock(ts)
+    torch.manual_seed(1000 + rank)
+    reals = [torch.randn(B, 3, size, size, device=dev).clamp(-1, 1) for _ in range(4)]   # resident in HBM
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    timer.enabled = not args.no_kernel_timing
+    for i in range(args.warmup):                                   # iteration 0 fires both lazy regularisers
+        ts.iteration(i, reals[i % 4])
+    fence(world)
+    timer.reset()
+    timer.enabled = timer.installed
+    clock.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
+        ts.iteration(i, reals[i % 4])
+    fence(world)
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    clock.enabled = False
+    elapsed = max_over_ranks(elapsed, world, dev)
 
+    n_r1 = sum(1 for i in range(args.steps) if i % targs.d_reg_every == 0)
+    n_path = sum(1 for i in range(args.steps) if i % targs.g_reg_every == 0)
+    out = dict(base, value=world * B * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
+               config={'workload': f'FFHQ-{size} full G+D training iteration (BASELINE configs[{2 if world == 1 else 3}]; '
+                                   f'train_spatial_query.py:166-294): D step, R1 every {targs.d_reg_every}, G step, path-length '
+                                   f'regulariser every {targs.g_reg_every} on batch {B // targs.path_batch_shrink}, Adam, EMA; '
+                                   f'batch {B}/GPU, num_trans=8, random-init weights, synthetic real images',
+                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'per_gpu_images_per_sec': B * args.steps / elapsed,
+                       'lazy_steps_in_window': {'r1': n_r1, 'path': n_path, 'of_iterations': args.steps}})
+    if timer.installed:
+        out['roofline'] = timer.roofline(elapsed, args.steps)
+    out['substeps'] = clock.summary(targs)
+    cw = out['substeps'].get('cadence_weighted_ms_per_iteration')
+    if cw:
+        out['substeps']['cadence_weighted_images_per_sec_per_gpu'] = 1e3 * B / cw
+
+    if world > 1:
+        # ---- comm evidence, outside the timed region
+        import torch.distributed as dist
+        ts.g_step()                                                # leaves averaged G grads in place
+        torch.cuda.synchronize()
+        chk = grads_checksum(ts.generator, world, dev)
+        per_iter_bytes = ts.g_sync.bytes_per_call() * (1 + 1 / targs.g_reg_every) \
+            + ts.d_sync.bytes_per_call() * (1 + 1 / targs.d_reg_every)
+        iso_g = isolated_allreduce(ts.g_sync, dev)
+        # exposed communication: the same iterations with the exchange switched off
+        ts.g_sync.enabled = ts.d_sync.enabled = False
+        k2 = min(args.steps, 8)
+        fence(world)
+        t0 = time.perf_counter()
+        for i in range(k2):
+            ts.iteration(1 + i, reals[i % 4])                      # indices 1..8: path at 4, 8; no R1
+        fence(world)
+        nocomm = max_over_ranks(time.perf_counter() - t0, world, dev) / k2
+        ts.g_sync.enabled = ts.d_sync.enabled = True
+        fence(world)
+        t0 = time.perf_counter()
+        for i in range(k2):
+            ts.iteration(1 + i, reals[i % 4])
+        fence(world)
+        withcomm = max_over_ranks(time.perf_counter() - t0, world, dev) / k2
+        out['comm'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world_size': dist.get_world_size(),
+                       'bytes_allreduced_per_iteration_per_gpu': per_iter_bytes,
+                       'g_bytes_per_exchange': ts.g_sync.bytes_per_call(), 'd_bytes_per_exchange': ts.d_sync.bytes_per_call(),
+                       'buckets_g': len(ts.g_sync.buckets), 'buckets_d': len(ts.d_sync.buckets),
+                       'isolated_allreduce_per_bucket_g': iso_g,
+                       'ms_per_iteration_with_exchange': 1e3 * withcomm, 'ms_per_iteration_without_exchange': 1e3 * nocomm,
+                       'exposed_comm_ms_per_iteration': 1e3 * (withcomm - nocomm),
+                       'grad_bit_identity': chk}
+        assert chk['identical_across_ranks'], f'averaged gradients differ across ranks: {chk}'
+
+    if world == 1 and rank == 0 and not args.no_sub:
+        # ---- named sub-benchmarks: configs[1] (the generator of the train step, same weights) and configs[4]
+        sub = {}
+        el, roof = run_generator(size, B, 10, 3, dev, 1, 0, timer, G=ts.generator)
+        sub['generator_fwd_bwd_256_b16'] = {
+            'config': f'BASELINE configs[1]: FFHQ-{size} generator fwd+bwd, batch {B}, 3 warm-up + 10 timed steps',
+            'value': B * 10 / el, 'unit': 'images/sec', 'ms_per_step': 1e2 * el, 'roofline': _slim(roof)}
+        del ts, clock
+        torch.cuda.empty_cache()
+        if size == 256:
+            el, roof = run_generator(1024, 4, 6, 2, dev, 1, 0, timer)
+            sub['generator_fwd_bwd_1024_b4'] = {
+                'config': 'BASELINE configs[4]: FFHQ-1024 generator fwd+bwd, batch 4, 2 warm-up + 6 timed steps',
+                'value': 4 * 6 / el, 'unit': 'images/sec', 'ms_per_step': 1e3 * el / 6, 'roofline': _slim(roof)}
+        out['sub_benchmarks'] = sub
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_train(size)
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        out = {
-            'metric': '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling',
-            'value': world * B * args.steps / elapsed, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'FFHQ-{size} generator fwd+bwd (BASELINE configs[1]), batch {B}/GPU, num_trans=8, '
-                                   f'random-init weights, random latents', 'global_batch': world * B,
-                       'parallelism': f'dp{world}', 'per_gpu_images_per_sec': B * args.steps / elapsed},
-        }
-        if not args.no_kernel_timing:
-            ks = timer.summary()
-            conv_keys = [k for k in ks if not k.endswith('1x1')]
-            flops = sum(ks[k]['tflops'] * ks[k]['total_ms'] for k in conv_keys)      # TFLOP*ms
-            tms = sum(ks[k]['total_ms'] for k in conv_keys)
-            ach = flops / tms if tms else 0.0
-            traffic, traffic_note = None, None
-            try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_round.sh + pmc_summary.py)
-                pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
-                k3 = next(v for k, v in pm.items() if k.startswith('conv_mfma_kernel<0'))
-                traffic = (k3['hbm_read_mb'] + k3['hbm_write_mb']) * 1e6
-                traffic_note = (f"PMC pass of the 128->128 @256x256 batch-16 launch: FETCH_SIZE x2 (gfx950 correction) = "
-                                f"{k3['hbm_read_mb']:.0f} MB read + WRITE_SIZE {k3['hbm_write_mb']:.0f} MB written vs "
-                                f"{k3['algorithmic_mb']:.0f} MB algorithmic; MFMA utilisation {k3['mfma_util_pct']:.1f} % "
-                                f"at {k3['mhz']:.0f} MHz (profiles/r01_pmc_summary.txt)")
-            except Exception:
-                pass
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
-                               'kernel': 'conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2, all 3x3 kinds)',
-                               'kernel_time_share': tms / (ms * args.steps), 'per_kernel': ks}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(size)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _slim(roof):
+    if roof is None:
+        return None
+    return {k: v for k, v in roof.items() if k not in ('traffic_note', 'kernel')}
 
 
 if __name__ == '__main__':

@@ -372,6 +372,65 @@ def gen_train_step(M):
         f'{k}={float(out[k]):.5f}' for k in ('d', 'r1', 'g', 'path', 'path_length', 'mean_path_length')))
 
 
+def gen_train_grads(M):
+    """Gradients of the four sub-steps of the reference loop BEFORE any optimiser update (train_spatial_query.py:173-250
+    evaluated on the initial weights, i.e. with the Adam steps left out), from the reference's own models and loss
+    functions: per-parameter gradient norms + the loss values.  Lets the GPU train step be compared at 1e-3 without the
+    lr * sign(grad) amplification of Adam's first step that the post-update fixture (train_step32_b4) carries."""
+    T = ref_import.reference_train_functions()
+    token = 2 * (int(math.log2(TRAIN_SIZE)) - 1)
+    G = M.Generator(TRAIN_SIZE, 512, 512, token, n_trans=8, pixel_norm_op_dim=1)
+    Dn = M.Discriminator(TRAIN_SIZE)
+    synth.fill_state_dict(G.state_dict(), 40)
+    synth.fill_state_dict(Dn.state_dict(), 41)
+    r1, path_regularize, d_reg_every, g_reg_every = 10.0, 2.0, 16, 4
+    dr_ = train_draws()
+    real_img = dr_['real']
+    out = {'g_names': np.array([n for n, _ in G.named_parameters()]), 'd_names': np.array([n for n, _ in Dn.named_parameters()])}
+
+    def norms(mod):
+        return np.array([0.0 if q.grad is None else float(q.grad.double().norm()) for q in mod.parameters()])
+
+    # D step :173-194
+    T.requires_grad(G, False)
+    T.requires_grad(Dn, True)
+    fake_img, _, _ = G(*dr_['d'])
+    fake_pred, real_pred = Dn(fake_img), Dn(real_img)
+    d_loss = T.d_logistic_loss(real_pred, fake_pred)
+    Dn.zero_grad()
+    d_loss.backward()
+    out.update(d=d_loss, d_grad_norms=norms(Dn), d_probe=Dn.final_linear[1].weight.grad.clone())
+    # R1 :196-206
+    real_img.requires_grad = True
+    real_pred = Dn(real_img)
+    r1_loss = T.d_r1_loss(real_pred, real_img)
+    Dn.zero_grad()
+    (r1 / 2 * r1_loss * d_reg_every + 0 * real_pred[0]).backward()
+    out.update(r1=r1_loss, r1_grad_norms=norms(Dn))
+    # G step :210-224
+    T.requires_grad(G, True)
+    T.requires_grad(Dn, False)
+    fake_img, _, _ = G(*dr_['g'])
+    g_loss = T.g_nonsaturating_loss(Dn(fake_img))
+    G.zero_grad()
+    g_loss.backward()
+    out.update(g=g_loss, g_grad_norms=norms(G), g_probe=G.adjust_style.weight.grad.clone())
+    # path-length regulariser :226-250
+    fake_img, latents, _ = G(*dr_['path'], return_latents=True)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: dr_['pl_noise'].to(t)
+    try:
+        path_loss, mean_path_length, path_lengths = T.g_path_regularize(fake_img, latents, 0)
+    finally:
+        torch.randn_like = orig
+    G.zero_grad()
+    (path_regularize * g_reg_every * path_loss + 0 * fake_img[0, 0, 0, 0]).backward()
+    out.update(path=path_loss, path_length=path_lengths.mean(), path_grad_norms=norms(G))
+    npz('train_grads32_b4', **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
+    REPORT.append('train sub-step gradients on the initial weights (32 px, batch 4): ' + ', '.join(
+        f'{k}={float(out[k]):.5f}' for k in ('d', 'r1', 'g', 'path', 'path_length')))
+
+
 def main():
     assert ref_import.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
@@ -382,6 +441,7 @@ def main():
     gen_generator(M)
     gen_discriminator(M)
     gen_train_step(M)
+    gen_train_grads(M)
     with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:
         f.write('golden fixtures generated by oracle/gen_golden.py from the imported reference\n')
         f.write(f'torch {torch.__version__}, numpy {np.__version__}\n')

@@ -36,7 +36,8 @@ def _worker(rank, world, port, q):
         sync = D.GradSync(net, bucket_bytes=256)               # tiny buckets: exercise several of them
         assert len(sync.buckets) > 1
         sync.all_reduce()
-        first_sync = [p.grad.clone() for p in net.parameters()]
+        assert unused.grad is None, 'a parameter without gradient must keep .grad None (DDP find_unused_parameters semantics)'
+        first_sync = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
         # second step: the hooks installed by GradSync fire DURING backward (buckets launch as they fill up)
         for prm in net.parameters():
             prm.grad = None
@@ -45,7 +46,8 @@ def _worker(rank, world, port, q):
         assert any(w is not None for w in sync._work), 'hook-driven launch did not happen'
         hook_local = None    # local grads were overwritten in place by the flat copy only after all_reduce()
         sync.all_reduce()
-        hooked = [p.grad.clone() for p in net.parameters() if p is not unused] + [unused.grad.clone()]
+        assert unused.grad is None
+        hooked = [p.grad.clone() for p in net.parameters() if p is not unused] + [torch.zeros_like(unused)]
         ref_net_grads = torch.autograd.grad(net(x2).pow(2).sum(), [prm for prm in net.parameters() if prm is not unused])
         # frozen module: nothing to exchange, nothing breaks
         for prm in net.parameters():
@@ -89,3 +91,100 @@ def test_gradient_sync_and_scalar_collectives_world2():
         assert abs(sa - mean).max() < 1e-6 and abs(sb - mean).max() < 1e-6
     assert red_a == red_b == 3.0
     assert loss_a == {'d': 15.0, 'g': 1.5}                     # rank 0 holds the mean, sorted keys
+
+
+class _DeferredWork:
+    """Stand-in for an asynchronous RCCL work object: the reduction only happens when wait() is called, on whatever the
+    buffer holds AT THAT TIME.  Reading the buffer before wait(), or writing it between launch and wait(), gives wrong
+    results, which is exactly what must not happen on a backend whose collectives really are asynchronous."""
+    log = []
+
+    def __init__(self, real_all_reduce, tensor, op):
+        self.real, self.tensor, self.op, self.done = real_all_reduce, tensor, op, False
+        self.snapshot = tensor.clone()
+        _DeferredWork.log.append(self)
+
+    def wait(self):
+        assert not self.done
+        assert torch.equal(self.tensor, self.snapshot), 'bucket modified between launch and wait()'
+        self.real(self.tensor, op=self.op)
+        self.done = True
+
+
+def _worker_deferred(rank, world, port, q):
+    import torch.distributed as dist
+    from transeditor_amd.utils import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        real = dist.all_reduce
+
+        def fake_all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=False, **kw):
+            if async_op:
+                return _DeferredWork(real, tensor, op)
+            return real(tensor, op=op)
+        D.dist.all_reduce = fake_all_reduce
+        torch.manual_seed(100 + rank)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                  torch.nn.Linear(16, 4))
+        D.dist.all_reduce = real
+        D.broadcast_module(net)
+        D.dist.all_reduce = fake_all_reduce
+        sync = D.GradSync(net, bucket_bytes=512)
+        assert len(sync.buckets) >= 3
+        outs = []
+        for step in range(3):                                   # several steps: buffers are reused, .grad aliases the buckets
+            for prm in net.parameters():
+                prm.grad = None
+            x = torch.randn(6, 8)
+            loss = net(x).pow(2).sum()
+            ref = torch.autograd.grad(loss, list(net.parameters()), retain_graph=True)
+            n_before = len(_DeferredWork.log)
+            loss.backward()
+            launched = _DeferredWork.log[n_before:]
+            assert launched and not any(w.done for w in launched), 'buckets must launch from the hooks and stay pending'
+            sync.all_reduce()
+            assert all(w.done for w in _DeferredWork.log)
+            outs.append(([g.numpy() for g in ref], [prm.grad.clone().numpy() for prm in net.parameters()]))
+        # second pass WITHOUT resetting .grad (zero_grad(set_to_none=False) style): autograd accumulates into the bucket views
+        for prm in net.parameters():
+            prm.grad.zero_()
+        x = torch.randn(6, 8)
+        loss = net(x).pow(2).sum()
+        ref = torch.autograd.grad(loss, list(net.parameters()), retain_graph=True)
+        loss.backward()
+        sync.all_reduce()
+        outs.append(([g.numpy() for g in ref], [prm.grad.clone().numpy() for prm in net.parameters()]))
+        # disabled: a no-op
+        sync.enabled = False
+        for prm in net.parameters():
+            prm.grad = None
+        net(x).pow(2).sum().backward()
+        sync.all_reduce()
+        local_only = [prm.grad.clone().numpy() for prm in net.parameters()]
+        q.put((rank, outs, [g.numpy() for g in ref], local_only, sync.bytes_per_call()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_with_deferred_async_work_world2():
+    """GradSync's ordering must not depend on gloo completing collectives eagerly (RCCL does not)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_deferred, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, outs_a, ref_a, loc_a, nb_a), (_, outs_b, ref_b, loc_b, nb_b) = res
+    assert nb_a == nb_b == 4 * (8 * 16 + 16 + 16 * 16 + 16 + 16 * 4 + 4)
+    for (ra, ga), (rb, gb) in zip(outs_a, outs_b):
+        for x, y, ma, mb in zip(ra, rb, ga, gb):
+            mean = (x + y) / 2
+            assert abs(ma - mean).max() < 1e-6 and abs(mb - mean).max() < 1e-6
+            assert (ma == mb).all()                              # bit-identical on both ranks
+    for x, l in zip(ref_a, loc_a):                               # disabled sync leaves the local gradient untouched
+        assert (x == l).all()

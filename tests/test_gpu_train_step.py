@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle.gen_golden import TRAIN_BATCH, TRAIN_PROBES, TRAIN_SIZE, train_draws
+from conftest import rel_err
 from transeditor_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -76,3 +77,58 @@ def test_requires_grad_toggling_and_unused_parameters():
     ts.g_step()
     missing = [n for n, p in ts.generator.named_parameters() if p.grad is None]
     assert len(missing) == 7 and all(n.endswith('noise.weight') for n in missing)
+
+
+def test_train_substep_gradients_before_adam_match_reference(golden):
+    """The four sub-steps on the INITIAL weights (learning rate 0: Adam leaves the weights alone), so losses and every
+    parameter-gradient norm compare with the reference's own models / loss functions at the north-star 1e-3 — without
+    the lr * sign(grad) amplification that the post-update comparison above has to allow for
+    (tests/golden/train_grads32_b4.npz, oracle/gen_golden.py::gen_train_grads; train_spatial_query.py:173-250)."""
+    from transeditor_amd.train_step import TrainStep, default_args
+    from transeditor_amd.model_spatial_query import Discriminator, Generator
+    gold = golden('train_grads32_b4')
+    args = default_args(size=TRAIN_SIZE, batch=TRAIN_BATCH, lr=0.0)
+    G = Generator(TRAIN_SIZE, 512, 512, args.token, n_trans=8, pixel_norm_op_dim=1)
+    Dn = Discriminator(TRAIN_SIZE)
+    synth.fill_state_dict(G.state_dict(), 40)
+    synth.fill_state_dict(Dn.state_dict(), 41)
+    w0 = float(sum(p.double().abs().sum() for p in G.parameters()))
+    draws = train_draws()
+    ts = TrainStep(args, DEV, G.to(DEV), Dn.to(DEV), FixedSampler(draws))
+    real = draws['real'].to(DEV)
+    TOL = 1e-3
+
+    def check(tag, mod, names_key):
+        names = [str(n) for n in gold[names_key]]
+        assert names == [n for n, _ in mod.named_parameters()]
+        bad = []
+        for n, q, want in zip(names, mod.parameters(), gold[f'{tag}_grad_norms']):
+            got = 0.0 if q.grad is None else float(q.grad.double().norm())
+            if want > 1e-9:
+                if abs(got - want) / want > TOL:
+                    bad.append((n, got, float(want)))
+            else:
+                assert got <= 1e-9, (tag, n, got)
+        assert not bad, (tag, bad[:6])
+
+    def close(key, got):
+        want = float(gold[key])
+        assert abs(float(got) - want) <= TOL * max(abs(want), 1e-3), (key, float(got), want)
+
+    ts.d_step(real)
+    close('d', ts.loss['d'])
+    check('d', ts.discriminator, 'd_names')
+    assert rel_err(ts.discriminator.final_linear[1].weight.grad, gold['d_probe']) < TOL
+    ts.r1_step(real)
+    close('r1', ts.loss['r1'])
+    check('r1', ts.discriminator, 'd_names')
+    ts.g_step()
+    close('g', ts.loss['g'])
+    check('g', ts.generator, 'g_names')
+    assert rel_err(ts.generator.adjust_style.weight.grad, gold['g_probe']) < TOL
+    ts.path_step()
+    close('path', ts.loss['path'])
+    close('path_length', ts.loss['path_length'])
+    check('path', ts.generator, 'g_names')
+    w1 = float(sum(p.double().abs().sum() for p in ts.generator.parameters()))
+    assert abs(w1 - w0) <= 1e-10 * w0                                          # lr = 0: weights untouched

@@ -80,12 +80,35 @@ def _check(rc, what):
         raise RuntimeError(f'{what} failed (code {rc}): {lib().te_last_error_string().decode()}')
 
 
+_cur_dev = getattr(torch._C, '_cuda_getDevice', torch.cuda.current_device)
+
+
+def _on_current_device(t):
+    """The kernels are enqueued on the CURRENT device's current stream (what the reference's ops do,
+    fused_bias_act_kernel.cu:90, upfirdn2d_kernel.cu:192).  Unlike the reference, a tensor that lives on another GPU is
+    refused instead of being read through a foreign pointer on the wrong stream."""
+    if t.device.index != _cur_dev():          # (a CUDA tensor exists, so the runtime is initialised)
+        raise RuntimeError(f'te_hip: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}; '
+                           f'call torch.cuda.set_device (one process per GPU) or wrap the call in torch.cuda.device(...)')
+
+
 def _ptr(t):
     if t is None:
         return None
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise RuntimeError(f'te_hip: expected a contiguous fp32 tensor on the GPU, got {t.dtype} {t.device} '
                            f'contiguous={t.is_contiguous()} (no CPU path exists)')
+    _on_current_device(t)
+    return t.data_ptr()
+
+
+def _raw(t):
+    """device pointer of a tensor addressed through explicit strides (no contiguity requirement)"""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
+    _on_current_device(t)
     return t.data_ptr()
 
 
@@ -263,10 +286,8 @@ def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alph
     c = torch.empty(I, J, device=a.device, dtype=a.dtype)
     pre = torch.empty_like(c) if want_pre else None
     rs = torch.empty(I, device=a.device, dtype=a.dtype) if rowsum_scale is not None else None
-    for t in (a, b):           # addressed through explicit strides: only device / dtype are checked
-        if not (t.is_cuda and t.dtype == torch.float32):
-            raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
-    _check(lib().te_small_gemm_f32(_ptr(c), _ptr(pre), a.data_ptr(), b.data_ptr(), _ptr(bias), _ptr(residual), _ptr(rs),
+    # a / b are addressed through explicit strides: only device / dtype are checked
+    _check(lib().te_small_gemm_f32(_ptr(c), _ptr(pre), _raw(a), _raw(b), _ptr(bias), _ptr(residual), _ptr(rs),
                                    rowsum_scale if rowsum_scale is not None else 0.0, I, J, K, sai, sak, sbk, sbj, alpha,
                                    beta, act, _stream()), 'te_small_gemm_f32')
     return c, pre, rs
@@ -276,12 +297,9 @@ def small_gemm_batched(c, a, b, bias, nz, za, zc, I, J, K, sai, sak, sbk, sbj, s
                        bias_tab=None, alpha=1.0, beta=1.0, act=0):
     """nz GEMMs in one launch (see te_hip.h); c is written in place through (zc, sci, scj).  b_tab / bias_tab: lists of
     element offsets relative to b / bias for separately allocated per-z operands."""
-    for t in (c, a, b):
-        if not (t.is_cuda and t.dtype == torch.float32):
-            raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {t.dtype} {t.device} (no CPU path exists)')
     bt = (C.c_int64 * nz)(*b_tab) if b_tab is not None else None
     bit = (C.c_int64 * nz)(*bias_tab) if bias_tab is not None else None
-    _check(lib().te_small_gemm_batched_f32(c.data_ptr(), a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None,
+    _check(lib().te_small_gemm_batched_f32(_raw(c), _raw(a), _raw(b), _raw(bias),
                                            nz, za, zc, zb, zbias, bt, bit, I, J, K, sai, sak, sbk, sbj, sci, scj, alpha, beta,
                                            act, _stream()), 'te_small_gemm_batched_f32')
     return c

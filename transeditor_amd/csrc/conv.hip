@@ -461,20 +461,13 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     return 0;
 }
 
-inline int conv_occ() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TE_CONV_OCC"); v = (e && atoi(e) == 2) ? 2 : 3; }
-    return v;
-}
+constexpr int conv_occ() { return 3; }      // waves per SIMD the plain 3x3 128-row tile is compiled for (2 measured slower)
 
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     constexpr int BM = tile_bm<KIND, TC>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC>, 128 * 1024);
     dim3 grid((unsigned)nblocks, (unsigned)te::cdiv(a.M, BM), (unsigned)a.ksplit);
     conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
 }
@@ -562,8 +555,7 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
     int tc = tile_class(M);
     // transposed conv on small images (<= 1024 of the 64 x 128 tiles): the 64 x 64 tile class fits 3 waves per SIMD and
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
-    static const bool t2small = !(getenv("TE_T2_SMALL") && atoi(getenv("TE_T2_SMALL")) == 0);
-    if (t2small && t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
+    if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
     const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the

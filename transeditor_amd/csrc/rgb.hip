@@ -173,11 +173,8 @@ extern "C" int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, in
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_rgb_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_f32: need 0 < K <= 512");
     const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)rgb_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel, 96 * 1024);
     dim3 grid((unsigned)S, (unsigned)B);
     rgb_wgrad_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
     return te::launch_status("te_rgb_wgrad_f32");

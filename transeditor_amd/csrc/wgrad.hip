@@ -408,12 +408,6 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
 
 // block tile: 8 waves (128 x 64 channels) by default; narrow layers (both channel counts <= 64, the 512 / 1024 px
 // generator tail) use the 4-wave 64 x 64 tile so half of the plain-operand rows are not zero padding
-inline int pick_nwp(int Co, int Ci);
-inline int wgrad_nwp() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TE_WGRAD_NWP"); v = (e && atoi(e) == 2) ? 2 : 4; }
-    return v;
-}
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int pow2ceil(int v) { return 1 << ilog2(v); }
@@ -448,18 +442,15 @@ bool fill_geometry(WgArgs& a) {
     return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
 }
 
-inline int pick_nwp(int Co, int Ci) { return (wgrad_nwp() == 2 || (Co <= 64 && Ci <= 64)) ? 2 : 4; }
+inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
     size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
     if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_mfma_kernel<KIND, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 128 * 1024);
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);
     dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
     wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);

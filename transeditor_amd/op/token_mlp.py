@@ -27,8 +27,14 @@ def _torch_expr(x, weights, biases, scale, lr_mul):
 
 
 def _offsets(ts):
+    """element offsets of separately allocated per-token operands relative to the first one"""
     base = ts[0].data_ptr()
     return [(t.data_ptr() - base) // 4 for t in ts]
+
+
+def _kernel_ready(x, params):
+    """the batched launch reads every weight / bias through a raw offset: each must be a dense fp32 tensor on x's device"""
+    return all(t.is_contiguous() and t.dtype == torch.float32 and t.device == x.device for t in params)
 
 
 class _TokenMLP(Function):
@@ -86,4 +92,7 @@ def token_mlp(x, weights, biases, scale, lr_mul):
         if not x.is_cuda:
             raise RuntimeError('te_hip: expected an fp32 tensor on the GPU (no CPU path exists)')
         return _torch_expr(x, weights, biases, scale, lr_mul)
+    if not _kernel_ready(x, list(weights) + list(biases)):
+        raise RuntimeError('te_hip: token_mlp needs contiguous fp32 weights / biases on the input\'s device '
+                           '(call .contiguous() on reassigned parameters)')
     return _TokenMLP.apply(x, scale, lr_mul, T, *weights, *biases)

@@ -13,6 +13,7 @@ Data parallelism (config 4): one process per GPU, `GradSync` mean all-reduce of 
 backward (what the reference's two DDP wrappers do, :494-509) and the scalar collectives of utils/distributed.
 `--spatial_regu` (off in every BASELINE config) is not built.
 """
+import copy
 import math
 from types import SimpleNamespace
 
@@ -95,8 +96,9 @@ class TrainStep:
         self.generator = generator if generator is not None else mk()
         self.discriminator = (discriminator if discriminator is not None
                               else Discriminator(args.size, channel_multiplier=args.channel_multiplier).to(device))
-        self.g_ema = mk()
-        self.g_ema.eval()
+        # :452-455 — the EMA copy has the generator's own structure (also when the caller supplied a generator built with
+        # other constructor options than `args` describes)
+        self.g_ema = copy.deepcopy(self.generator).eval() if generator is not None else mk().eval()
         accumulate(self.g_ema, self.generator, 0)                            # :455
         g_ratio = args.g_reg_every / (args.g_reg_every + 1)
         d_ratio = args.d_reg_every / (args.d_reg_every + 1)

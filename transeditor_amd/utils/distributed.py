@@ -5,9 +5,9 @@ On PyTorch-ROCm the "nccl" backend IS RCCL.  The only exchange step of the Trans
 is the gradient all-reduce (171.7 MB for G, 115.5 MB for D at 256 px) plus three
 scalar-sized collectives (C5/C6).  `GradSync` replaces the two DistributedDataParallel wrappers
 (`find_unused_parameters=True`, train_spatial_query.py:494-509): gradients are packed into a few
-large flat fp32 buckets (sized for the per-link xGMI bandwidth, default 64 MiB => 3 buckets for G)
+large flat fp32 buckets (sized for the per-link xGMI bandwidth, default 32 MiB => 6 buckets for G)
 and all-reduced asynchronously on RCCL's stream; parameters whose .grad is None (the 13 unused
-`noise.weight`s) contribute zeros, which is what DDP's unused-parameter handling amounts to.
+`noise.weight`s) contribute zeros and keep .grad None, which is what DDP's unused-parameter handling amounts to.
 The same code runs on CPU tensors with the gloo backend (tests).
 """
 import torch
@@ -80,14 +80,21 @@ class GradSync:
 
     Parameters are bucketed in REVERSE registration order (the order backward produces their gradients).  A
     post-accumulate hook counts the gradients of a bucket; when the last one has arrived the bucket is packed into its
-    flat buffer with one multi-tensor copy and its all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps the rest of the
-    backward.  `all_reduce()` issues whatever is left (buckets holding parameters that received no gradient, e.g. the
-    unused `noise.weight`s, are completed with zeros), waits, averages and points every `.grad` at its
+    flat buffer with one multi-tensor copy and its all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps
+    the rest of the backward.  `all_reduce()` issues whatever is left, waits, averages and points every `.grad` at its
     slice of the bucket (no copy back; the buffers are reused by the next backward, after `.grad` has been reset).
+    Parameters that received no gradient on this rank (the unused `noise.weight`s; by symmetry unused on every rank)
+    contribute zeros to the bucket and keep `.grad = None`, which is what DistributedDataParallel with
+    find_unused_parameters=True leaves (train_spatial_query.py:494-509), so optimiser state is created for exactly the
+    same parameters as in the reference.
+
+    Nothing here relies on the collective being synchronous: between `_launch` and `work.wait()` the flat buffer is
+    neither read nor written by this class (tests/test_distributed_gloo.py drives it with deferred work objects).
     """
 
     def __init__(self, module, bucket_bytes=32 << 20):
         self.params = [p for p in module.parameters()]
+        self.enabled = True                               # False: hooks and all_reduce() do nothing (bench: no-exchange leg)
         self.buckets, cur, cur_bytes = [], [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
@@ -111,9 +118,20 @@ class GradSync:
         # all_reduce() and no longer waited for, so their buckets can still launch from the hooks
         self._unused = set()
         self._late = []                                   # gradients that arrived after their bucket was launched
-        self._hooked = False
+        self._handles = []
+        self.calls = 0
         if get_world_size() > 1:
             self._install_hooks()
+
+    # ---- bookkeeping
+    def bytes_per_call(self):
+        """bytes this rank hands to the all-reduce in one all_reduce() call (all buckets)"""
+        return sum(p.numel() * p.element_size() for p in self.params)
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
 
     # ---- internals
     def _buffer(self, bi):
@@ -125,13 +143,14 @@ class GradSync:
         return flat
 
     def _install_hooks(self):
-        if self._hooked:
+        if self._handles:
             return
-        self._hooked = True
         for p in self.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
+            self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _on_grad(self, p):
+        if not self.enabled:
+            return
         bi, _ = self._slot[p]
         if self._work[bi] is not None:                    # bucket already in flight (parameter thought unused): fix up later
             self._late.append(p)
@@ -153,7 +172,7 @@ class GradSync:
         for p, v in zip(self.buckets[bi], views):
             if p.grad is None:                            # no gradient (unused or frozen): contributes zeros
                 v.zero_()
-            else:
+            elif p.grad.data_ptr() != v.data_ptr():       # (a .grad still aliasing its slice is already in place)
                 src.append(p.grad)
                 dst.append(v)
         if dst:
@@ -162,11 +181,14 @@ class GradSync:
 
     def all_reduce(self):
         world = get_world_size()
-        if world == 1:
+        if world == 1 or not self.enabled:
             return
+        self.calls += 1
         active = [bi for bi, b in enumerate(self.buckets) if any(p.requires_grad for p in b)]
+        had_grad = {}
         for bi in active:
             for p in self.buckets[bi]:
+                had_grad[p] = p.grad is not None
                 if p.requires_grad and p.grad is None:
                     self._unused.add(p)
                 elif p in self._unused and p in self._seen[bi]:
@@ -178,7 +200,7 @@ class GradSync:
             self._work[bi].wait()
             self._flat[bi].div_(world)
             for p, v in zip(self.buckets[bi], self._views(bi)):
-                if p.requires_grad and p not in late:
+                if p.requires_grad and p not in late and had_grad[p]:
                     p.grad = v                            # the averaged gradient lives in the bucket: no copy back
         for p in self._late:                              # rare: reduce stragglers one by one and stop treating them as unused
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
