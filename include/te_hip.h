@@ -220,6 +220,26 @@ int te_demod_fwd_f32(float* d, float* wsq, const float* w, const float* s, float
 int te_demod_bwd_f32(float* gw, float* gs, const float* gd, const float* d, const float* w, const float* wsq,
                      const float* s, float wscale, int B, int Co, int Ci, int T, int accumulate, te_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * T2  multi-tensor optimiser kernels: ONE launch over every parameter tensor of a module (reference:
+ * train_spatial_query.py:458-473 — two torch.optim.Adam over 257 / 38 tensors — and accumulate(), :56-61, the
+ * g_ema update; hundreds of tiny launches per iteration there).
+ * The tensors are described by DEVICE tables:
+ *   te_mt_adam_f32: table[5][n] (int64) = param ptr, grad ptr (0 = no gradient: tensor skipped), exp_avg ptr,
+ *                   exp_avg_sq ptr, numel;  te_mt_ema_f32: table[3][n] = dst ptr, src ptr, numel;
+ *   chunks[2][n_chunks] (int32) = tensor index, chunk index within the tensor; chunk c covers elements
+ *   [chunk_index * chunk_elems, +chunk_elems) of its tensor (chunk_elems % 4 == 0).
+ * Adam (no weight decay, no amsgrad), same operation order as torch.optim.Adam:
+ *   m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *   (beta1 == 0, the reference's setting: m is written (= g) but never read).  Hyper-parameters arrive as doubles (the
+ *   bias corrections are formed in double on the host, as torch does) and are applied in fp32.
+ * EMA: dst = dst * decay + (1 - decay) * src.
+ */
+int te_mt_adam_f32(const int64_t* table, const int32_t* chunks, int n_tensors, int n_chunks, int chunk_elems, double lr,
+                   double beta1, double beta2, double eps, int step, te_stream_t stream);
+int te_mt_ema_f32(const int64_t* table, const int32_t* chunks, int n_tensors, int n_chunks, int chunk_elems, double decay,
+                  te_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

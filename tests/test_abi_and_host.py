@@ -157,9 +157,8 @@ def test_train_step_losses_match_oracle_on_cpu():
     b = O.g_path_regularize(img, lat, 0.0, noise / 4.0)
     assert torch.allclose(a[0], b[0]) and torch.allclose(a[2], b[2])
     m1, m2 = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
-    w1, w2 = m1.weight.detach().clone(), m2.weight.detach().clone()
-    T.accumulate(m1, m2, 0.9)
-    assert torch.allclose(m1.weight, 0.9 * w1 + 0.1 * w2)
+    with pytest.raises(RuntimeError, match='no CPU path'):        # the EMA is a HIP kernel (tests/test_gpu_optim.py)
+        T.accumulate(m1, m2, 0.9)
     args = T.default_args(size=64)
     assert args.token == 10 and args.d_reg_every == 16 and args.g_reg_every == 4
 

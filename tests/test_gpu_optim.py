@@ -1,0 +1,98 @@
+"""T2: multi-tensor Adam / EMA kernels against torch.optim.Adam and the reference's accumulate() formula
+(train_spatial_query.py:56-61, 458-473).  Tolerance 1e-6 relative over three steps (same operation order, fp32)."""
+import copy
+
+import pytest
+import torch
+
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _params(seed, shapes):
+    return [torch.nn.Parameter(synth.normal(s, f'opt.p{i}', seed).to(DEV)) for i, s in enumerate(shapes)]
+
+
+SHAPES = [(512, 512, 3, 3), (512,), (1, 3, 1, 1), (16, 17), (3,), (130, 7, 3, 3), (1,), (8192 + 5,), (4, 2048)]
+
+
+@pytest.mark.parametrize('betas', [(0.0, 0.99 ** 0.8), (0.9, 0.999), (0.3, 0.99 ** (16 / 17))])
+def test_fused_adam_matches_torch_adam(betas):
+    from transeditor_amd.optim import FusedAdam
+    ours, ref = _params(1, SHAPES), _params(1, SHAPES)
+    o1 = FusedAdam(ours, lr=0.002 * 0.8, betas=betas)
+    o2 = torch.optim.Adam(ref, lr=0.002 * 0.8, betas=betas)
+    bucket = torch.zeros(sum(p.numel() for p in ours) + 3, device=DEV)      # gradients as 4-byte aligned bucket slices
+    for step in range(3):
+        off = 1 if step == 1 else 0                                          # step 1: misaligned views (scalar path)
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            g = synth.normal(tuple(a.shape), f'opt.g{i}', 10 + step).to(DEV) * (10.0 ** (i % 3 - 1))
+            if i == 4 and step < 2:
+                a.grad = b.grad = None                                       # a parameter that skips steps (own step count)
+                continue
+            b.grad = g.clone()
+            if step == 0:
+                a.grad = g.clone()
+            else:
+                v = bucket[off:off + a.numel()].view_as(a)
+                v.copy_(g)
+                a.grad = v
+                off += a.numel()
+        o1.step()
+        o2.step()
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            err = float((a.detach() - b.detach()).abs().max() / b.detach().abs().max())
+            assert err < 1e-6, (step, i, err)
+    # state layout == torch.optim.Adam's: a checkpoint written by one loads into the other and continues identically
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert sd1['state'].keys() == sd2['state'].keys()
+    for k in sd1['state']:
+        assert set(sd1['state'][k]) == {'step', 'exp_avg', 'exp_avg_sq'} == set(sd2['state'][k])
+        assert float(sd1['state'][k]['step']) == float(sd2['state'][k]['step'])
+        for name in ('exp_avg', 'exp_avg_sq'):
+            a, b = sd1['state'][k][name], sd2['state'][k][name]
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-30, (k, name)
+    o3 = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ours], lr=0.002 * 0.8, betas=betas)
+    o3.load_state_dict(copy.deepcopy(sd1))
+    o4 = FusedAdam([torch.nn.Parameter(p.detach().clone()) for p in ours], lr=0.002 * 0.8, betas=betas)
+    o4.load_state_dict(copy.deepcopy(sd2))
+    for i, (a, b) in enumerate(zip(o3.param_groups[0]['params'], o4.param_groups[0]['params'])):
+        a.grad = synth.normal(tuple(a.shape), f'opt.g{i}', 99).to(DEV)
+        b.grad = a.grad.clone()
+    o3.step()
+    o4.step()
+    for a, b in zip(o3.param_groups[0]['params'], o4.param_groups[0]['params']):
+        assert float((a.detach() - b.detach()).abs().max() / a.detach().abs().max()) < 1e-6
+
+
+def test_multi_tensor_ema_matches_reference_formula():
+    from transeditor_amd.optim import MultiTensorEMA
+    from transeditor_amd.train_step import accumulate
+
+    class M(torch.nn.Module):
+        def __init__(self, seed):
+            super().__init__()
+            self.ps = torch.nn.ParameterList(_params(seed, SHAPES))
+    a, b = M(3), M(4)
+    ref = [p.detach().clone() for p in a.parameters()]
+    decay = 0.5 ** (32 / (10 * 1000))
+    ema = MultiTensorEMA(a, b)
+    for _ in range(3):
+        ema.update(decay)
+        for r, q in zip(ref, b.parameters()):
+            r.mul_(decay).add_(q.detach(), alpha=1 - decay)                  # par1.mul_(decay).add_(1 - decay, par2)
+    for p, r in zip(a.parameters(), ref):
+        assert float((p.detach() - r).abs().max() / r.abs().max()) < 1e-6
+    accumulate(a, b, 0)                                                      # decay 0: plain copy (train_spatial_query.py:455)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+
+
+def test_fused_adam_rejects_cpu_parameters():
+    from transeditor_amd.optim import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match='GPU'):
+        FusedAdam([p], lr=0.1).step()

@@ -52,6 +52,8 @@ _SIGNATURES = {
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    'te_mt_adam_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
+    'te_mt_ema_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -392,3 +394,17 @@ def attn_bwd(go, gsim, q, k, v, sim, scale, groups):
                                  _ptr(gsim.contiguous()) if gsim is not None else None, _ptr(q), _ptr(k), _ptr(v),
                                  _ptr(sim), scale, N, groups, M, L, Cn // groups, _stream()), 'te_attn_bwd_f32')
     return gq, gk, gv
+
+
+# --------------------------------------------------------------------------------------------- T2
+def mt_adam(table, chunks, n_tensors, n_chunks, chunk_elems, lr, beta1, beta2, eps, step):
+    """table: int64 device tensor [5, n]; chunks: int32 device tensor [2, n_chunks] (see te_hip.h)"""
+    _on_current_device(table)
+    _check(lib().te_mt_adam_f32(table.data_ptr(), chunks.data_ptr(), n_tensors, n_chunks, chunk_elems, lr, beta1, beta2, eps,
+                                step, _stream()), 'te_mt_adam_f32')
+
+
+def mt_ema(table, chunks, n_tensors, n_chunks, chunk_elems, decay):
+    _on_current_device(table)
+    _check(lib().te_mt_ema_f32(table.data_ptr(), chunks.data_ptr(), n_tensors, n_chunks, chunk_elems, float(decay), _stream()),
+           'te_mt_ema_f32')

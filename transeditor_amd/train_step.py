@@ -18,11 +18,12 @@ import math
 from types import SimpleNamespace
 
 import torch
-from torch import autograd, optim
+from torch import autograd
 from torch.nn import functional as F
 
 from .model_spatial_query import Discriminator, Generator
 from .op.modconv import no_weight_grads, second_order
+from .optim import FusedAdam, MultiTensorEMA
 from .utils import distributed as D
 from .utils.sample import prepare_noise_new, prepare_param
 
@@ -65,13 +66,9 @@ def requires_grad(model, flag=True):
         p.requires_grad = flag
 
 
-def accumulate(model1, model2, decay=0.999):                                 # :56-61, as one fused multi-tensor update
-    p1 = dict(model1.named_parameters())
-    p2 = dict(model2.named_parameters())
-    names = list(p1.keys())
-    with torch.no_grad():
-        torch._foreach_mul_([p1[k] for k in names], decay)
-        torch._foreach_add_([p1[k] for k in names], [p2[k] for k in names], alpha=1 - decay)
+def accumulate(model1, model2, decay=0.999):                                 # :56-61, as ONE multi-tensor launch
+    """model1 <- decay * model1 + (1 - decay) * model2 over all parameters (te_mt_ema_f32)."""
+    MultiTensorEMA(model1, model2).update(decay)
 
 
 class RandomSampler:
@@ -102,9 +99,12 @@ class TrainStep:
         accumulate(self.g_ema, self.generator, 0)                            # :455
         g_ratio = args.g_reg_every / (args.g_reg_every + 1)
         d_ratio = args.d_reg_every / (args.d_reg_every + 1)
-        self.g_optim = optim.Adam(self.generator.parameters(), lr=args.lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
-        self.d_optim = optim.Adam(self.discriminator.parameters(), lr=args.lr * d_ratio,
-                                  betas=(0 ** d_ratio, 0.99 ** d_ratio))
+        # :458-473 — Adam with the lazy-regularisation ratios; one kernel launch per step (optim.FusedAdam keeps
+        # torch.optim.Adam's state layout, so g_optim / d_optim checkpoints interchange)
+        self.g_optim = FusedAdam(self.generator.parameters(), lr=args.lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
+        self.d_optim = FusedAdam(self.discriminator.parameters(), lr=args.lr * d_ratio,
+                                 betas=(0 ** d_ratio, 0.99 ** d_ratio))
+        self._ema = MultiTensorEMA(self.g_ema, self.generator)
         self.sampler = sampler if sampler is not None else RandomSampler(args, device)
         self.mean_path_length = 0
         self.mean_path_length_avg = 0
@@ -182,5 +182,5 @@ class TrainStep:
         self.g_step()
         if i % a.g_reg_every == 0:
             self.path_step()
-        accumulate(self.g_ema, self.generator, self.accum)
+        self._ema.update(self.accum)                                         # :294
         return D.reduce_loss_dict(self.loss)
