@@ -12,26 +12,26 @@ namespace {
 
 constexpr int THREADS = 256;
 
-__device__ __forceinline__ float adam_elem(float& p, float g, float& m, float& v, bool has_m, float lr_step, float beta1,
-                                           float beta2, float eps, float bc2_sqrt) {
+struct AdamK {       // scalar prefactors, formed in double on the host (as torch.optim.Adam does) and applied in fp32
+    float lr_step, beta1, beta2, w1, w2, eps, bc2_sqrt;      // w1 = 1 - beta1, w2 = 1 - beta2
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, bool has_m, const AdamK& k) {
     // torch.optim.Adam (non-amsgrad, no weight decay), same operation order:
     //   m = lerp(m, g, 1 - beta1);  v = v * beta2 + (1 - beta2) * g * g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-    const float w = 1.f - beta1;
     float mm;
     if (!has_m) mm = g;                                   // beta1 == 0: lerp weight 1 returns g exactly
-    else mm = (w < 0.5f) ? m + w * (g - m) : g - (g - m) * (1.f - w);
-    float vv = v * beta2;
-    vv = vv + (1.f - beta2) * g * g;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    p = p - lr_step * (mm / denom);
+    else mm = (k.w1 < 0.5f) ? m + k.w1 * (g - m) : g - (g - m) * (1.f - k.w1);
+    float vv = v * k.beta2;
+    vv = vv + k.w2 * g * g;
+    const float denom = sqrtf(vv) / k.bc2_sqrt + k.eps;
+    p = p - k.lr_step * (mm / denom);
     m = mm;
     v = vv;
-    return p;
 }
 
 __global__ __launch_bounds__(THREADS) void mt_adam_kernel(const int64_t* __restrict__ table, const int32_t* __restrict__ chunks,
-                                                           int n, int n_chunks, int chunk_elems, float lr_step, float beta1,
-                                                           float beta2, float eps, float bc2_sqrt) {
+                                                           int n, int n_chunks, int chunk_elems, const AdamK k) {
     const int c = blockIdx.x;
     const int t = chunks[c];
     const int64_t off = (int64_t)chunks[n_chunks + c] * chunk_elems;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(THREADS) void mt_adam_kernel(const int64_t* __restr
     float* v = reinterpret_cast<float*>(table[3 * n + t]);
     const int64_t numel = table[4 * n + t];
     if (g == nullptr) return;                              // parameter without gradient this step: skipped, as torch does
-    const bool has_m = beta1 != 0.f;
+    const bool has_m = k.beta1 != 0.f;
     const int64_t len = min((int64_t)chunk_elems, numel - off);
     p += off; g += off; m += off; v += off;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -53,23 +53,23 @@ __global__ __launch_bounds__(THREADS) void mt_adam_kernel(const int64_t* __restr
             const float4 G = reinterpret_cast<const float4*>(g)[i];
             float4 M = has_m ? reinterpret_cast<float4*>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 V = reinterpret_cast<float4*>(v)[i];
-            adam_elem(P.x, G.x, M.x, V.x, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
-            adam_elem(P.y, G.y, M.y, V.y, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
-            adam_elem(P.z, G.z, M.z, V.z, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
-            adam_elem(P.w, G.w, M.w, V.w, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
+            adam_elem(P.x, G.x, M.x, V.x, has_m, k);
+            adam_elem(P.y, G.y, M.y, V.y, has_m, k);
+            adam_elem(P.z, G.z, M.z, V.z, has_m, k);
+            adam_elem(P.w, G.w, M.w, V.w, has_m, k);
             reinterpret_cast<float4*>(p)[i] = P;
             reinterpret_cast<float4*>(m)[i] = M;
             reinterpret_cast<float4*>(v)[i] = V;
         }
         for (int64_t i = (n4 << 2) + threadIdx.x; i < len; i += THREADS) {
             float P = p[i], M = has_m ? m[i] : 0.f, V = v[i];
-            adam_elem(P, g[i], M, V, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
+            adam_elem(P, g[i], M, V, has_m, k);
             p[i] = P; m[i] = M; v[i] = V;
         }
     } else {
         for (int64_t i = threadIdx.x; i < len; i += THREADS) {
             float P = p[i], M = has_m ? m[i] : 0.f, V = v[i];
-            adam_elem(P, g[i], M, V, has_m, lr_step, beta1, beta2, eps, bc2_sqrt);
+            adam_elem(P, g[i], M, V, has_m, k);
             p[i] = P; m[i] = M; v[i] = V;
         }
     }
@@ -111,10 +111,11 @@ extern "C" int te_mt_adam_f32(const int64_t* table, const int32_t* chunks, int n
     // scalar prefactors in double, as torch.optim.Adam computes them on the host
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float lr_step = (float)(lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    mt_adam_kernel<<<n_chunks, THREADS, 0, (hipStream_t)stream_>>>(table, chunks, n_tensors, n_chunks, chunk_elems, lr_step, (float)beta1,
-                                                                   (float)beta2, (float)eps, bc2_sqrt);
+    AdamK k;
+    k.lr_step = (float)(lr / bc1);
+    k.bc2_sqrt = (float)sqrt(bc2);
+    k.beta1 = (float)beta1; k.beta2 = (float)beta2; k.w1 = (float)(1.0 - beta1); k.w2 = (float)(1.0 - beta2); k.eps = (float)eps;
+    mt_adam_kernel<<<n_chunks, THREADS, 0, (hipStream_t)stream_>>>(table, chunks, n_tensors, n_chunks, chunk_elems, k);
     return te::launch_status("te_mt_adam_f32");
 }
 
