@@ -181,6 +181,23 @@ int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, cons
                       float* arowsum, float rs_scale, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
                       int64_t sbj, float alpha, float beta, int act, te_stream_t stream);
 
+/* the same GEMM for WIDE reductions (reference: the discriminator's EqualLinear(8192, 512, 'fused_lrelu'),
+ * model_spatial_query.py:831-834): K is split into S chunks (K % S == 0, (K / S) % 8 == 0) that run as S x tiles blocks,
+ * partial tiles go to the caller's workspace ws[S][I][J], a second kernel sums them in a fixed order and applies the
+ * epilogue (deterministic, no atomics).  C / pre / residual are dense [I, J]. */
+int te_small_gemm_splitk_f32(float* c, float* pre, float* ws, int S, const float* a, const float* b, const float* bias,
+                             const float* residual, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk, int64_t sbj,
+                             float alpha, float beta, int act, te_stream_t stream);
+
+/* D1  minibatch standard deviation + channel concat of the discriminator (reference: Discriminator.forward,
+ * model_spatial_query.py:844-852) as one launch: with n = B / group, sample b = g * n + j belongs to set j;
+ *   s_j = mean over the C*HW positions of sqrt(var_g x[g*n + j] + eps)      (biased variance over the `group` samples)
+ *   y[b, :C] = x[b];  y[b, C, :] = s_{b mod n}                              x [B, C, HW], y [B, C + 1, HW]
+ * backward: gx = gy[:, :C] + d s / d x * (sum of gy[:, C] over the set).  group <= 4, B % group == 0. */
+int te_minibatch_stddev_fwd_f32(float* y, const float* x, int B, int group, int C, int HW, float eps, te_stream_t stream);
+int te_minibatch_stddev_bwd_f32(float* gx, const float* gy, const float* x, int B, int group, int C, int HW, float eps,
+                                te_stream_t stream);
+
 /* A2  parameter-free layer norm over whole samples (reference: AttentionBlock.forward, model_spatial_query.py:924 / 931,
  * F.layer_norm(x, x.size()[1:]), eps 1e-5): x / y / g / gx are [R, N] rows; stats [R, 2] = (mean, rstd) saved for the
  * backward  gx = rstd * (g - mean(g) - y * mean(g * y)).  N % 4 == 0, N <= 16384, 16-byte aligned rows. */

@@ -252,12 +252,13 @@ def gen_generator(M):
         del g
 
 
-def gen_discriminator(M):
-    dmod = M.Discriminator(64)
+def gen_discriminator(M, size=64):
+    """size 64: small fixture; size 256: the discriminator of BASELINE configs[2] (the architecture bench.py times)"""
+    dmod = M.Discriminator(size)
     synth.fill_state_dict(dmod.state_dict(), 5)
     P = {k: v.detach() for k, v in dmod.state_dict().items()}
-    img = synth.normal((4, 3, 64, 64), 'd.img').clamp(-1, 1).requires_grad_(True)
-    fake = synth.normal((4, 3, 64, 64), 'd.fake').clamp(-1, 1)
+    img = synth.normal((4, 3, size, size), 'd.img').clamp(-1, 1).requires_grad_(True)
+    fake = synth.normal((4, 3, size, size), 'd.fake').clamp(-1, 1)
     pred = dmod(img)
     fpred = dmod(fake)
     gr, = torch.autograd.grad(pred.sum(), img, create_graph=True)
@@ -266,10 +267,10 @@ def gen_discriminator(M):
     gs = torch.autograd.grad(10 / 2 * r1 * 16 + 0 * pred[0], list(dmod.parameters()), allow_unused=True, retain_graph=True)
     dl = F.softplus(-pred).mean() + F.softplus(fpred).mean()
     gl = F.softplus(-fpred).mean()
-    po = O.discriminator_forward(P, img, 64)
-    note('discriminator64.pred', rel_err(po, pred))
-    note('discriminator64.r1', abs(float(O.d_r1_loss(po, img)) - float(r1)) / float(r1))
-    npz('discriminator64_b4', pred=pred, fake_pred=fpred, r1=r1, d_loss=dl, g_loss=gl,
+    po = O.discriminator_forward(P, img, size)
+    note(f'discriminator{size}.pred', rel_err(po, pred))
+    note(f'discriminator{size}.r1', abs(float(O.d_r1_loss(po, img)) - float(r1)) / float(r1))
+    npz(f'discriminator{size}_b4', pred=pred, fake_pred=fpred, r1=r1, d_loss=dl, g_loss=gl,
         r1_grad_norms=np.array([0.0 if t is None else float(t.double().norm()) for t in gs]),
         r1_grad_names=np.array(names))
 
@@ -440,6 +441,7 @@ def main():
     gen_ops(M)
     gen_generator(M)
     gen_discriminator(M)
+    gen_discriminator(M, 256)
     gen_train_step(M)
     gen_train_grads(M)
     with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:

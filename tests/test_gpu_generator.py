@@ -152,16 +152,20 @@ def test_latent_gradient_conditioning():
         assert e_hip < 8 * max(e_cpu, 2e-5), (name, e_cpu, e_hip)
 
 
-def test_discriminator_golden(golden):
+@pytest.mark.parametrize('size', [64, 256])
+def test_discriminator_golden(golden, size):
+    """D1 against the reference's own Discriminator (fixtures from oracle/gen_golden.py::gen_discriminator): prediction, R1
+    and the R1 parameter-gradient norms (double backward); 256 px = the discriminator of BASELINE configs[2].  Every
+    compute op of the forward is a te_* kernel (convolutions, minibatch stddev, both final linears)."""
     from transeditor_amd.model_spatial_query import Discriminator
-    gold = golden('discriminator64_b4')
-    D = Discriminator(64)
+    gold = golden(f'discriminator{size}_b4')
+    D = Discriminator(size)
     sd = D.state_dict()
     synth.fill_state_dict(sd, 5)
     D.load_state_dict(sd)
     D = D.to(DEV)
-    img = synth.normal((4, 3, 64, 64), 'd.img').clamp(-1, 1).to(DEV).requires_grad_(True)
-    fake = synth.normal((4, 3, 64, 64), 'd.fake').clamp(-1, 1).to(DEV)
+    img = synth.normal((4, 3, size, size), 'd.img').clamp(-1, 1).to(DEV).requires_grad_(True)
+    fake = synth.normal((4, 3, size, size), 'd.fake').clamp(-1, 1).to(DEV)
     pred, fpred = D(img), D(fake)
     assert rel_err(pred, gold['pred']) < TOL and rel_err(fpred, gold['fake_pred']) < TOL
     r1 = O.d_r1_loss(pred, img)

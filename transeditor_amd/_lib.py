@@ -52,6 +52,9 @@ _SIGNATURES = {
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    'te_small_gemm_splitk_f32': (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
+    'te_minibatch_stddev_fwd_f32': (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    'te_minibatch_stddev_bwd_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'te_mt_adam_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     'te_mt_ema_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, _P]),
 }
@@ -293,6 +296,34 @@ def small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alph
                                    rowsum_scale if rowsum_scale is not None else 0.0, I, J, K, sai, sak, sbk, sbj, alpha,
                                    beta, act, _stream()), 'te_small_gemm_f32')
     return c, pre, rs
+
+
+def small_gemm_splitk(I, J, K, S, a, sai, sak, b, sbk, sbj, bias=None, residual=None, alpha=1.0, beta=1.0, act=0, want_pre=False):
+    """small_gemm for wide reductions: K in S chunks over the grid, fixed-order second pass (see te_hip.h)."""
+    c = torch.empty(I, J, device=a.device, dtype=a.dtype)
+    pre = torch.empty_like(c) if want_pre else None
+    ws = torch.empty(S, I, J, device=a.device, dtype=a.dtype)
+    _check(lib().te_small_gemm_splitk_f32(_ptr(c), _ptr(pre), _ptr(ws), S, _raw(a), _raw(b), _ptr(bias), _ptr(residual), I, J, K,
+                                          sai, sak, sbk, sbj, alpha, beta, act, _stream()), 'te_small_gemm_splitk_f32')
+    return c, pre
+
+
+def minibatch_stddev_fwd(x, group, eps):
+    """x [B, C, H, W] -> y [B, C + 1, H, W] (input copied, stddev channel appended)"""
+    x = x.contiguous()
+    B, Cn, H, W = x.shape
+    y = torch.empty(B, Cn + 1, H, W, device=x.device, dtype=x.dtype)
+    _check(lib().te_minibatch_stddev_fwd_f32(_ptr(y), _ptr(x), B, group, Cn, H * W, eps, _stream()), 'te_minibatch_stddev_fwd_f32')
+    return y
+
+
+def minibatch_stddev_bwd(gy, x, group, eps):
+    gy = gy.contiguous()
+    B, Cn, H, W = x.shape
+    gx = torch.empty_like(x)
+    _check(lib().te_minibatch_stddev_bwd_f32(_ptr(gx), _ptr(gy), _ptr(x), B, group, Cn, H * W, eps, _stream()),
+           'te_minibatch_stddev_bwd_f32')
+    return gx
 
 
 def small_gemm_batched(c, a, b, bias, nz, za, zc, I, J, K, sai, sak, sbk, sbj, sci, scj, zb=0, zbias=0, b_tab=None,

@@ -10,6 +10,7 @@
 // block of 1-16 waves owns one 32x32 output tile, the waves split K and combine through LDS.  Operands whose
 // reduction index is contiguous are read 16 bytes per lane (one load feeds 4 MFMAs).
 #include "te_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -124,6 +125,24 @@ __global__ __launch_bounds__(NW * 64) void small_gemm_kernel(const LinArgs p) {
     }
 }
 
+// second pass of the split-K form: c = act(alpha * sum_s ws[s] + beta * bias) + residual  (fixed summation order)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ c, float* __restrict__ pre, const float* __restrict__ ws,
+                                                            const float* __restrict__ bias, const float* __restrict__ residual, int S,
+                                                            int I, int J, float alpha, float beta, int act) {
+    const int64_t total = (int64_t)I * J;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int q = 0; q < S; ++q) v += ws[(int64_t)q * total + e];
+        v *= alpha;
+        if (bias) v += bias[e % J] * beta;
+        if (pre) pre[e] = v;
+        if (act == 1) v = gelu_erf(v);
+        else if (act == 3) v = (v > 0.f ? v : v * 0.2f) * 1.4142135623730951f;
+        if (residual) v += residual[e];
+        c[e] = v;
+    }
+}
+
 template <int NW>
 void launch_nw(const LinArgs& p, bool av, bool bv, dim3 grid, hipStream_t s) {
     if (av && bv) small_gemm_kernel<NW, true, true><<<grid, NW * 64, 0, s>>>(p);
@@ -189,4 +208,28 @@ extern "C" int te_small_gemm_batched_f32(float* c, const float* a, const float* 
     }
     launch_small_gemm(p, nz, (hipStream_t)stream_);
     return te::launch_status("te_small_gemm_batched_f32");
+}
+
+/* wide reductions (the discriminator's 8192 -> 512 linear, model_spatial_query.py:831-834): K is cut into S chunks that run
+ * as the z dimension of the same kernel (S x tiles blocks instead of `tiles`), partial tiles go to the caller's workspace
+ * ws[S][I][J], a second tiny kernel sums them in fixed order and applies the epilogue.  Deterministic, no atomics. */
+extern "C" int te_small_gemm_splitk_f32(float* c, float* pre, float* ws, int S, const float* a, const float* b, const float* bias,
+                                        const float* residual, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
+                                        int64_t sbj, float alpha, float beta, int act, te_stream_t stream_) {
+    TE_REQUIRE(c && ws && a && b, TE_ERR_NULL, "te_small_gemm_splitk_f32: NULL pointer");
+    TE_REQUIRE(I > 0 && J > 0 && K > 0 && S > 0, TE_ERR_SHAPE, "te_small_gemm_splitk_f32: bad dims");
+    TE_REQUIRE(K % S == 0 && (K / S) % 8 == 0, TE_ERR_SHAPE, "te_small_gemm_splitk_f32: K must split into S chunks of a multiple of 8");
+    TE_REQUIRE(act == 0 || act == 1 || act == 3, TE_ERR_UNSUPPORTED, "te_small_gemm_splitk_f32: act must be 0, 1 or 3");
+    const int Kc = K / S;
+    LinArgs p{};
+    p.c = ws; p.a = a; p.b = b;
+    p.I = I; p.J = J; p.K = Kc; p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj; p.sci = J; p.scj = 1;
+    p.alpha = 1.f; p.beta = 0.f; p.act = 0;
+    p.za = (int64_t)Kc * sak; p.zb = (int64_t)Kc * sbk; p.zc = (int64_t)I * J;
+    hipStream_t s = (hipStream_t)stream_;
+    launch_small_gemm(p, S, s);
+    const int64_t total = (int64_t)I * J;
+    splitk_finish_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 4), 256, 0, s>>>(c, pre, ws, bias, residual, S, I, J,
+                                                                                                     alpha, beta, act);
+    return te::launch_status("te_small_gemm_splitk_f32");
 }

@@ -29,7 +29,8 @@ from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
 from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused
-from .op.modconv import modconv
+from .op.modconv import modconv, _STATE as _modconv_state
+from .op.stddev import minibatch_stddev
 from .op.style import demod
 from .op.token_mlp import token_mlp
 
@@ -519,11 +520,9 @@ class Discriminator(nn.Module):                                                 
 
     def forward(self, input):
         out = self.convs(input)
-        batch, channel, height, width = out.shape
-        group = min(batch, self.stddev_group)
-        sd = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
-        sd = torch.sqrt(sd.var(0, unbiased=False) + 1e-8).mean([2, 3, 4], keepdims=True).squeeze(2)
-        out = torch.cat([out, sd.repeat(group, 1, height, width)], 1)
+        batch = out.shape[0]
+        # :844-852 minibatch stddev + concat: one launch (op/stddev.py)
+        out = minibatch_stddev(out, self.stddev_group, self.stddev_feat, second_order=_modconv_state['second_order'])
         out = self.final_conv(out)
         return self.final_linear(out.view(batch, -1))
 

@@ -15,7 +15,15 @@ from torch.autograd import Function
 from .. import _lib
 
 _ACT = {None: 0, 'gelu': 1, 'lrelu': 3}
-MAX_K = 1024          # beyond this a library GEMM with split-K is the better tool (discriminator's 8192-wide linear)
+MAX_K = 1024          # widest reduction of the single-pass kernel; beyond it the split-K form (discriminator's 8192-wide linear)
+
+
+def _ksplit(K):
+    """number of K chunks for the split-K form: chunks of <= 1024 that are multiples of 8, or 0 if K does not split"""
+    for S in range(-(-K // MAX_K), 65):
+        if K % S == 0 and (K // S) % 8 == 0:
+            return S
+    return 0
 
 
 def _torch_expr(x, weight, bias, alpha, beta, act, residual):
@@ -40,8 +48,12 @@ class _Linear(Function):
         N, K = weight.shape
         x2 = _rows(x, K)
         res2 = None if residual is None else residual.reshape(-1, N).contiguous()
-        y, pre, _ = _lib.small_gemm(x2.shape[0], N, K, x2, x2.stride(0), 1, weight.contiguous(), 1, K, bias, res2, alpha, beta,
-                                 _ACT[act], want_pre=(act == 'gelu'))
+        if K > MAX_K:       # wide reduction: K chunks over the grid + fixed-order second pass (deterministic)
+            y, pre = _lib.small_gemm_splitk(x2.shape[0], N, K, _ksplit(K), x2, x2.stride(0), 1, weight.contiguous(), 1, K, bias, res2,
+                                            alpha, beta, _ACT[act], want_pre=(act == 'gelu'))
+        else:
+            y, pre, _ = _lib.small_gemm(x2.shape[0], N, K, x2, x2.stride(0), 1, weight.contiguous(), 1, K, bias, res2, alpha, beta,
+                                        _ACT[act], want_pre=(act == 'gelu'))
         ctx.save_for_backward(x, weight, bias, residual, pre if act == 'gelu' else (y if act == 'lrelu' else None))
         ctx.cfg = (alpha, beta, act)
         return y.reshape(*x.shape[:-1], N)
@@ -75,7 +87,9 @@ class _Linear(Function):
             if R <= MAX_K:
                 gw, _, gb = _lib.small_gemm(N, K, R, g, 1, N, x2, x2.stride(0), 1, alpha=alpha,
                                             rowsum_scale=beta if want_b else None)
-            else:       # tall reductions (adjust_style: 8192 rows): library GEMM with split-K
+            elif _ksplit(R):       # tall reductions (adjust_style: 8192 rows): the split-K form of the same kernel
+                gw, _ = _lib.small_gemm_splitk(N, K, R, _ksplit(R), g, 1, N, x2, x2.stride(0), 1, alpha=alpha)
+            else:
                 gw = torch.mm(g.t(), x2 if x2.is_contiguous() else x2.contiguous())
                 gw = gw * alpha if alpha != 1.0 else gw
         if want_b and gb is None:
@@ -85,8 +99,8 @@ class _Linear(Function):
 
 
 def linear_fused(x, weight, bias=None, alpha=1.0, beta=1.0, act=None, residual=None):
-    """act in (None, 'gelu', 'lrelu'); falls back to the torch expression for very wide reductions."""
-    if weight.shape[1] > MAX_K or not (x.is_cuda and x.dtype == torch.float32):
+    """act in (None, 'gelu', 'lrelu'); reductions wider than MAX_K run the split-K form of the same kernel."""
+    if (weight.shape[1] > MAX_K and not _ksplit(weight.shape[1])) or not (x.is_cuda and x.dtype == torch.float32):
         if not x.is_cuda:
             raise RuntimeError('te_hip: expected a contiguous fp32 tensor on the GPU (no CPU path exists)')
         return _torch_expr(x, weight, bias, alpha, beta, act, residual)
