@@ -52,9 +52,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 16; 4 at --size 1024)')
-    ap.add_argument('--workload', choices=['train', 'generator'], default='train',
+    ap.add_argument('--workload', choices=['train', 'generator', 'sample'], default='train',
                     help='train = BASELINE configs[2]/[3], the full G+D iteration (default, = the metric); '
-                         'generator = configs[1] / configs[4] generator fwd+bwd only')
+                         'generator = configs[1] / configs[4] generator fwd+bwd only; sample = the inference-only pipeline '
+                         '(frozen g_ema sampling loop, test_spatial_query.py:20-31)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-sub', action='store_true', help='skip the sub-benchmarks (configs[1], configs[4])')
@@ -370,6 +371,47 @@ def run_generator(size, B, steps, warmup, dev, world, rank, timer, G=None):
     return elapsed, roof
 
 
+def run_sampling(args, size, B, dev, base):
+    """(f.3) the reference's sample_generation loop (test_spatial_query.py:20-31): a frozen generator under no_grad,
+    fixed batch, fresh latents every iteration.  Three ways: the training-path forward, the frozen-weight cache, and the
+    cache + hipGraph replay (inference.GeneratorSampler)."""
+    from transeditor_amd.inference import GeneratorSampler
+    from transeditor_amd.model_spatial_query import Generator
+    token = 2 * (int(math.log2(size)) - 1)
+    torch.manual_seed(1234)
+    G = Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).to(dev).eval()
+    n = args.steps + args.warmup
+    zs = [torch.randn(B, 512, 16, device=dev) * 0.7 for _ in range(n)]
+    p = torch.randn(B, 512, 16, device=dev) * 0.7
+
+    def timed(fn):
+        for i in range(args.warmup):
+            fn(zs[i], p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            fn(zs[args.warmup + i], p)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def plain(z, q):
+        with torch.no_grad():
+            return G(z, q)
+    t_plain = timed(plain)
+    t_cache = timed(GeneratorSampler(G, use_graph=False))
+    t_graph = timed(GeneratorSampler(G, use_graph=True))
+    out = dict(base, metric=f'{size}x{size} images/sec/GPU, frozen generator sampling loop (inference-only pipeline)',
+               value=B * args.steps / t_graph, ms_per_step=1e3 * t_graph / args.steps,
+               config={'workload': f'FFHQ-{size} g_ema sampling loop (test_spatial_query.py:20-31), batch {B}, no_grad, '
+                                   f'{args.steps} batches = {B * args.steps} samples', 'global_batch': B, 'parallelism': 'dp1'},
+               sampling={'training_path_forward_img_s': B * args.steps / t_plain,
+                         'frozen_weight_cache_img_s': B * args.steps / t_cache,
+                         'cache_plus_hipgraph_img_s': B * args.steps / t_graph,
+                         'ms_per_batch': {'training_path': 1e3 * t_plain / args.steps, 'cache': 1e3 * t_cache / args.steps,
+                                          'graph': 1e3 * t_graph / args.steps}})
+    print(json.dumps(out), flush=True)
+
+
 class SubstepClock:
     """HIP events around the four sub-steps of TrainStep.iteration (wraps the bound methods)."""
 
@@ -468,6 +510,10 @@ def main():
         timer.install()
     base = {'metric': METRIC, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+
+    if args.workload == 'sample':
+        run_sampling(args, size, B if args.batch is not None else 8, dev, base)
+        return
 
     if args.workload == 'generator':
         elapsed, roof = run_generator(size, B, args.steps, args.warmup, dev, world, rank, timer)

@@ -229,6 +229,7 @@ int te_small_gemm_batched_f32(float* c, const float* a, const float* b, const fl
  *   wsq[co,ci] = wscale^2 sum_t w[co,ci,t]^2            (output, kept for the backward)
  *   d[b,co]    = rsqrt(sum_ci s[b,ci]^2 wsq[co,ci] + eps)
  * backward, u = -gd d^3 / 2:  gw[co,ci,t] = 2 wscale^2 w sum_b u[b,co] s[b,ci]^2,  gs[b,ci] = 2 s sum_co u[b,co] wsq[co,ci]
+ * T == 0 in the forward: `w` already IS wsq[Co,Ci] (kept by the host for frozen weights), wsq output unused (may be NULL).
  * (gw / gs may be NULL; B <= 64 in the backward).  w [Co,Ci,T], s [B,Ci], d / gd [B,Co].  accumulate != 0: the results are
  * ADDED to gw / gs (which then hold the convolution's own dW / d style from te_wgrad_reduce_f32).
  */

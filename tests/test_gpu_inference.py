@@ -1,0 +1,82 @@
+"""(f.3) inference-only pipeline: frozen-weight cache + hipGraph replay of the generator forward against the golden
+vectors of the reference (tests/golden/generator64_flags.npz) and against the eager training-path forward."""
+import pytest
+import torch
+
+from conftest import rel_err
+from test_oracle_golden import generator_state
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def g64():
+    g, sd = generator_state(64, 0)
+    g.load_state_dict(sd)
+    return g.to(DEV)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_sampler_matches_reference_fixtures(golden, g64, use_graph):
+    """kwarg combinations of the reference's sampling scripts (test_spatial_query.py:20-31,
+    our_interfaceGAN/edit_all_noinversion_ffhq.py:103-130) through the sampler."""
+    from transeditor_amd.inference import GeneratorSampler
+    gold = golden('generator64_flags')
+    S = GeneratorSampler(g64, use_graph=use_graph)
+    zz, pp = (t.to(DEV) for t in synth.latents(2, 1001))
+    for _ in range(2):                                    # second pass = cached weights / graph replay
+        out = S(zz, pp)
+        assert isinstance(out, tuple) and len(out) == 3 and out[1] is None and out[2] is None
+        assert rel_err(out[0], gold['img_default']) < TOL
+        assert rel_err(S(zz, pp, return_only_mapped_p=True), gold['mapped_p']) < 1e-4
+        assert rel_err(S(zz, pp, return_only_mapped_z=True), gold['mapped_z']) < 1e-4
+        mz, mp = gold['mapped_z'].to(DEV), gold['mapped_p'].to(DEV)
+        assert rel_err(S(mz, mp, use_style_mapping=False, use_spatial_mapping=False)[0], gold['img_nomap']) < TOL
+        img, lat = S(zz, pp, return_style=True)
+        assert rel_err(lat, gold['ret_style_latent']) < TOL and rel_err(img, gold['img_default']) < TOL
+
+
+def test_sampler_graph_replay_equals_eager_and_tracks_weight_updates(g64):
+    from transeditor_amd.inference import GeneratorSampler
+    import copy
+    G = copy.deepcopy(g64)
+    S = GeneratorSampler(G, use_graph=True)
+    for seed in (1, 2, 3):                                # replays with fresh latents
+        z, p = (t.to(DEV) for t in synth.latents(4, 3000 + seed))
+        with torch.no_grad():
+            want = G(z, p)[0]
+        got = S(z, p)[0]
+        assert rel_err(got, want) < 1e-5, seed
+    assert len(S._graphs) == 1
+    # an autograd-visible weight update invalidates cache and graphs; the next call re-captures with the new weights
+    with torch.no_grad():
+        G.convs[1].conv.weight.mul_(1.5)
+        G.to_rgbs[0].conv.weight.add_(0.1)
+    with torch.no_grad():
+        want = G(z, p)[0]
+    got = S(z, p)[0]
+    assert rel_err(got, want) < 1e-5
+    # ... and an update behind autograd's back (.data, as the reference's accumulate does) needs refresh()
+    G.convs[1].conv.weight.data.mul_(0.5)
+    S.refresh()
+    with torch.no_grad():
+        want = G(z, p)[0]
+    assert rel_err(S(z, p)[0], want) < 1e-5
+
+
+def test_optimizer_kernels_bump_parameter_versions():
+    """FusedAdam / EMA write parameters through raw pointers: they must advance the version counters the frozen-weight
+    cache (and autograd's saved-tensor checks) rely on."""
+    from transeditor_amd.optim import FusedAdam, MultiTensorEMA
+    a, b = torch.nn.Linear(8, 8).to(DEV), torch.nn.Linear(8, 8).to(DEV)
+    v0 = a.weight._version
+    a.weight.grad = torch.ones_like(a.weight)
+    a.bias.grad = torch.ones_like(a.bias)
+    FusedAdam(a.parameters(), lr=0.1).step()
+    assert a.weight._version > v0
+    v1 = b.weight._version
+    MultiTensorEMA(b, a).update(0.5)
+    assert b.weight._version > v1

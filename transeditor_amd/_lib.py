@@ -390,6 +390,15 @@ def demod_fwd(w, s, wscale, eps):
     return d, wsq
 
 
+def demod_from_wsq(wsq, s, eps):
+    """d [B,Co] from a cached wsq [Co,Ci] (frozen weights: the 9-tap squares are not recomputed)"""
+    Co, Ci = wsq.shape
+    B = s.shape[0]
+    d = torch.empty(B, Co, device=wsq.device, dtype=wsq.dtype)
+    _check(lib().te_demod_fwd_f32(_ptr(d), None, _ptr(wsq), _ptr(s), 1.0, eps, B, Co, Ci, 0, _stream()), 'te_demod_fwd_f32')
+    return d
+
+
 def demod_bwd(gd, d, w, wsq, s, wscale, want_w=True, want_s=True, into=None):
     """into = (gw, gs): accumulate into these existing gradients (either may be None) instead of allocating new ones."""
     Co, Ci, T = w.shape

@@ -25,15 +25,19 @@ __global__ __launch_bounds__(256) void demod_fwd_kernel(float* __restrict__ d, f
     const int co = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* wr = w + (size_t)co * Ci * T;
     const float ws2 = wscale * wscale;
-    for (int ci = tid; ci < Ci; ci += 256) {
-        float a = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float v = wr[(size_t)ci * T + t];
-            a += v * v;
+    if (T == 0) {                                         // w already holds wsq[Co, Ci] (cached for frozen weights)
+        for (int ci = tid; ci < Ci; ci += 256) wq[ci] = w[(size_t)co * Ci + ci];
+    } else {
+        for (int ci = tid; ci < Ci; ci += 256) {
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float v = wr[(size_t)ci * T + t];
+                a += v * v;
+            }
+            a *= ws2;
+            wq[ci] = a;
+            wsq[(size_t)co * Ci + ci] = a;
         }
-        a *= ws2;
-        wq[ci] = a;
-        wsq[(size_t)co * Ci + ci] = a;
     }
     __syncthreads();
     for (int b = wid; b < B; b += 4) {                    // one wave per sample: no block barrier in the loop
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(256) void demod_bwd_s_kernel(float* __restrict__ gs
 
 extern "C" int te_demod_fwd_f32(float* d, float* wsq, const float* w, const float* s, float wscale, float eps, int B, int Co,
                                 int Ci, int T, te_stream_t stream_) {
-    TE_REQUIRE(d && wsq && w && s, TE_ERR_NULL, "te_demod_fwd_f32: NULL pointer");
-    TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && T > 0, TE_ERR_SHAPE, "te_demod_fwd_f32: bad dims");
+    TE_REQUIRE(d && w && s && (wsq || T == 0), TE_ERR_NULL, "te_demod_fwd_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && T >= 0, TE_ERR_SHAPE, "te_demod_fwd_f32: bad dims");
     TE_REQUIRE(Ci <= 8192, TE_ERR_UNSUPPORTED, "te_demod_fwd_f32: Ci <= 8192");
     demod_fwd_kernel<<<Co, 256, sizeof(float) * Ci, (hipStream_t)stream_>>>(d, wsq, w, s, wscale, eps, B, Co, Ci, T);
     return te::launch_status("te_demod_fwd_f32");

@@ -62,6 +62,51 @@ def no_weight_grads():
         _STATE['skip_w'] = old
 
 
+# Frozen-weight cache (inference-only pipeline): inside `frozen_weights()` a forward that needs no gradient
+# reuses the packed weight layout and the demodulation squares wsq[Co,Ci] of every layer instead of re-deriving them from
+# the [Co,Ci,k,k] parameter on every call.  Opt-in because weights can be rewritten behind autograd's back (the reference's
+# accumulate() goes through `.data`, train_spatial_query.py:60-61, which does not touch the version counter): whoever opens
+# the context promises the weights stay put (inference.GeneratorSampler); an entry is still re-validated against the
+# parameter's version counter and storage address.
+_FROZEN = {'on': False, 'cache': None}
+
+
+@contextlib.contextmanager
+def frozen_weights(cache):
+    """`cache`: a dict owned by the caller (lives as long as the weights it describes)."""
+    old = (_FROZEN['on'], _FROZEN['cache'])
+    _FROZEN['on'], _FROZEN['cache'] = True, cache
+    try:
+        yield
+    finally:
+        _FROZEN['on'], _FROZEN['cache'] = old
+
+
+def _frozen_entry(w, kind, wscale, want_wsq):
+    base = w._base if w._base is not None else w
+    key = (id(base), w.data_ptr(), tuple(w.shape), kind, float(wscale))
+    stamp = (base._version, base.data_ptr())
+    ent = _FROZEN['cache'].get(key)
+    if ent is None or ent['stamp'] != stamp:
+        ent = {'stamp': stamp, 'wp': _lib.conv_pack(w, _lib.PACK_FWD, wscale), 'wsq': None, 'keep': base}
+        _FROZEN['cache'][key] = ent
+    if want_wsq and ent['wsq'] is None:
+        w3 = w.reshape(w.shape[0], w.shape[1], -1)
+        ent['wsq'] = (w3 * wscale).square().sum(dim=2).contiguous()
+    return ent
+
+
+def _modconv_frozen(x, w, isc, osc, bias, act, kind, wscale, demod_eps):
+    """forward only, weights taken from the frozen cache (no autograd node is created)"""
+    ent = _frozen_entry(w, kind, wscale, demod_eps is not None)
+    if demod_eps is not None:
+        osc = _lib.demod_from_wsq(ent['wsq'], isc, demod_eps)
+    if kind == '1x1' and osc is None and not act and _lib.rgb_supported(w.shape[0], w.shape[1], x.shape[2] * x.shape[3]):
+        return _lib.rgb_fwd(x, w.reshape(w.shape[0], w.shape[1]), isc, bias, wscale)
+    H, W = _lowres_hw(kind, False, x)
+    return _lib.conv(x, ent['wp'], _KIND[kind], w.shape[0], H, W, isc, osc, bias, _act_code(act))
+
+
 _KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2, 'down': _lib.CONV_S2}
 
 
@@ -305,4 +350,6 @@ def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1
         return _composite(x, w, isc, osc, bias, act, kind, float(wscale))
     isc = isc.contiguous() if isc is not None else None
     osc = osc.contiguous() if osc is not None else None
+    if _FROZEN['on'] and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, isc, osc, bias))):
+        return _modconv_frozen(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
     return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)

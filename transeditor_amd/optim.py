@@ -119,6 +119,8 @@ class FusedAdam(torch.optim.Optimizer):
                 tab.upload(rows)
                 _lib.mt_adam(tab.dev, tab.chunks, tab.n, tab.n_chunks, CHUNK, float(group['lr']), float(beta1), float(beta2),
                              float(group['eps']), step)
+            # the kernel wrote the parameters through raw pointers: tell autograd / the frozen-weight caches (op/modconv.py)
+            torch.autograd.graph.increment_version(active)
         return loss
 
 
@@ -146,3 +148,4 @@ class MultiTensorEMA:
         t.upload([[a.data_ptr() for a, _ in self.pairs], [b.data_ptr() for _, b in self.pairs],
                   [a.numel() for a, _ in self.pairs]])
         _lib.mt_ema(t.dev, t.chunks, t.n, t.n_chunks, CHUNK, decay)
+        torch.autograd.graph.increment_version([a for a, _ in self.pairs])      # written through raw pointers
