@@ -107,6 +107,14 @@ int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, int kind_b, 
 int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
                 const float* bias, int act, int kind, int B, int K, int M, int H, int W,
                 te_stream_t stream);
+/* Small images (4x4 ... 16x16 layers) split the input-channel loop over the grid so every CU gets work.
+ * te_conv_splitk_count returns the number of splits S of a problem (1 = no split).  te_conv_ws_f32 is te_conv_f32 with
+ * a caller-owned workspace ws[S][B][M][Ho][Wo] (ignored / may be NULL when S == 1): each split writes its own slab and a
+ * second kernel sums them in a fixed order (DETERMINISTIC, no atomics, no memset).  te_conv_f32 itself (no workspace)
+ * combines the splits with atomic adds into a zero-filled `out`: same values up to summation order. */
+int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
+int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
+                   const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 
 /* Weight-gradient correlation, per sample and per pixel chunk ("slabs"), NO modulation applied:
  *   slab[b][s][co][ci][tap] = sum_{pixels of chunk s} g[b,co,p (+) tap] * x[b,ci,p]

@@ -29,6 +29,8 @@ _SIGNATURES = {
     'te_conv_pack_weights_f32': (C.c_int, [_P, _P, _F, _I, _I, _I, _I, _P]),
     'te_conv_pack_weights2_f32': (C.c_int, [_P, _I, _P, _I, _P, _F, _I, _I, _I, _P]),
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
+    'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -216,8 +218,13 @@ def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0):
     x = x.contiguous()
     B, K = x.shape[0], x.shape[1]
     out = torch.empty(conv_out_shape(kind, B, M, H, W), device=x.device, dtype=x.dtype)
-    _check(lib().te_conv_f32(_ptr(out), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias), act, kind, B, K, M, H, W,
-                             _stream()), 'te_conv_f32')
+    S = lib().te_conv_splitk_count(kind, B, K, M, H, W)
+    if S < 1:
+        raise RuntimeError(f'te_conv_splitk_count failed ({S})')
+    # small images split the channel loop over the grid: per-split slabs + fixed-order sum (deterministic, graph-capturable)
+    ws = torch.empty((S,) + tuple(out.shape), device=x.device, dtype=x.dtype) if S > 1 else None
+    _check(lib().te_conv_ws_f32(_ptr(out), _ptr(ws), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias), act, kind, B, K, M, H, W,
+                                _stream()), 'te_conv_ws_f32')
     return out
 
 

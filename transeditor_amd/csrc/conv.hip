@@ -64,6 +64,7 @@ constexpr int NTHREADS = 256;
 
 struct ConvArgs {
     float* out;
+    float* ws;               // split-K partial sums [ksplit][B][M][Ho][Wo] (NULL: accumulate into `out` with atomics)
     const float* in;
     const float* wp;
     const float* isc;
@@ -300,14 +301,20 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
                 const bool ok = cell_ok && m < p.M;
                 float* obase = p.out + ((size_t)bc * p.M + (m < p.M ? m : 0)) * oplane;
-                if (p.ksplit > 1) {      // partial sums: accumulate raw, scale/bias/activation happen in conv_finalize_kernel
+                if (p.ksplit > 1) {      // partial sums, raw: scale / bias / activation happen in conv_finalize_kernel
+                    // with a workspace every split writes its own slab (plain stores, summed in fixed order: deterministic);
+                    // without one the splits meet in `out` through atomics
+                    float* pbase = p.ws ? p.ws + ((size_t)blockIdx.z * p.B * p.M + (size_t)bc * p.M + (m < p.M ? m : 0)) * oplane : obase;
                     if (!IS_T2) {
-                        if (ok) atomicAdd(obase + (size_t)ci * p.Wo + cj, acc[mb][nb][r]);
+                        if (ok) { if (p.ws) pbase[(size_t)ci * p.Wo + cj] = acc[mb][nb][r]; else atomicAdd(pbase + (size_t)ci * p.Wo + cj, acc[mb][nb][r]); }
                     } else {
 #pragma unroll
                         for (int ph = 0; ph < 4; ++ph) {
                             const int Y = 2 * ci + (ph >> 1), X = 2 * cj + (ph & 1);
-                            if (ok && Y < p.Ho && X < p.Wo) atomicAdd(obase + (size_t)Y * p.Wo + X, acc[mb][nb * 4 + ph][r]);
+                            if (ok && Y < p.Ho && X < p.Wo) {
+                                if (p.ws) pbase[(size_t)Y * p.Wo + X] = acc[mb][nb * 4 + ph][r];
+                                else atomicAdd(pbase + (size_t)Y * p.Wo + X, acc[mb][nb * 4 + ph][r]);
+                            }
                         }
                     }
                 } else if (!IS_T2) {
@@ -343,12 +350,19 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     }
 }
 
-// epilogue of the split-K path: out = act(out * osc[b,m] + bias[m])
-__global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ out, const float* __restrict__ osc,
+// epilogue of the split-K path: out = act((sum_z ws[z] | out) * osc[b,m] + bias[m]); the slabs are summed in fixed order
+__global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ out, const float* __restrict__ ws, int ksplit,
+                                                            const float* __restrict__ osc,
                                                             const float* __restrict__ bias, int act, int M, int plane, int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t bm = e / plane;
-        float v = out[e];
+        float v;
+        if (ws) {
+            v = 0.f;
+            for (int z = 0; z < ksplit; ++z) v += ws[(int64_t)z * total + e];
+        } else {
+            v = out[e];
+        }
         if (osc) v *= osc[bm];
         if (bias) v += bias[bm % M];
         if (act >= 3) v = (v > 0.f ? v : v * 0.2f) * (act == 3 ? 1.4142135623730951f : 1.f);
@@ -542,42 +556,61 @@ extern "C" int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, i
     return te::launch_status("te_conv_pack_weights2_f32");
 }
 
-extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
-                           const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
-    TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
-    TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
-    TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
-    hipStream_t s = (hipStream_t)stream_;
-    ConvArgs a{};
-    a.out = out; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
-    a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
+// tile class + split-K plan of a launch (shared by te_conv_splitk_count and the launch itself)
+struct ConvPlan { int tc, ksplit, kchunk; };
+static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
+    ConvPlan pl;
+    const int Kp = roundup(K, KPAD);
     const bool t2k = (kind == TE_CONV_T2);
     int tc = tile_class(M);
+#ifdef TE_EXP_T2_TC1
+    if (t2k && tc == 0) tc = 1;
+#endif
     // transposed conv on small images (<= 1024 of the 64 x 128 tiles): the 64 x 64 tile class fits 3 waves per SIMD and
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
     if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
+    pl.tc = tc;
     const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
-    // split count comes from the real tile geometry of the main region and is shared by every region launch
-    {
-        const bool t2 = (kind == TE_CONV_T2);
-        const int ntile = t2 ? (tc == 1 ? 64 : 128) : ((tc == 0 || (kind == TE_CONV_S2 && tc == 1)) ? 128 : 256);      // cells per block tile of the chosen tile class
-        int rh = H, rw = W;
-        if (t2 && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
-        const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
-        const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * te::cdiv(M, BM);
-        const int stages = a.Kp / KC;
-        int ks = 1;
-        if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
-        a.ksplit = std::max(1, ks);
-        a.kchunk = (int)te::cdiv(stages, a.ksplit) * KC;
-        a.ksplit = (int)te::cdiv(a.Kp, a.kchunk);
-        if (a.ksplit > 1) {
-            const size_t bytes = sizeof(float) * (size_t)B * M * (t2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
-            hipError_t e = hipMemsetAsync(out, 0, bytes, s);
-            if (e != hipSuccess) return te::fail((int)e, "te_conv_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-        }
+    // split count comes from the real tile geometry of the main region and is shared by every region of the launch
+    const int ntile = t2k ? (tc == 1 ? 64 : 128) : ((tc == 0 || (kind == TE_CONV_S2 && tc == 1)) ? 128 : 256);      // cells per block tile of the chosen tile class
+    int rh = H, rw = W;
+    if (t2k && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
+    const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
+    const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * te::cdiv(M, BM);
+    const int stages = Kp / KC;
+    int ks = 1;
+    if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
+    pl.ksplit = std::max(1, ks);
+    pl.kchunk = (int)te::cdiv(stages, pl.ksplit) * KC;
+    pl.ksplit = (int)te::cdiv(Kp, pl.kchunk);
+    return pl;
+}
+
+extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
+    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 3) return TE_ERR_SHAPE;
+    return conv_plan(kind, B, K, M, H, W).ksplit;
+}
+
+extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
+                              const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
+    TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
+    TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
+    TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
+    TE_REQUIRE(kind >= 0 && kind <= 3, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
+    hipStream_t s = (hipStream_t)stream_;
+    ConvArgs a{};
+    a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
+    a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
+    const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
+    const int tc = pl.tc;
+    a.ksplit = pl.ksplit; a.kchunk = pl.kchunk;
+    if (a.ksplit == 1) a.ws = nullptr;
+    if (a.ksplit > 1 && !a.ws) {       // no workspace: the splits accumulate into `out` with atomics (order not fixed)
+        const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
+        hipError_t e = hipMemsetAsync(out, 0, bytes, s);
+        if (e != hipSuccess) return te::fail((int)e, "te_conv_f32: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     int rc = 0;
     switch (kind) {
@@ -597,7 +630,7 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
             const int r[1][4] = {{0, 0, H, W}};
             rc = launch_regions<TE_CONV_S2>(a, r, 1, s, tc);
         } break;
-        case TE_CONV_T2: {
+        default: {      // TE_CONV_T2
             a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
             if (W + 1 <= 16 || H + 1 <= 16) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
@@ -607,14 +640,18 @@ extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const f
                 rc = launch_regions<TE_CONV_T2>(a, r, 3, s, tc);
             }
         } break;
-        default:
-            return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     }
     if (rc) return rc;
-    if (a.ksplit > 1 && (osc || bias || act)) {
+    if (a.ksplit > 1 && (a.ws || osc || bias || act)) {
         const int plane = a.Ho * a.Wo;
         const int64_t total = (int64_t)B * M * plane;
-        conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, osc, bias, act, M, plane, total);
+        conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, a.ws, a.ksplit, osc, bias, act,
+                                                                                                     M, plane, total);
     }
     return te::launch_status("te_conv_f32");
+}
+
+extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,
+                           const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
+    return te_conv_ws_f32(out, nullptr, in, wp, isc, osc, bias, act, kind, B, K, M, H, W, stream_);
 }

@@ -60,10 +60,15 @@ def _check_param(p):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (no weight decay, no amsgrad, not maximize) as one kernel launch per parameter group."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False, **other):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError(f'invalid Adam hyper-parameters lr={lr} betas={betas} eps={eps}')
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if weight_decay or amsgrad or maximize:
+            raise NotImplementedError('FusedAdam covers the reference\'s configuration: no weight decay / amsgrad / maximize')
+        # param_groups carry every key torch.optim.Adam's do, so a state_dict written by either loads into the other
+        defaults = dict(torch.optim.Adam([torch.zeros(1)]).defaults)
+        defaults.update(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False)
+        super().__init__(params, defaults)
         self._tables = {}
 
     def _init_state(self, p):
