@@ -22,25 +22,9 @@
 //        output phases (row parity a, col parity b): phase (a,b) of cell (i,j) is output (2i+a, 2j+b) and
 //        receives only the taps with ky = a (mod 2), kx = b (mod 2) -> 4+2+2+1 = 9 tap-GEMMs per cell,
 //        i.e. exactly the FLOPs of the zero-insertion-free transposed convolution.
-#include "te_common.h"
-#include <stdlib.h>
+#include "conv_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 struct copies lower to memcpy and stay in scratch)
-
-constexpr unsigned OOBH = 0x40000000u;   // "out of bounds" half-offset: any sum containing it exceeds num_records -> load returns 0
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-
-constexpr int KPAD = 16;    // packed weights: K padded to a multiple of 16 (stages take 8 or 16 channels)
-constexpr int MPAD = 128;   // packed weights: M padded to a multiple of 128 (block tiles cover 64 or 128 rows)
 
 // Tile configuration per (kind, tile class TC).  4 waves as WM (along M) x 4/WM (along the cells); each wave owns MBW
 // 32-row M blocks and NBW 32-cell blocks; KC input channels per stage; NSP staging sweeps for the input tile.
@@ -60,7 +44,6 @@ template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NB
 template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
-constexpr int NTHREADS = 256;
 
 struct ConvArgs {
     float* out;
@@ -635,6 +618,11 @@ extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const floa
             if (W + 1 <= 16 || H + 1 <= 16) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
                 rc = launch_regions<TE_CONV_T2>(a, r, 1, s, tc);
+#ifndef TE_EXP_NO_T2P
+            } else if (tc == 0 && a.ksplit == 1) {
+                // large images, wide layers: one phase per block at 3 waves / SIMD (conv_t2p.hip)
+                rc = te_launch_t2p(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
+#endif
             } else {
                 const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row
                 rc = launch_regions<TE_CONV_T2>(a, r, 3, s, tc);

@@ -1,0 +1,25 @@
+// Shared by the convolution kernels (conv.hip, conv_t2p.hip): vector types, buffer-descriptor loads, packed-weight layout.
+#pragma once
+#include "te_common.h"
+#include <stdlib.h>
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (HIP's float4 struct copies lower to memcpy and stay in scratch)
+
+constexpr unsigned OOBH = 0x40000000u;   // "out of bounds" half-offset: any sum containing it exceeds num_records -> load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+constexpr int KPAD = 16;    // packed weights Wp[tap][Kp][Mp]: K padded to a multiple of 16 (stages take 8, 16 or 32 channels)
+constexpr int MPAD = 128;   // ... M padded to a multiple of 128 (block tiles cover 32, 64 or 128 rows)
+constexpr int NTHREADS = 256;
+
+// conv_t2p.hip: single-phase-per-block transposed convolution for images with more than 16 x 16 cells
+int te_launch_t2p(float* out, const float* in, const float* wp, const float* isc, const float* osc, const float* bias, int act,
+                  int B, int K, int M, int H, int W, hipStream_t s);
