@@ -1,24 +1,24 @@
-// F1 (upsampling layers): 3x3 transposed convolution, stride 2, as FOUR single-phase implicit GEMMs.
+// F1 (upsampling layers): 3x3 transposed convolution, stride 2, split by OUTPUT ROW PARITY into two implicit GEMMs.
 //
 // Reference: ModulatedConv2d.forward upsample branch, model_spatial_query.py:310-321 (F.conv_transpose2d(stride=2) on B
 // materialised weight copies).  Output pixel (2i + a, 2j + b) of "cell" (i, j) only receives the taps with ky = a and
 // kx = b (mod 2):
 //     out[2i + a, 2j + b] = sum_{ky in T(a), kx in T(b)} W[ky][kx] * x[i - (ky >> 1), j - (kx >> 1)],   T(0) = {0, 2}, T(1) = {1}
-// i.e. phase (a, b) is a plain correlation with 4 / 2 / 2 / 1 taps.  conv.hip's TE_CONV_T2 kernel keeps all four phase
-// accumulators of a cell block in one wave (8 accumulator tiles = 128 VGPRs -> 256 VGPRs, 2 waves per SIMD, 70 % MFMA
-// utilisation).  Here a BLOCK owns ONE phase: the plain-3x3 tile configuration (128 output channels x 128 cells, 4 waves
-// as 2 x 2, 2 x 2 accumulator tiles = 64 VGPRs, 3 waves per SIMD) with only that phase's taps staged — the same FLOPs,
-// the same register-prefetch pipeline, results interleaved into the (2H+1) x (2W+1) output with stride-2 stores.
-// The four phase blocks of a tile sit next to each other in the grid, so the input tile they all read stays in L2 / MALL.
-// Cells of the last output row / column (i = H or j = W; only the phases with a = 0 / b = 0 reach them) form thin extra
-// regions of the same launch.  Used for images with more than 16 x 16 cells; smaller ones stay on conv.hip's kernel
-// (multi-sample tiles, split-K).
+// conv.hip's TE_CONV_T2 kernel keeps all four phase accumulators of a cell block in one wave (8 accumulator tiles = 128
+// VGPRs -> 256 VGPRs, 2 waves per SIMD, 70 % MFMA utilisation).  Here a BLOCK owns ONE ROW PARITY a: 64 output channels
+// x 128 cells, 4 waves as 2 x 2, per wave 2 cell blocks x 2 column phases = 4 accumulator tiles (64 VGPRs) -> 3 waves per
+// SIMD, and only the 6 (a = 0) or 3 (a = 1) taps of that parity are staged (same FLOPs in total).  The two column phases
+// of a cell are adjacent output pixels, so every lane stores 8 contiguous bytes and a wave writes full 256-byte row
+// segments (a single-phase-per-block variant with stride-2 4-byte stores measured 55 TFLOP/s against 98: partial-line
+// writes).  The two parity blocks of a tile sit next to each other in the grid so the input tile both read stays on chip.
+// Cells of the last output column (j = W) and row (i = H, a = 0 only) form thin extra regions of the same launch.
+// Used for images with more than 16 x 16 cells and >= 96 output channels; everything else stays on conv.hip's kernel.
 #include "conv_common.h"
 
 namespace {
 
-constexpr int BM = 128, NBW = 2, MBW = 2, WN = 2;
-constexpr int MAXREG = 8;
+constexpr int BM = 64, NBW = 2, WN = 2;       // block tile: 64 output channels (2 waves x 32) x 128 cells (2 waves x 2 x 32)
+constexpr int MAXREG = 5;
 
 struct T2pArgs {
     float* out;
@@ -30,9 +30,9 @@ struct T2pArgs {
     int B, K, M, Kp, Mp;
     int Hi, Wi, Ho, Wo;
     int act;
-    int main_tiles;          // tiles of one main region (all four have the same grid); blocks [0, 4 * main_tiles) interleave the phases
+    int main_tiles;          // tiles of one main region (both have the same grid); blocks [0, 2 * main_tiles) interleave the parities
     struct Region {
-        int phase;               // 2 * a + b
+        int phase;               // row parity a
         int ri0, rj0, rh, rw;    // cell region
         int TH, TW, lgTW;
         int tiles_x, tiles_y;
@@ -42,21 +42,20 @@ struct T2pArgs {
     int nreg;
 };
 
-template <int A, int B> struct Phase {
-    static constexpr int NY = A ? 1 : 2, NX = B ? 1 : 2, NT = NY * NX;
-#ifndef T2P_KC4
-#define T2P_KC4 8
-#define T2P_KC2 16
+#ifndef T2P_KC0
+#define T2P_KC0 16
 #define T2P_KC1 16
 #endif
-    static constexpr int KC = NT == 1 ? T2P_KC1 : (NT == 2 ? T2P_KC2 : T2P_KC4);     // channels per stage (register budget: 168 VGPRs)
-    static constexpr int ky(int t) { return A ? 1 : 2 * (t / NX); }
-    static constexpr int kx(int t) { return B ? 1 : 2 * (t % NX); }
+template <int A> struct Phase {
+    static constexpr int NY = A ? 1 : 2, NT = NY * 3;                  // taps of this row parity
+    static constexpr int KC = A ? T2P_KC1 : T2P_KC0;                   // channels per stage
+    static constexpr int ky(int t) { return A ? 1 : 2 * (t / 3); }
+    static constexpr int kx(int t) { return t % 3; }
 };
 
-template <int A, int B, bool HAS_ISC>
+template <int A, bool HAS_ISC>
 __device__ __forceinline__ void t2p_body(const T2pArgs& p, const T2pArgs::Region& g, int t, float* smem) {
-    using P = Phase<A, B>;
+    using P = Phase<A>;
     constexpr int NT = P::NT, KC = P::KC;
     constexpr int WSTAGE = NT * KC * BM;
     constexpr int WLDR = WSTAGE / 4 / NTHREADS;
@@ -94,13 +93,13 @@ __device__ __forceinline__ void t2p_body(const T2pArgs& p, const T2pArgs::Region
         const int ty = c >> g.lgTW, tx = c & (g.TW - 1);
         boff[nb] = (ty < g.TH ? (ty + 1) * g.TIW + tx + 1 : g.TIW + 1) + half * g.CS;     // cells beyond the tile: any valid address
     }
-    const int aoff = half * BM + wm * (MBW * 32) + l31;
+    const int aoff = half * BM + wm * 32 + l31;
 
-    f32x16 acc[MBW][NBW];
+    f32x16 acc[NBW][2];          // [cell block][column phase b]
 #pragma unroll
-    for (int i = 0; i < MBW; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int j = 0; j < NBW; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -149,15 +148,14 @@ __device__ __forceinline__ void t2p_body(const T2pArgs& p, const T2pArgs::Region
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int toff = -(P::ky(tt) == 2 ? g.TIW : 0) - (P::kx(tt) == 2 ? 1 : 0);
-                float a[MBW];
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) a[mb] = wl[(tt * KC + kk) * BM + aoff + mb * 32];
+                const float a = wl[(tt * KC + kk) * BM + aoff];
+                constexpr int dummy = 0;
+                (void)dummy;
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
                     const float bv = xl[kk * g.CS + boff[nb] + toff];
-#pragma unroll
-                    for (int mb = 0; mb < MBW; ++mb)
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bv, acc[mb][nb], 0, 0, 0);
+                    const int j = P::kx(tt) == 1 ? 1 : 0;
+                    acc[nb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[nb][j], 0, 0, 0);
                 }
             }
         }
@@ -165,39 +163,52 @@ __device__ __forceinline__ void t2p_body(const T2pArgs& p, const T2pArgs::Region
 
     // ---- epilogue.  C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const size_t oplane = (size_t)p.Ho * p.Wo;
+    const int mbase = m0 + wm * 32 + 4 * half;
+    float sc[16], bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 1.f; bi[r] = 0.f; }
+    if (p.osc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            sc[r] = p.osc[(size_t)b * p.M + (m < p.M ? m : p.M - 1)];
+        }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            bi[r] = p.bias[m < p.M ? m : p.M - 1];
+        }
+    }
+    const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int c = wn * (NBW * 32) + nb * 32 + l31;
         const int ty = c >> g.lgTW, tx = c & (g.TW - 1);
         const int ci = ci0 + ty, cj = cj0 + tx;
         const bool cell_ok = ty < g.TH && ci < g.ri0 + g.rh && cj < g.rj0 + g.rw;
-        const size_t opix = (size_t)(2 * ci + A) * p.Wo + 2 * cj + B;
+        const int X = 2 * cj;
+        const size_t opix = (size_t)(2 * ci + A) * p.Wo + X;
 #pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) {
-            const int mbase = m0 + wm * (MBW * 32) + mb * 32 + 4 * half;
-            float sc[16], bi[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sc[r] = 1.f; bi[r] = 0.f; }
-            if (p.osc) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    sc[r] = p.osc[(size_t)b * p.M + (m < p.M ? m : p.M - 1)];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            float v0 = acc[nb][0][r] * sc[r] + bi[r];
+            float v1 = acc[nb][1][r] * sc[r] + bi[r];
+            if (p.act >= 3) {
+                v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * gain;
+                v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * gain;
             }
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    bi[r] = p.bias[m < p.M ? m : p.M - 1];
+            if (cell_ok && m < p.M) {
+                // the two column phases of a cell are adjacent outputs: one 8-byte store (rows are 2W+1 wide, so the pair
+                // is only 4-byte aligned, which global stores accept)
+                float* dst = p.out + ((size_t)b * p.M + m) * oplane + opix;
+                if (X + 1 < p.Wo) {
+                    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                    *reinterpret_cast<f32x2u*>(dst) = f32x2u{v0, v1};
+                } else {
+                    dst[0] = v0;
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[mb][nb][r] * sc[r] + bi[r];
-                if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
-                if (cell_ok && m < p.M) p.out[((size_t)b * p.M + m) * oplane + opix] = v;
             }
         }
     }
@@ -207,22 +218,18 @@ template <bool HAS_ISC>
 __global__ __launch_bounds__(NTHREADS, 3) void t2p_kernel(const T2pArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int ridx, t;
-    if ((int)blockIdx.x < 4 * p.main_tiles) {          // the four phases of a tile are neighbours in the grid
-        ridx = blockIdx.x & 3;
-        t = blockIdx.x >> 2;
+    if ((int)blockIdx.x < 2 * p.main_tiles) {          // the two parities of a tile are neighbours in the grid
+        ridx = blockIdx.x & 1;
+        t = blockIdx.x >> 1;
     } else {
-        ridx = 4;
-        for (int r = 5; r < p.nreg; ++r)
+        ridx = 2;
+        for (int r = 3; r < p.nreg; ++r)
             if ((int)blockIdx.x >= p.reg[r].first_block) ridx = r;
         t = blockIdx.x - p.reg[ridx].first_block;
     }
     const T2pArgs::Region g = p.reg[ridx];
-    switch (g.phase) {
-        case 0: t2p_body<0, 0, HAS_ISC>(p, g, t, smem); break;
-        case 1: t2p_body<0, 1, HAS_ISC>(p, g, t, smem); break;
-        case 2: t2p_body<1, 0, HAS_ISC>(p, g, t, smem); break;
-        default: t2p_body<1, 1, HAS_ISC>(p, g, t, smem); break;
-    }
+    if (g.phase == 0) t2p_body<0, HAS_ISC>(p, g, t, smem);
+    else t2p_body<1, HAS_ISC>(p, g, t, smem);
 }
 
 inline int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -238,8 +245,7 @@ int fill_region(T2pArgs::Region& g, int phase, int ri0, int rj0, int rh, int rw,
     g.tiles_y = (rh + g.TH - 1) / g.TH;
     g.TIH = g.TH + 1; g.TIW = g.TW + 1;
     g.CS = g.TIH * g.TIW;
-    const int a = phase >> 1, b = phase & 1;
-    const int nt = (a ? 1 : 2) * (b ? 1 : 2), kc = nt == 1 ? T2P_KC1 : (nt == 2 ? T2P_KC2 : T2P_KC4);
+    const int nt = phase ? 3 : 6, kc = phase ? T2P_KC1 : T2P_KC0;
     lds_floats = std::max(lds_floats, (size_t)nt * kc * BM + (size_t)kc * g.CS);
     return g.tiles_x * g.tiles_y;
 }
@@ -256,15 +262,15 @@ int te_launch_t2p(float* out, const float* in, const float* wp, const float* isc
     if ((int64_t)K * H * W * 4 >= (int64_t)OOBH) return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: sample of %d x %dx%d exceeds 1 GiB", K, H, W);
     size_t lds_floats = 0;
     int n = 0;
-    for (int ph = 0; ph < 4; ++ph) {                      // main regions: cells [0,H) x [0,W), identical tile grids
+    for (int ph = 0; ph < 2; ++ph) {                      // main regions: cells [0,H) x [0,W), identical tile grids
         a.main_tiles = fill_region(a.reg[n], ph, 0, 0, H, W, lds_floats) * B;
         a.reg[n].first_block = 0;
         ++n;
     }
-    int nblocks = 4 * a.main_tiles;
-    // last cell column j = W (+ the corner) for the phases with b = 0; last cell row i = H for the phases with a = 0
-    const int thin[4][5] = {{0, 0, W, H + 1, 1}, {2, 0, W, H, 1}, {0, H, 0, 1, W}, {1, H, 0, 1, W}};
-    for (int i = 0; i < 4; ++i) {
+    int nblocks = 2 * a.main_tiles;
+    // last cell column j = W (rows i <= H - a), and for a = 0 the last cell row i = H (the corner belongs to the column)
+    const int thin[3][5] = {{0, 0, W, H + 1, 1}, {1, 0, W, H, 1}, {0, H, 0, 1, W}};
+    for (int i = 0; i < 3; ++i) {
         const int tiles = fill_region(a.reg[n], thin[i][0], thin[i][1], thin[i][2], thin[i][3], thin[i][4], lds_floats) * B;
         a.reg[n].first_block = nblocks;
         nblocks += tiles;
