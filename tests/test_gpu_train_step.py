@@ -132,3 +132,38 @@ def test_train_substep_gradients_before_adam_match_reference(golden):
     check('path', ts.generator, 'g_names')
     w1 = float(sum(p.double().abs().sum() for p in ts.generator.parameters()))
     assert abs(w1 - w0) <= 1e-10 * w0                                          # lr = 0: weights untouched
+
+
+def test_checkpoint_layout_round_trip_and_device_prefetcher(tmp_path):
+    """(f.4) the checkpoint dictionary has the reference's keys (train_spatial_query.py:361-371) and restores a TrainStep so
+    that the next iteration is identical; a 'g_ema'-only dictionary (the published inference checkpoints,
+    test_spatial_query.py:285) loads into the EMA generator; batches arrive on the device through the prefetcher."""
+    from transeditor_amd.train_step import TrainStep, default_args
+    from transeditor_amd.utils.dataset import DevicePrefetcher
+    args = default_args(size=TRAIN_SIZE, batch=2)
+    torch.manual_seed(3)
+    a = TrainStep(args, DEV)
+    reals = [torch.randn(2, 3, TRAIN_SIZE, TRAIN_SIZE).clamp(-1, 1) for _ in range(3)]
+    dev_batches = list(DevicePrefetcher(reals, DEV))
+    assert len(dev_batches) == 3 and all(t.is_cuda for t in dev_batches)
+    assert all(torch.equal(d.cpu(), r) for d, r in zip(dev_batches, reals))
+    a.iteration(1, dev_batches[0])                                  # one D step + one G step: optimiser state exists
+    path = a.save_checkpoint(str(tmp_path), 20000)
+    assert path.endswith('020000.pt')
+    ck = torch.load(path)
+    assert set(ck) == {'g', 'd', 'g_ema', 'g_optim', 'd_optim'}
+    assert set(ck['g_optim']['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    b = TrainStep(args, DEV)
+    assert b.load_checkpoint(path) == 20000
+    for pa, pb in zip(a.generator.parameters(), b.generator.parameters()):
+        assert torch.equal(pa, pb)
+    # identical continuation (same latents): the restored optimiser state drives the same update
+    for ts in (a, b):
+        torch.manual_seed(11)
+        ts.d_step(dev_batches[1])
+    for pa, pb in zip(a.discriminator.parameters(), b.discriminator.parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=1e-7)
+    c = TrainStep(args, DEV)
+    assert c.load_checkpoint({'g_ema': ck['g_ema']}) is None
+    for pa, pc in zip(a.g_ema.parameters(), c.g_ema.parameters()):
+        assert torch.equal(pa, pc)

@@ -619,9 +619,12 @@ extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const floa
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
                 rc = launch_regions<TE_CONV_T2>(a, r, 1, s, tc);
 #ifndef TE_EXP_NO_T2P
-            } else if (tc == 0 && a.ksplit == 1) {
-                // large images, wide layers: one phase per block at 3 waves / SIMD (conv_t2p.hip)
+            } else if (tc == 0 && a.ksplit == 1 && te_t2p_supported(M, H, W)) {
+                // large images, wide layers: body cells on the row-parity kernel at 3 waves / SIMD (conv_t2p.hip), the last
+                // output column (+ corner) and row on this file's kernel
                 rc = te_launch_t2p(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
+                const int r[2][4] = {{0, W, H + 1, 1}, {H, 0, 1, W}};
+                if (!rc) rc = launch_regions<TE_CONV_T2>(a, r, 2, s, tc);
 #endif
             } else {
                 const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row

@@ -173,6 +173,37 @@ class TrainStep:
         self.mean_path_length_avg = D.reduce_sum(self.mean_path_length).item() / D.get_world_size()
         self.loss.update(path=path_loss.detach(), path_length=path_lengths.mean().detach())
 
+    # ---- checkpoints in the reference's layout (train_spatial_query.py:361-371 writes, :478-492 / test_spatial_query.py:285 read)
+    def checkpoint(self):
+        """{'g', 'd', 'g_ema', 'g_optim', 'd_optim'}: the dictionary the reference saves every 10000 iterations."""
+        return {'g': self.generator.state_dict(), 'd': self.discriminator.state_dict(), 'g_ema': self.g_ema.state_dict(),
+                'g_optim': self.g_optim.state_dict(), 'd_optim': self.d_optim.state_dict()}
+
+    def save_checkpoint(self, directory, i):
+        import os
+        path = os.path.join(directory, f'{str(i).zfill(6)}.pt')
+        torch.save(self.checkpoint(), path)
+        return path
+
+    def load_checkpoint(self, ckpt):
+        """`ckpt`: a path or an already loaded dictionary.  Returns the start iteration parsed from the file name (:481-484),
+        or None.  A published inference checkpoint that only holds 'g_ema' loads into the EMA generator alone."""
+        import os
+        start = None
+        if isinstance(ckpt, (str, bytes, os.PathLike)):
+            try:
+                start = int(os.path.splitext(os.path.basename(ckpt))[0])
+            except ValueError:
+                pass
+            ckpt = torch.load(ckpt, map_location=self.device)
+        self.g_ema.load_state_dict(ckpt['g_ema'])
+        if 'g' in ckpt:
+            self.generator.load_state_dict(ckpt['g'])
+            self.discriminator.load_state_dict(ckpt['d'])
+            self.g_optim.load_state_dict(ckpt['g_optim'])
+            self.d_optim.load_state_dict(ckpt['d_optim'])
+        return start
+
     def iteration(self, i, real_img):
         """One iteration `i` of the reference loop on a batch of real images already on the device."""
         a = self.args

@@ -1,0 +1,115 @@
+"""Image data path of the train step: LMDB -> decoded fp32 batch -> device, off the critical path.
+
+Reference: utils/dataset.py:9-45 (`MultiResolutionDataset`: LMDB environment, key f'{resolution}-{index:05d}' -> encoded
+image bytes, 'length' -> sample count, a failed decode falls back to a random other sample) and the loader set-up of
+train_spatial_query.py:511-525 (RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5), `num_workers=0`, so decode and
+the host->device copy sit inside the training iteration there).  Here:
+
+* `MultiResolutionDataset` keeps the reference's name, constructor and key format (a dataset prepared for the reference
+  is read unchanged).  `lmdb` is imported when the dataset is opened (it is not a dependency of the kernels); an already
+  opened environment can be passed instead of a path.
+* `image_transform` is the torchvision-free equivalent of the reference's transform pipeline.
+* `DevicePrefetcher` moves batches to the GPU through pinned memory on a side HIP stream, one batch ahead, so the copy of
+  batch i+1 overlaps the kernels of iteration i (the MI355X train step is GPU-bound: 201 ms per iteration, profiles/).
+"""
+import random
+from io import BytesIO
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def image_transform(flip_probability=0.5):
+    """PIL image -> fp32 [3, H, W] in [-1, 1]: RandomHorizontalFlip -> ToTensor -> Normalize((.5,.5,.5), (.5,.5,.5))."""
+    def run(img):
+        a = np.asarray(img.convert('RGB'), dtype=np.float32)            # [H, W, 3] in 0..255
+        if flip_probability > 0 and random.random() < flip_probability:
+            a = a[:, ::-1]
+        t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1)
+        return t.div_(255.0).sub_(0.5).div_(0.5)
+    return run
+
+
+class MultiResolutionDataset(Dataset):
+    def __init__(self, path, transform, resolution=256):
+        if isinstance(path, (str, bytes)):
+            try:
+                import lmdb
+            except ImportError as e:          # same failure point as the reference's module-level import
+                raise ImportError('MultiResolutionDataset reads an LMDB environment: the `lmdb` package is required') from e
+            self.env = lmdb.open(path, max_readers=32, readonly=True, lock=False, readahead=False, meminit=False)
+        else:
+            self.env = path                   # an opened environment (anything with .begin(write=False) -> txn.get(key))
+        if not self.env:
+            raise IOError('Cannot open lmdb dataset', path)
+        with self.env.begin(write=False) as txn:
+            self.length = int(txn.get('length'.encode('utf-8')).decode('utf-8'))
+        self.resolution = resolution
+        self.transform = transform
+
+    def __len__(self):
+        return self.length
+
+    def key(self, index):
+        return f'{self.resolution}-{str(index).zfill(5)}'.encode('utf-8')      # b'256-00140'
+
+    def __getitem__(self, index):
+        from PIL import Image
+        with self.env.begin(write=False) as txn:
+            img_bytes = txn.get(self.key(index))
+        try:
+            img = Image.open(BytesIO(img_bytes))
+            return self.transform(img)
+        except Exception as e:                # reference behaviour: report, then serve a random other sample
+            print(e)
+            return self.__getitem__(random.randint(0, self.length - 1))
+
+
+def sample_data(loader):
+    """train_spatial_query.py:64-67: cycle over the loader forever."""
+    while True:
+        for batch in loader:
+            yield batch
+
+
+class DevicePrefetcher:
+    """Iterate `batches` (an iterable of CPU tensors) as device tensors, one batch ahead: pinned staging buffer ->
+    asynchronous copy on a side stream -> the consumer's stream waits on the copy's event only."""
+
+    def __init__(self, batches, device):
+        self.it = iter(batches)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self._next = None
+        self._preload()
+
+    def _preload(self):
+        try:
+            cpu = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        if not self.cuda:
+            self._next = (cpu, None)
+            return
+        pinned = cpu if cpu.is_pinned() else cpu.pin_memory()
+        with torch.cuda.stream(self.stream):
+            dev = pinned.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._next = (dev, ev, pinned)        # the pinned buffer stays alive until the copy has been consumed
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        cur = self._next
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(cur[1])
+            cur[0].record_stream(torch.cuda.current_stream(self.device))
+        self._preload()
+        return cur[0]
