@@ -546,9 +546,6 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     const int Kp = roundup(K, KPAD);
     const bool t2k = (kind == TE_CONV_T2);
     int tc = tile_class(M);
-#ifdef TE_EXP_T2_TC1
-    if (t2k && tc == 0) tc = 1;
-#endif
     // transposed conv on small images (<= 1024 of the 64 x 128 tiles): the 64 x 64 tile class fits 3 waves per SIMD and
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
     if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
@@ -618,14 +615,6 @@ extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const floa
             if (W + 1 <= 16 || H + 1 <= 16) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
                 rc = launch_regions<TE_CONV_T2>(a, r, 1, s, tc);
-#ifndef TE_EXP_NO_T2P
-            } else if (tc == 0 && a.ksplit == 1 && te_t2p_supported(M, H, W)) {
-                // large images, wide layers: body cells on the row-parity kernel at 3 waves / SIMD (conv_t2p.hip), the last
-                // output column (+ corner) and row on this file's kernel
-                rc = te_launch_t2p(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
-                const int r[2][4] = {{0, W, H + 1, 1}, {H, 0, 1, W}};
-                if (!rc) rc = launch_regions<TE_CONV_T2>(a, r, 2, s, tc);
-#endif
             } else {
                 const int r[3][4] = {{0, 0, H, W}, {0, W, H + 1, 1}, {H, 0, 1, W}};  // body, last column (+corner), last row
                 rc = launch_regions<TE_CONV_T2>(a, r, 3, s, tc);

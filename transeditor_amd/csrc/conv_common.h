@@ -1,4 +1,4 @@
-// Shared by the convolution kernels (conv.hip, conv_t2p.hip): vector types, buffer-descriptor loads, packed-weight layout.
+// Shared by the convolution kernels: vector types, buffer-descriptor loads, packed-weight layout.
 #pragma once
 #include "te_common.h"
 #include <stdlib.h>
@@ -20,7 +20,3 @@ constexpr int KPAD = 16;    // packed weights Wp[tap][Kp][Mp]: K padded to a mul
 constexpr int MPAD = 128;   // ... M padded to a multiple of 128 (block tiles cover 32, 64 or 128 rows)
 constexpr int NTHREADS = 256;
 
-// conv_t2p.hip: row-parity-per-block transposed convolution (body cells of large, wide layers)
-bool te_t2p_supported(int M, int H, int W);
-int te_launch_t2p(float* out, const float* in, const float* wp, const float* isc, const float* osc, const float* bias, int act,
-                  int B, int K, int M, int H, int W, hipStream_t s);
