@@ -58,8 +58,41 @@ def run(label):
     return res
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'fir' not in sys.argv:
     name = sys.argv[1] if len(sys.argv) > 1 else None
     if name and name != 'product':
         _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', f'libte_{name}.so')
     run(name or 'product')
+
+
+def fir_bench(label):
+    """HBM-bound tail at the FFHQ-256 batch-16 top shapes: blur (+bias+lrelu) 257^2 -> 256^2, adjoint blur 256^2 -> 257^2,
+    backward of blur+bias+lrelu in one pass (AG), bias_act backward; TB/s of ALGORITHMIC bytes (each operand once)."""
+    from oracle import te_oracle as O       # taps only
+    B, C, H = 16, 128, 256
+    k = O.fir_kernel((1, 3, 3, 1), 4.0).to(DEV)
+    kf = torch.flip(k, [0, 1]).contiguous()
+    x = torch.randn(B, C, 2 * (H // 2) + 1, H + 1, device=DEV)
+    bias = torch.randn(C, device=DEV)
+    f1 = lambda: _lib.upfirdn2d_raw(x, k, (1, 1), (1, 1), (1, 1, 1, 1), bias=bias, act=3, alpha=0.2, scale=2 ** 0.5)
+    y = f1()
+    g = torch.randn_like(y)
+    f2 = lambda: _lib.upfirdn2d_raw(g, kf, (1, 1), (1, 1), (2, 2, 2, 2))
+    f3 = lambda: _lib.blur_actgrad(g, y, kf, (2, 2, 2, 2), 0.2, 2 ** 0.5)
+    f4 = lambda: _lib.bias_act_bwd(g, y, 0.2, 2 ** 0.5, want_bias=True)
+    xs = torch.randn(B, C, H, H, device=DEV)
+    f5 = lambda: _lib.upfirdn2d_raw(xs, k, (1, 1), (2, 2), (2, 2, 2, 2))       # D skip branch: blur + keep every 2nd pixel
+    for name, fn, nbytes in (('blur+bias+lrelu 257->256', f1, 4 * (x.numel() + y.numel())),
+                             ('adjoint blur 256->257', f2, 4 * (g.numel() + x.numel())),
+                             ('blur_actgrad (AG) 256->257', f3, 4 * (2 * g.numel() + x.numel())),
+                             ('bias_act_bwd', f4, 4 * 3 * g.numel()),
+                             ('blur-down2 256->128', f5, 4 * (xs.numel() + xs.numel() // 4))):
+        ms = timeit(fn, 20)
+        print(f'[{label}] FIR {name:28s}: {ms * 1e3:8.1f} us  {nbytes / ms / 1e9:6.2f} TB/s algorithmic', flush=True)
+
+
+if __name__ == '__main__' and 'fir' in sys.argv:
+    name = sys.argv[1] if sys.argv[1] != 'fir' else 'product'
+    if name != 'product':
+        _lib.LIB_PATH = os.path.join(ROOT, 'tools', 'exp', f'libte_{name}.so')
+    fir_bench(name)

@@ -230,12 +230,187 @@ void launch_tile(float* out, const float* x, const float* k, const float* b, con
     fir_tile_kernel<UP, DOWN, KH, KW><<<grid, 256, 0, s>>>(out, x, k, b, p);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Blur fast path: up = down = 1, 4 x 4 taps (every Blur of the generator and discriminator, model_spatial_query.py:137-153,
+// and their adjoints), optionally with the activation-gradient prologue (AG, see fir_tile_kernel).  HBM-bound: what it
+// has to get right is the memory pipeline —
+//   * the input tile is fetched as 16-byte loads (buffer_load_dwordx4 at 4-byte alignment: rows of 257 / 129 / ... floats
+//     are not 16-byte aligned, the hardware does not care) from a tile origin rounded DOWN to a multiple of 4 columns, so
+//     a group of four is either entirely left of the image or starts inside it; only the group that straddles the right
+//     edge falls back to guarded 4-byte loads.  4x fewer vector-memory instructions than one dword per lane: at one dword
+//     per lane the texture addresser (64 lanes = 16 cycles per instruction) caps a CU near 16 B/clk, i.e. the chip near
+//     8 TB/s * efficiency, which is where the dword version sat (3.5 - 4.8 TB/s);
+//   * 32 x 64 output tiles (35 x 72 staged elements): 9 % halo rows instead of 19 %;
+//   * LDS rows are 128 floats apart: ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+//     (+32), i.e. 8 lanes of one tile row and 8 lanes of the next; with a row stride that is a multiple of 64 banks the
+//     two rows' 16-byte slots interleave exactly and every read is conflict-free (the old stride of 68 floats was 2-way:
+//     47 - 59 % of LDS cycles were bank conflicts);
+//   * the window of a lane starts D = (tile origin - aligned origin) columns into its aligned 16-byte slots; D is a
+//     launch constant, so it is a template parameter and the window is picked with static register indices.
+constexpr int BOH = 32, BOW = 64;                 // output tile
+constexpr int BIH = BOH + 3, BNQ = 18;            // staged rows, 16-byte groups per row (72 columns >= 3 + 67)
+constexpr int BST = 128;                          // LDS row stride (floats)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool AG, int D>
+__global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ k,
+                                                     const float* __restrict__ b, const FirParams p,
+                                                     const float* __restrict__ ref = nullptr, float* __restrict__ partial = nullptr) {
+    __shared__ __attribute__((aligned(16))) float sx[BIH * BST];
+    __shared__ float sred[4];
+    float kf[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kf[a][c] = k[(3 - a) * 4 + (3 - c)];
+
+    const int ox0 = blockIdx.x * BOW, oy0 = blockIdx.y * BOH;
+    const int ix0 = ox0 - p.pad_x0, iy0 = oy0 - p.pad_y0;      // up = down = 1: mid = o - pad, i0 = mid, taps 0..3
+    const int ax0 = ix0 - D;                                    // multiple of 4 (D = ix0 & 3, the same for every tile)
+    const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
+    const unsigned plane_b = (unsigned)p.in_h * p.in_w * 4u;
+
+    constexpr int NIT = BIH * BNQ, NLD = (NIT + 255) / 256;
+    f32x4v stage[NLD];
+    f32x4v rv[AG ? NLD : 1];
+    // per-item geometry (the same for every plane)
+    unsigned goff[NLD];
+    int lds_off[NLD], kind[NLD];          // kind: 0 nothing, 1 one 16-byte load, 2 guarded 4-byte loads (right edge)
+    int gx_i[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int e = threadIdx.x + 256 * r;
+        const int ry = e / BNQ, q = e - ry * BNQ;
+        const int gy = iy0 + ry, gx = ax0 + 4 * q;
+        lds_off[r] = ry * BST + 4 * q;
+        gx_i[r] = gx;
+        kind[r] = 0;
+        goff[r] = 0;
+        if (e < NIT && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) {
+            kind[r] = (gx + 3 < p.in_w) ? 1 : 2;
+            goff[r] = (unsigned)(gy * p.in_w + gx) * 4u;
+        } else if (e >= NIT) {
+            kind[r] = -1;
+        }
+    }
+    auto load_tile = [&](const float* base, int64_t mj, f32x4v* dst) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)mj * p.in_h * p.in_w), 0, plane_b, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (kind[r] == 1) {
+                v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[r], 0, 0));
+            } else if (kind[r] == 2) {        // the group straddles the right edge of the image
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gx_i[r] + j < p.in_w) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[r] + 4u * j, 0, 0));
+            }
+            dst[r] = v;
+        }
+    };
+    auto fetch = [&](int64_t mj) {
+        load_tile(x, mj, stage);
+        if constexpr (AG) load_tile(ref, mj, rv);
+    };
+    if ((int64_t)blockIdx.z < p.major) fetch(blockIdx.z);
+
+    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+        __syncthreads();                 // the previous plane's filter pass is done with sx / sred
+        if constexpr (AG) {
+            float own = 0.f;
+            const bool last_y = blockIdx.y == gridDim.y - 1, last_x = blockIdx.x == gridDim.x - 1;
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) {
+                const int e = threadIdx.x + 256 * r;
+                const int ry = e / BNQ, q = e - ry * BNQ;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    stage[r][j] *= rv[r][j] > 0.f ? p.scale : p.alpha * p.scale;
+                    const int rx = 4 * q + j - D;                      // column relative to the tile origin
+                    if (kind[r] > 0 && (ry < BOH || last_y) && rx >= 0 && (rx < BOW || last_x)) own += stage[r][j];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) own += __shfl_down(own, o, 64);
+            if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = own;
+        }
+#pragma unroll
+        for (int r = 0; r < NLD; ++r)
+            if (kind[r] >= 0) *reinterpret_cast<f32x4v*>(&sx[lds_off[r]]) = stage[r];
+        __syncthreads();
+        if (mj + gridDim.z < p.major) fetch(mj + gridDim.z);       // in flight during the filter pass below
+        if constexpr (AG) {
+            if (threadIdx.x == 0)
+                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                    (sred[0] + sred[1]) + (sred[2] + sred[3]);
+        }
+        // lane (ty, tx) filters output rows oy0 + 2 ty, oy0 + 2 ty + 1 (they share 3 of their 4 input rows), columns tx..tx+3
+        float res[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[h][q] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const float* row = &sx[(2 * ty + a) * BST + tx];
+            const f32x4v w0 = *reinterpret_cast<const f32x4v*>(row);
+            const f32x4v w1 = *reinterpret_cast<const f32x4v*>(row + 4);
+            const f32x4v w2 = *reinterpret_cast<const f32x4v*>(row + 8);
+            const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ka = a - h;                 // tap row of output row h
+                if (ka < 0 || ka > 3) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) res[h][q] += w[D + q + c] * kf[ka][c];
+            }
+        }
+        const int ch = b ? (int)(mj % p.size_b) : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oy = oy0 + 2 * ty + h;
+            if (oy >= p.out_h) continue;
+            float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
+            if (ox0 + tx + 3 < p.out_w) {      // one 16-byte store per lane (4-byte aligned rows are fine for global stores)
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                f32x4u v;
+                v[0] = epilogue<AG>(res[h][0], b, ch, p); v[1] = epilogue<AG>(res[h][1], b, ch, p);
+                v[2] = epilogue<AG>(res[h][2], b, ch, p); v[3] = epilogue<AG>(res[h][3], b, ch, p);
+                *reinterpret_cast<f32x4u*>(orow + ox0 + tx) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ox = ox0 + tx + q;
+                    if (ox < p.out_w) orow[ox] = epilogue<AG>(res[h][q], b, ch, p);
+                }
+            }
+        }
+    }
+}
+
+template <bool AG>
+void launch_blur44(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s, const float* ref,
+                   float* partial) {
+    const int64_t tiles = te::cdiv(p.out_w, BOW) * te::cdiv(p.out_h, BOH);
+    dim3 grid((unsigned)te::cdiv(p.out_w, BOW), (unsigned)te::cdiv(p.out_h, BOH), (unsigned)fir_planes_z(p.major, 2 * tiles));
+    switch ((-p.pad_x0) & 3) {
+        case 0: blur44_kernel<AG, 0><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
+        case 1: blur44_kernel<AG, 1><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
+        case 2: blur44_kernel<AG, 2><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
+        default: blur44_kernel<AG, 3><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
+    }
+}
+
 }  // namespace
 
 extern "C" int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1) {
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return TE_ERR_SHAPE;
-    return (int)(te::cdiv(ow, TOW) * te::cdiv(oh, TOH));
+    return (int)(te::cdiv(ow, BOW) * te::cdiv(oh, BOH));
 }
 
 extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major,
@@ -256,9 +431,8 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
     p.size_b = 1; p.act = 0; p.alpha = alpha; p.scale = scale;
     if (major == 0) return 0;
     TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_actgrad_f32: too many planes");
-    const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
-    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(major, tiles));
-    fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
+    TE_REQUIRE((int64_t)in_h * in_w * 4 < 0x7FFFFFFF, TE_ERR_UNSUPPORTED, "te_blur_actgrad_f32: plane too large");
+    launch_blur44<true>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
     return te::launch_status("te_blur_actgrad_f32");
 }
 
@@ -284,7 +458,8 @@ extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int6
     if (major == 0) return 0;
     hipStream_t s = (hipStream_t)stream_;
     const bool sq = (up_x == up_y) && (down_x == down_y) && minor == 1;
-    if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1) launch_tile<1, 1, 4, 4>(out, x, k, b, p, s);
+    if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1 && (int64_t)in_h * in_w * 4 < 0x7FFFFFFF)
+        launch_blur44<false>(out, x, k, b, p, s, nullptr, nullptr);
     else if (sq && kh == 4 && kw == 4 && up_x == 2 && down_x == 1) launch_tile<2, 1, 4, 4>(out, x, k, b, p, s);
     else if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 2) launch_tile<1, 2, 4, 4>(out, x, k, b, p, s);
     else {
