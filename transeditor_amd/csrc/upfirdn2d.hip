@@ -275,40 +275,38 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
     constexpr int NIT = BIH * BNQ, NLD = (NIT + 255) / 256;
     f32x4v stage[NLD];
     f32x4v rv[AG ? NLD : 1];
-    // per-item geometry (the same for every plane)
+    // per-item geometry (the same for every plane).  Every item is ONE unconditional 16-byte buffer load (no branch between
+    // the loads of a tile: they are all in flight together): items outside the image get an out-of-range offset (the
+    // hardware returns 0), the group that straddles the right edge is loaded 1-3 columns further left (entirely inside
+    // the row) and shifted into place with selects when the tile is committed.
     unsigned goff[NLD];
-    int lds_off[NLD], kind[NLD];          // kind: 0 nothing, 1 one 16-byte load, 2 guarded 4-byte loads (right edge)
-    int gx_i[NLD];
+    int lds_off[NLD], sh[NLD];            // sh: -1 no item, 0..3 columns the loaded group sits left of its slot
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
         const int e = threadIdx.x + 256 * r;
         const int ry = e / BNQ, q = e - ry * BNQ;
         const int gy = iy0 + ry, gx = ax0 + 4 * q;
         lds_off[r] = ry * BST + 4 * q;
-        gx_i[r] = gx;
-        kind[r] = 0;
-        goff[r] = 0;
+        sh[r] = e < NIT ? 0 : -1;
+        goff[r] = 0x80000000u;
         if (e < NIT && gy >= 0 && gy < p.in_h && gx >= 0 && gx < p.in_w) {
-            kind[r] = (gx + 3 < p.in_w) ? 1 : 2;
-            goff[r] = (unsigned)(gy * p.in_w + gx) * 4u;
-        } else if (e >= NIT) {
-            kind[r] = -1;
+            const int gxs = min(gx, p.in_w - 4);
+            sh[r] = gx - gxs;
+            goff[r] = (unsigned)(gy * p.in_w + gxs) * 4u;
         }
     }
     auto load_tile = [&](const float* base, int64_t mj, f32x4v* dst) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)mj * p.in_h * p.in_w), 0, plane_b, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < NLD; ++r) {
-            f32x4v v = {0.f, 0.f, 0.f, 0.f};
-            if (kind[r] == 1) {
-                v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[r], 0, 0));
-            } else if (kind[r] == 2) {        // the group straddles the right edge of the image
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (gx_i[r] + j < p.in_w) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[r] + 4u * j, 0, 0));
-            }
-            dst[r] = v;
-        }
+        for (int r = 0; r < NLD; ++r) dst[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[r], 0, 0));
+    };
+    auto place = [&](f32x4v L, int s_) {      // v[j] = L[j + s] (0 beyond the group): the right-edge group, shifted into its slot
+        f32x4v v;
+        v[0] = s_ == 0 ? L[0] : (s_ == 1 ? L[1] : (s_ == 2 ? L[2] : L[3]));
+        v[1] = s_ == 0 ? L[1] : (s_ == 1 ? L[2] : (s_ == 2 ? L[3] : 0.f));
+        v[2] = s_ == 0 ? L[2] : (s_ == 1 ? L[3] : 0.f);
+        v[3] = s_ == 0 ? L[3] : 0.f;
+        return v;
     };
     auto fetch = [&](int64_t mj) {
         load_tile(x, mj, stage);
@@ -325,11 +323,13 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
             for (int r = 0; r < NLD; ++r) {
                 const int e = threadIdx.x + 256 * r;
                 const int ry = e / BNQ, q = e - ry * BNQ;
+                stage[r] = place(stage[r], sh[r]);
+                const f32x4v rr = place(rv[r], sh[r]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    stage[r][j] *= rv[r][j] > 0.f ? p.scale : p.alpha * p.scale;
+                    stage[r][j] *= rr[j] > 0.f ? p.scale : p.alpha * p.scale;
                     const int rx = 4 * q + j - D;                      // column relative to the tile origin
-                    if (kind[r] > 0 && (ry < BOH || last_y) && rx >= 0 && (rx < BOW || last_x)) own += stage[r][j];
+                    if (sh[r] >= 0 && (ry < BOH || last_y) && rx >= 0 && (rx < BOW || last_x)) own += stage[r][j];   // 0 outside the image
                 }
             }
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         }
 #pragma unroll
         for (int r = 0; r < NLD; ++r)
-            if (kind[r] >= 0) *reinterpret_cast<f32x4v*>(&sx[lds_off[r]]) = stage[r];
+            if (sh[r] >= 0) *reinterpret_cast<f32x4v*>(&sx[lds_off[r]]) = AG ? stage[r] : place(stage[r], sh[r]);
         __syncthreads();
         if (mj + gridDim.z < p.major) fetch(mj + gridDim.z);       // in flight during the filter pass below
         if constexpr (AG) {
@@ -410,6 +410,7 @@ void launch_blur44(float* out, const float* x, const float* k, const float* b, c
 extern "C" int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1) {
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return TE_ERR_SHAPE;
+    if (in_w < 4) return (int)(te::cdiv(ow, TOW) * te::cdiv(oh, TOH));     // narrower than one 16-byte group: generic tile kernel
     return (int)(te::cdiv(ow, BOW) * te::cdiv(oh, BOH));
 }
 
@@ -432,7 +433,13 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
     if (major == 0) return 0;
     TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_actgrad_f32: too many planes");
     TE_REQUIRE((int64_t)in_h * in_w * 4 < 0x7FFFFFFF, TE_ERR_UNSUPPORTED, "te_blur_actgrad_f32: plane too large");
-    launch_blur44<true>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
+    if (in_w >= 4) {
+        launch_blur44<true>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
+    } else {
+        const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
+        dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(major, tiles));
+        fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
+    }
     return te::launch_status("te_blur_actgrad_f32");
 }
 
@@ -458,7 +465,7 @@ extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int6
     if (major == 0) return 0;
     hipStream_t s = (hipStream_t)stream_;
     const bool sq = (up_x == up_y) && (down_x == down_y) && minor == 1;
-    if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1 && (int64_t)in_h * in_w * 4 < 0x7FFFFFFF)
+    if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1 && in_w >= 4 && (int64_t)in_h * in_w * 4 < 0x7FFFFFFF)
         launch_blur44<false>(out, x, k, b, p, s, nullptr, nullptr);
     else if (sq && kh == 4 && kw == 4 && up_x == 2 && down_x == 1) launch_tile<2, 1, 4, 4>(out, x, k, b, p, s);
     else if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 2) launch_tile<1, 2, 4, 4>(out, x, k, b, p, s);
