@@ -25,6 +25,7 @@ struct FirParams {
     int64_t major;
     int size_b, act;
     float alpha, scale;
+    int ext_x, ext_y;        // blur44: the last tile column / row also covers one extra output column / row
 };
 
 template <bool AG = false>
@@ -249,7 +250,7 @@ void launch_tile(float* out, const float* x, const float* k, const float* b, con
 //   * the window of a lane starts D = (tile origin - aligned origin) columns into its aligned 16-byte slots; D is a
 //     launch constant, so it is a template parameter and the window is picked with static register indices.
 constexpr int BOH = 32, BOW = 64;                 // output tile
-constexpr int BIH = BOH + 3, BNQ = 18;            // staged rows, 16-byte groups per row (72 columns >= 3 + 67)
+constexpr int BIH = BOH + 4, BNQ = 18;            // staged rows (33 output rows: see the +1 rule), 16-byte groups per row (72 columns >= 3 + 68)
 constexpr int BST = 128;                          // LDS row stride (floats)
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -346,34 +347,39 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
                 partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
                     (sred[0] + sred[1]) + (sred[2] + sred[3]);
         }
-        // lane (ty, tx) filters output rows oy0 + 2 ty, oy0 + 2 ty + 1 (they share 3 of their 4 input rows), columns tx..tx+3
-        float res[2][4];
+        // lane (ty, tx) filters output rows oy0 + 2 ty, oy0 + 2 ty + 1 (they share 3 of their 4 input rows), columns tx..tx+3.
+        // The +1 rule: sizes of the form 64 n + 1 / 32 n + 1 (every (2H+1)-sized tensor of the upsampling path) do not get a
+        // tile column / row of their own for the last pixel; the last tile's edge lanes filter a 5th column / 3rd row.
+        const bool xcol = p.ext_x && blockIdx.x == gridDim.x - 1 && tx == BOW - 4;
+        const bool xrow = p.ext_y && blockIdx.y == gridDim.y - 1 && ty == 15;
+        float res[3][5];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 3; ++h)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) res[h][q] = 0.f;
+            for (int q = 0; q < 5; ++q) res[h][q] = 0.f;
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
+        for (int a = 0; a < 6; ++a) {
+            if (a == 5 && !xrow) break;
             const float* row = &sx[(2 * ty + a) * BST + tx];
             const f32x4v w0 = *reinterpret_cast<const f32x4v*>(row);
             const f32x4v w1 = *reinterpret_cast<const f32x4v*>(row + 4);
             const f32x4v w2 = *reinterpret_cast<const f32x4v*>(row + 8);
             const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 3; ++h) {
                 const int ka = a - h;                 // tap row of output row h
                 if (ka < 0 || ka > 3) continue;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 5; ++q)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) res[h][q] += w[D + q + c] * kf[ka][c];
             }
         }
         const int ch = b ? (int)(mj % p.size_b) : 0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 3; ++h) {
             const int oy = oy0 + 2 * ty + h;
-            if (oy >= p.out_h) continue;
+            if (oy >= p.out_h || (h == 2 && !xrow)) continue;
             float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
             if (ox0 + tx + 3 < p.out_w) {      // one 16-byte store per lane (4-byte aligned rows are fine for global stores)
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
                 v[0] = epilogue<AG>(res[h][0], b, ch, p); v[1] = epilogue<AG>(res[h][1], b, ch, p);
                 v[2] = epilogue<AG>(res[h][2], b, ch, p); v[3] = epilogue<AG>(res[h][3], b, ch, p);
                 *reinterpret_cast<f32x4u*>(orow + ox0 + tx) = v;
+                if (xcol) orow[ox0 + tx + 4] = epilogue<AG>(res[h][4], b, ch, p);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -392,16 +399,22 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
     }
 }
 
+inline int blur44_tiles(int n, int t) { return (n > t && n % t == 1) ? n / t : (int)te::cdiv(n, t); }     // the +1 rule
+
 template <bool AG>
 void launch_blur44(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s, const float* ref,
                    float* partial) {
-    const int64_t tiles = te::cdiv(p.out_w, BOW) * te::cdiv(p.out_h, BOH);
-    dim3 grid((unsigned)te::cdiv(p.out_w, BOW), (unsigned)te::cdiv(p.out_h, BOH), (unsigned)fir_planes_z(p.major, 2 * tiles));
+    FirParams q = p;
+    const int tx_n = blur44_tiles(p.out_w, BOW), ty_n = blur44_tiles(p.out_h, BOH);
+    q.ext_x = tx_n * BOW < p.out_w;
+    q.ext_y = ty_n * BOH < p.out_h;
+    const int64_t tiles = (int64_t)tx_n * ty_n;
+    dim3 grid((unsigned)tx_n, (unsigned)ty_n, (unsigned)fir_planes_z(p.major, 2 * tiles));
     switch ((-p.pad_x0) & 3) {
-        case 0: blur44_kernel<AG, 0><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
-        case 1: blur44_kernel<AG, 1><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
-        case 2: blur44_kernel<AG, 2><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
-        default: blur44_kernel<AG, 3><<<grid, 256, 0, s>>>(out, x, k, b, p, ref, partial); break;
+        case 0: blur44_kernel<AG, 0><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+        case 1: blur44_kernel<AG, 1><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+        case 2: blur44_kernel<AG, 2><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+        default: blur44_kernel<AG, 3><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
     }
 }
 
@@ -411,7 +424,7 @@ extern "C" int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad
     const int oh = in_h + pad_y0 + pad_y1 - kh + 1, ow = in_w + pad_x0 + pad_x1 - kw + 1;
     if (oh <= 0 || ow <= 0) return TE_ERR_SHAPE;
     if (in_w < 4) return (int)(te::cdiv(ow, TOW) * te::cdiv(oh, TOH));     // narrower than one 16-byte group: generic tile kernel
-    return (int)(te::cdiv(ow, BOW) * te::cdiv(oh, BOH));
+    return blur44_tiles(ow, BOW) * blur44_tiles(oh, BOH);
 }
 
 extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major,
@@ -422,7 +435,7 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
     TE_REQUIRE(kh == 4 && kw == 4, TE_ERR_UNSUPPORTED, "te_blur_actgrad_f32: 4x4 taps only");
     TE_REQUIRE(pad_x0 >= 0 && pad_x1 >= 0 && pad_y0 >= 0 && pad_y1 >= 0, TE_ERR_UNSUPPORTED,
                "te_blur_actgrad_f32: pads must be >= 0 (every input element has to be staged by some tile)");
-    FirParams p;
+    FirParams p{};
     p.in_h = in_h; p.in_w = in_w;
     p.out_h = in_h + pad_y0 + pad_y1 - kh + 1;
     p.out_w = in_w + pad_x0 + pad_x1 - kw + 1;
@@ -454,7 +467,7 @@ extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int6
     TE_REQUIRE(act == 0 || act == 3, TE_ERR_UNSUPPORTED, "te_upfirdn2d_f32: act must be 0 or 3");
     TE_REQUIRE(!(b || act) || minor == 1, TE_ERR_UNSUPPORTED, "te_upfirdn2d_f32: fused epilogue needs minor == 1");
     TE_REQUIRE(!b || size_b > 0, TE_ERR_SHAPE, "te_upfirdn2d_f32: bias given but size_b <= 0");
-    FirParams p;
+    FirParams p{};
     p.in_h = in_h; p.in_w = in_w;
     p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
     p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
