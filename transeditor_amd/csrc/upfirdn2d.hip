@@ -255,7 +255,7 @@ constexpr int BST = 128;                          // LDS row stride (floats)
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool AG, int D>
+template <bool AG, int D, bool EXT>
 __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ k,
                                                      const float* __restrict__ b, const FirParams p,
                                                      const float* __restrict__ ref = nullptr, float* __restrict__ partial = nullptr) {
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
 #pragma unroll
         for (int r = 0; r < NLD; ++r) dst[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[r], 0, 0));
     };
+    const bool edge_x = ax0 + 4 * BNQ > p.in_w;       // block-uniform: only tiles that reach the right edge hold a shifted group
     auto place = [&](f32x4v L, int s_) {      // v[j] = L[j + s] (0 beyond the group): the right-edge group, shifted into its slot
+        if (!edge_x) return L;
         f32x4v v;
         v[0] = s_ == 0 ? L[0] : (s_ == 1 ? L[1] : (s_ == 2 ? L[2] : L[3]));
         v[1] = s_ == 0 ? L[1] : (s_ == 1 ? L[2] : (s_ == 2 ? L[3] : 0.f));
@@ -350,15 +352,18 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         // lane (ty, tx) filters output rows oy0 + 2 ty, oy0 + 2 ty + 1 (they share 3 of their 4 input rows), columns tx..tx+3.
         // The +1 rule: sizes of the form 64 n + 1 / 32 n + 1 (every (2H+1)-sized tensor of the upsampling path) do not get a
         // tile column / row of their own for the last pixel; the last tile's edge lanes filter a 5th column / 3rd row.
-        const bool xcol = p.ext_x && blockIdx.x == gridDim.x - 1 && tx == BOW - 4;
-        const bool xrow = p.ext_y && blockIdx.y == gridDim.y - 1 && ty == 15;
-        float res[3][5];
+        // (EXT: compiled in only for launches that need it, the extra multiply-adds cost every lane: the kernel is bound by
+        // instruction issue, not by HBM)
+        constexpr int NH = EXT ? 3 : 2, NQ = EXT ? 5 : 4;
+        const bool xcol = EXT && p.ext_x && blockIdx.x == gridDim.x - 1 && tx == BOW - 4;
+        const bool xrow = EXT && p.ext_y && blockIdx.y == gridDim.y - 1 && ty == 15;
+        float res[NH][NQ];
 #pragma unroll
-        for (int h = 0; h < 3; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) res[h][q] = 0.f;
+            for (int q = 0; q < NQ; ++q) res[h][q] = 0.f;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < NH + 3; ++a) {
             if (a == 5 && !xrow) break;
             const float* row = &sx[(2 * ty + a) * BST + tx];
             const f32x4v w0 = *reinterpret_cast<const f32x4v*>(row);
@@ -366,18 +371,18 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
             const f32x4v w2 = *reinterpret_cast<const f32x4v*>(row + 8);
             const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 const int ka = a - h;                 // tap row of output row h
                 if (ka < 0 || ka > 3) continue;
 #pragma unroll
-                for (int q = 0; q < 5; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) res[h][q] += w[D + q + c] * kf[ka][c];
             }
         }
         const int ch = b ? (int)(mj % p.size_b) : 0;
 #pragma unroll
-        for (int h = 0; h < 3; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int oy = oy0 + 2 * ty + h;
             if (oy >= p.out_h || (h == 2 && !xrow)) continue;
             float* orow = out + ((size_t)mj * p.out_h + oy) * p.out_w;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
                 v[0] = epilogue<AG>(res[h][0], b, ch, p); v[1] = epilogue<AG>(res[h][1], b, ch, p);
                 v[2] = epilogue<AG>(res[h][2], b, ch, p); v[3] = epilogue<AG>(res[h][3], b, ch, p);
                 *reinterpret_cast<f32x4u*>(orow + ox0 + tx) = v;
-                if (xcol) orow[ox0 + tx + 4] = epilogue<AG>(res[h][4], b, ch, p);
+                if (EXT && xcol) orow[ox0 + tx + 4] = epilogue<AG>(res[h][NQ - 1], b, ch, p);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -410,11 +415,21 @@ void launch_blur44(float* out, const float* x, const float* k, const float* b, c
     q.ext_y = ty_n * BOH < p.out_h;
     const int64_t tiles = (int64_t)tx_n * ty_n;
     dim3 grid((unsigned)tx_n, (unsigned)ty_n, (unsigned)fir_planes_z(p.major, 2 * tiles));
-    switch ((-p.pad_x0) & 3) {
-        case 0: blur44_kernel<AG, 0><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
-        case 1: blur44_kernel<AG, 1><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
-        case 2: blur44_kernel<AG, 2><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
-        default: blur44_kernel<AG, 3><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+    const int d = (-p.pad_x0) & 3;
+    if (q.ext_x || q.ext_y) {
+        switch (d) {
+            case 0: blur44_kernel<AG, 0, true><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            case 1: blur44_kernel<AG, 1, true><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            case 2: blur44_kernel<AG, 2, true><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            default: blur44_kernel<AG, 3, true><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+        }
+    } else {
+        switch (d) {
+            case 0: blur44_kernel<AG, 0, false><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            case 1: blur44_kernel<AG, 1, false><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            case 2: blur44_kernel<AG, 2, false><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+            default: blur44_kernel<AG, 3, false><<<grid, 256, 0, s>>>(out, x, k, b, q, ref, partial); break;
+        }
     }
 }
 
