@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-KEEP = ('conv_mfma', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'bias_act', 'rgb_')
+KEEP = ('conv_mfma', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
 # algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
 ALG = {
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
@@ -15,6 +15,8 @@ ALG = {
     'conv_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wgrad_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'blur44_kernel<true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),
+    'blur44_kernel<false': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
     'fir_tile_kernel<1, 1, 4, 4, true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),
     'fir_tile_kernel<1, 1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
     'wgrad_reduce_fused': dict(flops=0, bytes=16 * 16 * 128 * 128 * 9 * 4),
@@ -43,7 +45,7 @@ def load(path):
     return agg, dur
 
 
-def main(src='gpurun_out/pmc', tag='profiles/r01'):
+def main(src='gpurun_out/pmc', tag='profiles/r02'):
     mf, dur = load(f'{src}/mfma_counter_collection.csv')
     fe, _ = load(f'{src}/fetch_counter_collection.csv')
     wr, _ = load(f'{src}/write_counter_collection.csv')
