@@ -63,10 +63,37 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// C[16][J] = alpha * A[16][K] W[J][K]^T for the 16-column tiles this wave owns (tile = j0 / 16, tiles go round the waves);
-// epi(row, col, value) is called for the 4 results of every lane.  A lives in LDS (row stride sa), W in global memory.
+// C[16][J] = alpha * A[16][K] W[J][K]^T for the 16-column tiles this wave owns (tiles go round the waves);
+// epi(row, col, value) is called for the 4 results of every lane.  A lives in LDS (row stride sa), W in global memory / L2.
 // Lane t = (lo = t & 15, hi = t >> 4) supplies A[lo][k0 + 4 hi + i] and W[j0 + lo][k0 + 4 hi + i] to MFMA i of a 16-wide k step
-// and receives C[4 hi + r][j0 + lo].  K % 16 == 0, J % 16 == 0.  Two GEMMs can share one accumulator (A2 / W2 / K2 != 0).
+// and receives C[4 hi + r][j0 + lo].  K % 16 == 0, J % 16 == 0.  The kernel is bound by the latency of the weight stream
+// (16 workgroups x 3 MB per block out of L2), so a wave issues the 16-byte loads of CH k-steps back to back before it
+// touches the first one: 8 KB in flight per wave, 128 KB per CU.
+constexpr int CH = 8;
+
+__device__ __forceinline__ void gemm16_acc(f32x4& acc, const float* __restrict__ A, int sa, const float* __restrict__ W, int K, int j0) {
+    const int t = threadIdx.x & 63, lo = t & 15, hi = t >> 4;
+    const float* ar = A + lo * sa + 4 * hi;
+    const float* wr = W + (size_t)(j0 + lo) * K + 4 * hi;
+    for (int kc = 0; kc < K; kc += 16 * CH) {
+        f32x4 b[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int k = kc + 16 * s;
+            b[s] = *reinterpret_cast<const f32x4*>(wr + (k < K ? k : 0));       // clamped: the tail step is skipped below
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int k = kc + 16 * s;
+            if (k < K) {                                                          // wave-uniform
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ar + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[s][i], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <typename Epi>
 __device__ __forceinline__ void gemm16(const float* __restrict__ A, int sa, const float* __restrict__ W, int K, int J, float alpha,
                                        const float* __restrict__ A2, int sa2, const float* __restrict__ W2, int K2, float alpha2,
@@ -76,30 +103,12 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ A, int sa, cons
     if (wid < 0 || wid >= nw) return;
     for (int j0 = wid * 16; j0 < J; j0 += nw * 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        {
-            const float* ar = A + lo * sa + 4 * hi;
-            const float* wr = W + (size_t)(j0 + lo) * K + 4 * hi;
-#pragma unroll 4
-            for (int k0 = 0; k0 < K; k0 += 16) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ar + k0);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wr + k0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
-            }
-        }
+        gemm16_acc(acc, A, sa, W, K, j0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-        if (A2) {
+        if (A2) {                                                                 // a second product into the same tile
             f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-            const float* ar = A2 + lo * sa2 + 4 * hi;
-            const float* wr = W2 + (size_t)(j0 + lo) * K2 + 4 * hi;
-#pragma unroll 4
-            for (int k0 = 0; k0 < K2; k0 += 16) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ar + k0);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wr + k0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc2, 0, 0, 0);
-            }
+            gemm16_acc(acc2, A2, sa2, W2, K2, j0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] += acc2[r] * alpha2;
         }
@@ -301,48 +310,81 @@ struct BwdArgs {
     BlockW blk[MAXBLK];
 };
 
-// out[16][Kout] = alpha * A[16][J] W[J][Kout]  (W row-major [J][ldw]): the data gradient of y = x W^T.  Lane (lo, hi) supplies
-// A[lo][j0 + 4 hi + i] (one 16-byte LDS read) and W[j0 + 4 hi + i][k0 + lo] and receives out[4 hi + r][k0 + lo].
-template <typename Epi>
+// out[16][Kout] = alpha * A[16][J] W[J][Kout]  (W row-major [J][ldw]): the data gradient of y = x W^T, reading W as stored.
+// A wave owns 16 * NQ consecutive output columns as NQ interleaved tiles: lane (lo, hi) loads the NQ consecutive weights
+// W[j0 + hi][kb + NQ lo .. + NQ - 1] (one 4 / 8 / 16-byte load) and feeds value q to the tile of the columns kb + NQ lo + q, with
+// A[lo][j0 + hi] (one LDS read) as the other operand of all NQ MFMAs of the 4-deep j step.  Loads of CHT j steps are issued
+// together.  Kout % 16 == 0 (columns beyond Kout are masked), J % 4 == 0.
+constexpr int CHT = 16;
+
+template <int NQ>
+__device__ __forceinline__ void gemm16_t_acc(f32x4 (&acc)[NQ], const float* __restrict__ A, int sa, const float* __restrict__ W, int ldw,
+                                             int J, int kb, bool valid) {
+    typedef float vq __attribute__((ext_vector_type(NQ == 1 ? 2 : NQ)));          // (NQ == 1 uses element 0 of a dummy pair)
+    const int t = threadIdx.x & 63, lo = t & 15, hi = t >> 4;
+    const float* ar = A + lo * sa + hi;
+    const float* wr = W + (size_t)hi * ldw + kb + NQ * lo;
+    for (int jc = 0; jc < J; jc += 4 * CHT) {
+        float b[CHT][NQ];
+#pragma unroll
+        for (int s = 0; s < CHT; ++s) {
+            const int j = jc + 4 * s;
+            const float* src = wr + (size_t)((j < J && valid) ? j : 0) * ldw;
+            if constexpr (NQ == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(valid ? src : W);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[s][q] = v[q];
+            } else if constexpr (NQ == 2) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 v = *reinterpret_cast<const f32x2*>(valid ? src : W);
+                b[s][0] = v[0]; b[s][1] = v[1];
+            } else {
+                b[s][0] = *(valid ? src : W);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < CHT; ++s) {
+            const int j = jc + 4 * s;
+            if (j < J) {                                                          // wave-uniform
+                const float a = ar[j];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, valid ? b[s][q] : 0.f, acc[q], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NQ, typename Epi>
 __device__ __forceinline__ void gemm16_t(const float* __restrict__ A, int sa, const float* __restrict__ W, int ldw, int J, int Kout,
                                          float alpha, const float* __restrict__ A2, const float* __restrict__ W2, float alpha2, Epi epi) {
     const int t = threadIdx.x & 63, lo = t & 15, hi = t >> 4;
     const int wid = threadIdx.x >> 6;
-    for (int k0 = wid * 16; k0 < Kout; k0 += NWAVES * 16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        {
-            const float* ar = A + lo * sa + 4 * hi;
-            const float* wr = W + (size_t)(4 * hi) * ldw + k0 + lo;
-#pragma unroll 2
-            for (int j0 = 0; j0 < J; j0 += 16) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ar + j0);
-                float b[4];
+    for (int kb = wid * 16 * NQ; kb < Kout; kb += NWAVES * 16 * NQ) {
+        const bool valid = kb + NQ * lo + NQ - 1 < Kout;
+        f32x4 acc[NQ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = wr[(size_t)(j0 + i) * ldw];
+        for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm16_t_acc<NQ>(acc, A, sa, W, ldw, J, kb, valid);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
-            }
-        }
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+            for (int r = 0; r < 4; ++r) acc[q][r] *= alpha;
         if (A2) {
-            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-            const float* ar = A2 + lo * sa + 4 * hi;
-            const float* wr = W2 + (size_t)(4 * hi) * ldw + k0 + lo;
-#pragma unroll 2
-            for (int j0 = 0; j0 < J; j0 += 16) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ar + j0);
-                float b[4];
+            f32x4 acc2[NQ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = wr[(size_t)(j0 + i) * ldw];
+            for (int q = 0; q < NQ; ++q) acc2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm16_t_acc<NQ>(acc2, A2, sa, W2, ldw, J, kb, valid);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc2, 0, 0, 0);
-            }
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += acc2[r] * alpha2;
+                for (int r = 0; r < 4; ++r) acc[q][r] += acc2[q][r] * alpha2;
         }
+        if (valid) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) epi(4 * hi + r, k0 + lo, acc[r]);
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi(4 * hi + r, kb + NQ * lo + q, acc[q][r]);
+        }
     }
 }
 
@@ -403,7 +445,7 @@ __global__ __launch_bounds__(THREADS) void attn_stack_bwd_kernel(const BwdArgs p
         {
             const float* hp = p.s_hpre + sn * T * CO;
             float* gh = p.g_hpre + sn * T * CO;
-            gemm16_t(bufG, SB, w.w2, CO, CO, CO, p.lr_mul * rsqrtf((float)CO), nullptr, nullptr, 0.f, [&](int r, int c, float v) {
+            gemm16_t<2>(bufG, SB, w.w2, CO, CO, CO, p.lr_mul * rsqrtf((float)CO), nullptr, nullptr, 0.f, [&](int r, int c, float v) {
                 v *= gelu_grad(hp[r * CO + c]);
                 bufA[r * SB + c] = v;
                 gh[r * CO + c] = v;
@@ -411,14 +453,14 @@ __global__ __launch_bounds__(THREADS) void attn_stack_bwd_kernel(const BwdArgs p
         }
         __syncthreads();
         // ---- 2. g_xn1 = alpha1 g_hpre W1 -> bufB
-        gemm16_t(bufA, SB, w.w1, CO, CO, CO, p.lr_mul * rsqrtf((float)CO), nullptr, nullptr, 0.f,
+        gemm16_t<2>(bufA, SB, w.w1, CO, CO, CO, p.lr_mul * rsqrtf((float)CO), nullptr, nullptr, 0.f,
                  [&](int r, int c, float v) { bufB[r * SB + c] = v; });
         __syncthreads();
         // ---- 3. g_x1 = g_x2 + LN'(g_xn1) -> bufG ; -> global (dWproj, dWskip)
         layer_norm16_bwd(bufG, true, bufB, p.s_xn1 + sn * T * CO, CO, CO, stats[3], red);
         for (int e = tid; e < T * CO; e += THREADS) p.g_x1[sn * T * CO + e] = bufG[(e / CO) * SB + e % CO];
         // ---- 4. g_o = alpha_p g_x1 Wproj -> bufO ; q, k, v, sim of the forward -> LDS
-        gemm16_t(bufG, SB, w.wp, PL, CO, PL, p.lr_mul * rsqrtf((float)PL), nullptr, nullptr, 0.f,
+        gemm16_t<1>(bufG, SB, w.wp, PL, CO, PL, p.lr_mul * rsqrtf((float)PL), nullptr, nullptr, 0.f,
                  [&](int r, int c, float v) { bufO[r * SS + c] = v; });
         for (int e = tid; e < T * PL; e += THREADS) {
             const int r = e / PL, c = e % PL;
@@ -481,10 +523,10 @@ __global__ __launch_bounds__(THREADS) void attn_stack_bwd_kernel(const BwdArgs p
         // ---- 6. g_xn = alpha (g_k Wk + g_v Wv) -> bufB ;  g_P = alpha_q g_q Wq -> global (summed over the blocks that share P)
         {
             const float alpha = p.lr_mul * rsqrtf((float)C);
-            gemm16_t(bufK, SS, w.wk, C, PL, C, alpha, bufV, w.wv, alpha, [&](int r, int c, float v) { bufB[r * SB + c] = v; });
+            gemm16_t<2>(bufK, SS, w.wk, C, PL, C, alpha, bufV, w.wv, alpha, [&](int r, int c, float v) { bufB[r * SB + c] = v; });
             float* gpp = (bi == 0 ? p.gp0 : p.gp) + (size_t)n * T * CP;
             const bool first = (bi == 0) || (bi == p.nblocks - 1);
-            gemm16_t(bufQ, SS, w.wq, CP, PL, CP, p.lr_mul * rsqrtf((float)CP), nullptr, nullptr, 0.f, [&](int r, int c, float v) {
+            gemm16_t<2>(bufQ, SS, w.wq, CP, PL, CP, p.lr_mul * rsqrtf((float)CP), nullptr, nullptr, 0.f, [&](int r, int c, float v) {
                 if (first) gpp[r * CP + c] = v;
                 else gpp[r * CP + c] += v;
             });
@@ -493,7 +535,7 @@ __global__ __launch_bounds__(THREADS) void attn_stack_bwd_kernel(const BwdArgs p
         // ---- 7. gradient w.r.t. the block input: LN'(g_xn) + (g_x1 W0 alpha0 | g_x1) -> bufA, which becomes the next bufG
         layer_norm16_bwd(bufA, false, bufB, p.s_xn + sn * T * 528, 528, C, stats[1], red);
         if (C != CO) {
-            gemm16_t(bufG, SB, w.w0, C, CO, C, p.lr_mul * rsqrtf((float)C), nullptr, nullptr, 0.f,
+            gemm16_t<2>(bufG, SB, w.w0, C, CO, C, p.lr_mul * rsqrtf((float)C), nullptr, nullptr, 0.f,
                      [&](int r, int c, float v) { bufA[r * SB + c] += v; });
         } else {
             for (int e = tid; e < T * CO; e += THREADS) bufA[(e / CO) * SB + e % CO] += bufG[(e / CO) * SB + e % CO];
