@@ -5,7 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from transeditor_amd import synth                              # noqa: E402
+from transeditor_amd import synth, _lib                        # noqa: E402
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'exp', f'libte_{sys.argv[1]}.so')
 from transeditor_amd.model_spatial_query import AttentionBlock  # noqa: E402
 from transeditor_amd.op import attn_stack as A                  # noqa: E402
 
@@ -44,4 +46,5 @@ def fb(f):
 
 
 print(f'fused  : fwd {timeit(lambda: fwd(A.attention_stack)):8.1f} us   fwd+bwd {timeit(lambda: fb(A.attention_stack)):8.1f} us')
-print(f'single : fwd {timeit(lambda: fwd(A._composite)):8.1f} us   fwd+bwd {timeit(lambda: fb(A._composite)):8.1f} us')
+if len(sys.argv) <= 1:
+    print(f'single : fwd {timeit(lambda: fwd(A._composite)):8.1f} us   fwd+bwd {timeit(lambda: fb(A._composite)):8.1f} us')

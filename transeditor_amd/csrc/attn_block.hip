@@ -8,10 +8,10 @@
 //     x1 = Lproj(o) + (Lskip(x) if C != 512 else x)
 //     x2 = L2(GELU(L1(LN(x1)))) + x1
 // The unfused form is ~26 launches per block (7 us GEMMs, layer norms, attention core, residual adds): 0.2 % of the FLOPs
-// but most of the step's dispatches.  Here a sample's activations never leave the CU: a 1024-thread workgroup keeps
+// but most of the step's dispatches.  Here a sample's activations never leave the CU: a 512-thread workgroup keeps
 // x / xn / x1 / h (16 x 528 fp32 each) and q / k / v / o (16 x 128) in LDS (147 KB of the 160 KB), streams every weight
 // matrix once from L2 straight into MFMA B operands (v_mfma_f32_16x16x4_f32, exact fp32; a wave owns 16-column tiles of
-// the output and reads 16 bytes per lane and load), runs the layer norms as workgroup reductions and the attention core
+// the output and reads 16 bytes per lane and load, 16 loads in flight per wave), runs the layer norms as workgroup reductions and the attention core
 // on four of its waves, and walks through all n_trans blocks.  What the backward needs (normalised inputs, q/k/v/o, the
 // attention matrix, x1, the pre-GELU activations, LN statistics) is written to caller-provided save buffers.
 // LDS rows are 584 / 136 floats apart (= 8 mod 64): the 16-byte A-operand reads of the 16 x 4 lane grid are conflict-free.
@@ -22,7 +22,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int THREADS = 1024, NWAVES = THREADS / 64;
+constexpr int THREADS = 512, NWAVES = THREADS / 64;     // 8 waves = 2 per SIMD: 256 VGPRs each for the in-flight weight loads
 constexpr int T = 16;                 // tokens
 constexpr int CO = 512;               // block output width
 constexpr int PL = 128;               // planes (q / k / v width), 4 heads x 32
@@ -69,7 +69,11 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // and receives C[4 hi + r][j0 + lo].  K % 16 == 0, J % 16 == 0.  The kernel is bound by the latency of the weight stream
 // (16 workgroups x 3 MB per block out of L2), so a wave issues the 16-byte loads of CH k-steps back to back before it
 // touches the first one: 8 KB in flight per wave, 128 KB per CU.
-constexpr int CH = 8;
+#ifndef TE_ATT_CH
+#define TE_ATT_CH 16
+#define TE_ATT_CHT 16
+#endif
+constexpr int CH = TE_ATT_CH;
 
 __device__ __forceinline__ void gemm16_acc(f32x4& acc, const float* __restrict__ A, int sa, const float* __restrict__ W, int K, int j0) {
     const int t = threadIdx.x & 63, lo = t & 15, hi = t >> 4;
@@ -183,17 +187,17 @@ __global__ __launch_bounds__(THREADS) void attn_stack_fwd_kernel(const StackArgs
         __syncthreads();
         // ---- xn = LN(x) -> bufN
         layer_norm16(bufN, bufX, C, p.eps, red, p.s_xn ? p.s_xn + sn * T * 528 : nullptr, 528, p.s_stats ? p.s_stats + sn * 4 : nullptr);
-        // ---- k, v = Lk(xn), Lv(xn): waves 0-7 take k, waves 8-15 take v
+        // ---- k, v = Lk(xn), Lv(xn): the first half of the waves takes k, the second half v
         {
             const float alpha = p.lr_mul * rsqrtf((float)C);
             float* sk = p.s_k ? p.s_k + sn * T * PL : nullptr;
             float* sv = p.s_v ? p.s_v + sn * T * PL : nullptr;
-            gemm16(bufN, SB, w.wk, C, PL, alpha, nullptr, 0, nullptr, 0, 0.f, 0, 8, [&](int r, int c, float v) {
+            gemm16(bufN, SB, w.wk, C, PL, alpha, nullptr, 0, nullptr, 0, 0.f, 0, NWAVES / 2, [&](int r, int c, float v) {
                 v += w.bk[c] * p.lr_mul;
                 bufK[r * SS + c] = v;
                 if (sk) sk[r * PL + c] = v;
             });
-            gemm16(bufN, SB, w.wv, C, PL, alpha, nullptr, 0, nullptr, 0, 0.f, 8, 8, [&](int r, int c, float v) {
+            gemm16(bufN, SB, w.wv, C, PL, alpha, nullptr, 0, nullptr, 0, 0.f, NWAVES / 2, NWAVES / 2, [&](int r, int c, float v) {
                 v += w.bv[c] * p.lr_mul;
                 bufV[r * SS + c] = v;
                 if (sv) sv[r * PL + c] = v;
@@ -315,7 +319,7 @@ struct BwdArgs {
 // W[j0 + hi][kb + NQ lo .. + NQ - 1] (one 4 / 8 / 16-byte load) and feeds value q to the tile of the columns kb + NQ lo + q, with
 // A[lo][j0 + hi] (one LDS read) as the other operand of all NQ MFMAs of the 4-deep j step.  Loads of CHT j steps are issued
 // together.  Kout % 16 == 0 (columns beyond Kout are masked), J % 4 == 0.
-constexpr int CHT = 16;
+constexpr int CHT = TE_ATT_CHT;
 
 template <int NQ>
 __device__ __forceinline__ void gemm16_t_acc(f32x4 (&acc)[NQ], const float* __restrict__ A, int sa, const float* __restrict__ W, int ldw,

@@ -392,8 +392,8 @@ class Generator(nn.Module):                                                     
         if trans_interact:                                                           # :670-679
             eye = self.token_spatial.unsqueeze(0).expand(stylecode.shape[0], -1, -1)
             z0, p0 = torch.cat([stylecode, eye], 2), torch.cat([spatialcode, eye], 2)
-            if attn_stack.supported(self.interact) and z0.is_cuda and z0.dtype == torch.float32:
-                # all n_trans blocks in one launch per direction (op/attn_stack.py)
+            if attn_stack.FUSED and attn_stack.supported(self.interact) and z0.is_cuda and z0.dtype == torch.float32:
+                # all n_trans blocks in one launch per direction (op/attn_stack.py; opt-in, see the note there)
                 x = attn_stack.attention_stack(z0, p0, spatialcode if self.n_trans > 1 else None,
                                                [attn_stack.block_params(b) for b in self.interact], self.lr_mlp,
                                                self.interact[0].atten.scale, second_order=_modconv_state['second_order'])

@@ -21,6 +21,18 @@ from .linear import linear_fused
 
 PLANES, GROUPS, OUT = 128, 4, 512
 EPS = 1e-5
+# Which form Generator.forward uses.  Measured on MI355X (profiles/README.md, FFHQ-256 generator fwd+bwd, batch 16): the
+# fused stack cuts the step from 640 to 369 dispatches but costs 2.3 ms of GPU time per step against ~1.45 ms for the
+# layer-by-layer launches, which spread every 7 us GEMM over 100+ CUs while a per-sample workgroup is bound by ONE CU's
+# MFMA rate (25 MFLOP x 8 blocks per sample = 0.33 ms at 614 GFLOP/s per CU, before any stall).  The train step is
+# GPU-bound, so the default is the faster one; `use_fused(True)` selects the single-launch form (host-bound callers).
+FUSED = False
+
+
+def use_fused(flag=True):
+    global FUSED
+    FUSED = bool(flag)
+
 _NAMES = ('wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'wp', 'bp', 'w1', 'b1', 'w2', 'b2', 'w0', 'b0')
 
 
