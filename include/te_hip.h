@@ -13,6 +13,12 @@
  *
  * Each entry point names the reference interface it replaces (paths relative to the
  * BillyXYB/TransEditor repository root).
+ *
+ * Precision: every entry point is fp32 (suffix _f32).  The reference's two CUDA ops dispatch over half / float / double
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:196); the TransEditor scripts
+ * only ever run them in fp32 (no autocast / .half() anywhere on the path), so this narrowing is deliberate: the Python
+ * wrappers raise on any other dtype instead of silently casting (tests/test_gpu_generator.py::
+ * test_non_contiguous_and_wrong_dtype_inputs).
  */
 #ifndef TE_HIP_H
 #define TE_HIP_H
@@ -23,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 1
+#define TE_ABI_VERSION 2
 
 #define TE_ERR_NULL -1      /* required pointer is NULL              */
 #define TE_ERR_SHAPE -2     /* non-positive / inconsistent dimension */

@@ -1,0 +1,24 @@
+"""run only the lazy-regulariser sub-steps (path length x4, R1 x2) of the FFHQ-256 train step: for a kernel trace of the
+twice-differentiated paths (rocprofv3 --kernel-trace --stats -- python tools/reg_steps_trace.py [path|r1])"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transeditor_amd.train_step import TrainStep, default_args      # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'path'
+dev = 'cuda'
+ts = TrainStep(default_args(size=256, batch=16), dev)
+real = torch.randn(16, 3, 256, 256, device=dev).clamp(-1, 1)
+fn = ts.path_step if which == 'path' else (lambda: ts.r1_step(real))
+fn()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(4):
+    fn()
+e.record()
+torch.cuda.synchronize()
+print(f'{which}: {s.elapsed_time(e) / 4:.1f} ms per step')
