@@ -432,6 +432,39 @@ def gen_train_grads(M):
         f'{k}={float(out[k]):.5f}' for k in ('d', 'r1', 'g', 'path', 'path_length')))
 
 
+def gen_spatial_regu(M):
+    """`--spatial_regu` (train_spatial_query.py:252-285): path-length penalty w.r.t. the P input ('p') and the mapped P+ code,
+    evaluated with the reference's generator / g_path_regularize on the initial weights: loss, lengths, parameter-gradient norms."""
+    T = ref_import.reference_train_functions()
+    token = 2 * (int(math.log2(TRAIN_SIZE)) - 1)
+    out = {}
+    for space in ('p', 'p+'):
+        G = M.Generator(TRAIN_SIZE, 512, 512, token, n_trans=8, pixel_norm_op_dim=1)
+        synth.fill_state_dict(G.state_dict(), 40)
+        noise, param = synth.latents(TRAIN_BATCH // 2, 7003)
+        pl = synth.normal((TRAIN_BATCH // 2, 3, TRAIN_SIZE, TRAIN_SIZE), 'train.spl')
+        if space == 'p':
+            wrt = param.requires_grad_()
+            fake_img, _, _ = G(noise, wrt)
+        else:
+            wrt = G(noise, param, return_only_mapped_p=True).detach().requires_grad_()
+            fake_img, _, _ = G(noise, wrt, use_spatial_mapping=False)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, *a, **k: pl.to(t)
+        try:
+            loss, mean_len, lengths = T.g_path_regularize(fake_img, wrt, 0)
+        finally:
+            torch.randn_like = orig
+        G.zero_grad()
+        (2.0 * 4 * loss + 0 * fake_img[0, 0, 0, 0]).backward()
+        tag = 'p' if space == 'p' else 'pp'
+        out[f'{tag}.loss'], out[f'{tag}.lengths'], out[f'{tag}.mean'] = loss, lengths, mean_len
+        out[f'{tag}.grad_norms'] = np.array([0.0 if q.grad is None else float(q.grad.double().norm()) for q in G.parameters()])
+    out['names'] = np.array([n for n, _ in G.named_parameters()])
+    npz('spatial_regu32_b2', **{k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
+    REPORT.append('spatial path regulariser (32 px, batch 2): ' + ', '.join(f'{k}={float(out[k]):.5f}' for k in ('p.loss', 'pp.loss')))
+
+
 def main():
     assert ref_import.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
@@ -444,6 +477,7 @@ def main():
     gen_discriminator(M, 256)
     gen_train_step(M)
     gen_train_grads(M)
+    gen_spatial_regu(M)
     with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:
         f.write('golden fixtures generated by oracle/gen_golden.py from the imported reference\n')
         f.write(f'torch {torch.__version__}, numpy {np.__version__}\n')

@@ -167,3 +167,39 @@ def test_checkpoint_layout_round_trip_and_device_prefetcher(tmp_path):
     assert c.load_checkpoint({'g_ema': ck['g_ema']}) is None
     for pa, pc in zip(a.g_ema.parameters(), c.g_ema.parameters()):
         assert torch.equal(pa, pc)
+
+
+@pytest.mark.parametrize('space', ['p', 'p+'])
+def test_spatial_path_regulariser_matches_reference(golden, space):
+    """`--spatial_regu` (train_spatial_query.py:252-285): the path-length penalty with respect to the P-space input / the
+    mapped P+ code: double backward through the mapping network, the attention blocks' q path and the 4x4 synthesis input.
+    Loss, path lengths and every parameter-gradient norm against the reference's generator (tests/golden/spatial_regu32_b2.npz)."""
+    from transeditor_amd.train_step import TrainStep, default_args
+    from transeditor_amd.model_spatial_query import Generator
+    gold = golden('spatial_regu32_b2')
+    tag = 'p' if space == 'p' else 'pp'
+    args = default_args(size=TRAIN_SIZE, batch=TRAIN_BATCH, lr=0.0, spatial_regu=True, regu_sapce=space)
+    G = Generator(TRAIN_SIZE, 512, 512, args.token, n_trans=8, pixel_norm_op_dim=1)
+    synth.fill_state_dict(G.state_dict(), 40)
+
+    class S:
+        def latents(self, n):
+            z, p = synth.latents(n, 7003)
+            return z.to(DEV), p.to(DEV)
+
+        def randn_like(self, t):
+            return synth.normal(tuple(t.shape), 'train.spl').to(t)
+    ts = TrainStep(args, DEV, G.to(DEV), None, S())
+    ts.spatial_step()
+    want = float(gold[f'{tag}.loss'])
+    assert abs(float(ts.loss['spatial_path']) - want) <= 2e-3 * abs(want)
+    assert abs(float(ts.loss['spatial_path_length']) - float(gold[f'{tag}.lengths'].mean())) <= 1e-3 * float(gold[f'{tag}.lengths'].mean())
+    assert abs(float(ts.mean_spatial_path_length) - float(gold[f'{tag}.mean'])) <= 1e-3 * abs(float(gold[f'{tag}.mean']))
+    names = [str(n) for n in gold['names']]
+    bad = []
+    for n, q, w in zip(names, ts.generator.parameters(), gold[f'{tag}.grad_norms']):
+        got = 0.0 if q.grad is None else float(q.grad.double().norm())
+        if w > 1e-7 * float(gold[f'{tag}.grad_norms'].max()):
+            if abs(got - w) / w > 5e-3:          # second-order quantity of a squared deviation: 5x the first-order bar (as the path-length test)
+                bad.append((n, got, float(w)))
+    assert not bad, bad[:6]

@@ -11,7 +11,7 @@ setup :458-473, EMA :56-61), restated as a small class instead of one long funct
 
 Data parallelism (config 4): one process per GPU, `GradSync` mean all-reduce of the gradients after every
 backward (what the reference's two DDP wrappers do, :494-509) and the scalar collectives of utils/distributed.
-`--spatial_regu` (off in every BASELINE config) is not built.
+`--spatial_regu` (the P-space path regulariser, :252-285; off in every BASELINE config) is `spatial_step`.
 """
 import copy
 import math
@@ -31,7 +31,8 @@ from .utils.sample import prepare_noise_new, prepare_param
 def default_args(**kw):
     """The reference's CLI defaults that matter for one iteration (train_spatial_query.py:377-433)."""
     a = dict(size=256, batch=16, para_num=16, latent=512, r1=10.0, path_regularize=2.0, path_batch_shrink=2,
-             d_reg_every=16, g_reg_every=4, lr=0.002, channel_multiplier=2, num_trans=8, pixel_norm_op_dim=1)
+             d_reg_every=16, g_reg_every=4, lr=0.002, channel_multiplier=2, num_trans=8, pixel_norm_op_dim=1,
+             spatial_regu=False, regu_sapce='p+', spatial_path_regularize=2.0)       # (`regu_sapce`: the reference's spelling, :406)
     a.update(kw)
     a['token'] = 2 * (int(math.log2(a['size'])) - 1)
     return SimpleNamespace(**a)
@@ -108,6 +109,8 @@ class TrainStep:
         self.sampler = sampler if sampler is not None else RandomSampler(args, device)
         self.mean_path_length = 0
         self.mean_path_length_avg = 0
+        self.mean_spatial_path_length = 0
+        self.mean_spatial_path_length_avg = 0
         self.accum = 0.5 ** (32 / (10 * 1000))
         D.broadcast_module(self.generator)
         D.broadcast_module(self.discriminator)
@@ -173,6 +176,30 @@ class TrainStep:
         self.mean_path_length_avg = D.reduce_sum(self.mean_path_length).item() / D.get_world_size()
         self.loss.update(path=path_loss.detach(), path_length=path_lengths.mean().detach())
 
+    def spatial_step(self):
+        """:252-285 — the same path-length penalty w.r.t. the P-space input (`regu_sapce == 'p'`) or the mapped P+ code."""
+        G, a = self.generator, self.args
+        n = max(1, a.batch // a.path_batch_shrink)
+        noise, param = self.sampler.latents(n)
+        with second_order():
+            if a.regu_sapce == 'p':
+                wrt = param.requires_grad_()
+                fake_img, _, _ = G(noise, wrt)
+            else:
+                wrt = G(noise, param, return_only_mapped_p=True).detach().requires_grad_()
+                fake_img, _, _ = G(noise, wrt, use_spatial_mapping=False)
+        loss, self.mean_spatial_path_length, lengths = g_path_regularize(
+            fake_img, wrt, self.mean_spatial_path_length, self.sampler.randn_like(fake_img))
+        G.zero_grad()
+        weighted = a.spatial_path_regularize * a.g_reg_every * loss
+        if a.path_batch_shrink:
+            weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+        weighted.backward()
+        self.g_sync.all_reduce()
+        self.g_optim.step()
+        self.mean_spatial_path_length_avg = D.reduce_sum(self.mean_spatial_path_length).item() / D.get_world_size()
+        self.loss.update(spatial_path=loss.detach(), spatial_path_length=lengths.mean().detach())
+
     # ---- checkpoints in the reference's layout (train_spatial_query.py:361-371 writes, :478-492 / test_spatial_query.py:285 read)
     def checkpoint(self):
         """{'g', 'd', 'g_ema', 'g_optim', 'd_optim'}: the dictionary the reference saves every 10000 iterations."""
@@ -213,5 +240,7 @@ class TrainStep:
         self.g_step()
         if i % a.g_reg_every == 0:
             self.path_step()
+        if a.spatial_regu and i % a.g_reg_every == 0:
+            self.spatial_step()
         self._ema.update(self.accum)                                         # :294
         return D.reduce_loss_dict(self.loss)
