@@ -466,7 +466,7 @@ def isolated_allreduce(sync, dev, reps=5):
     import torch.distributed as dist
     out = []
     for bucket in sync.buckets:
-        n = sum(p.numel() for p in bucket)
+        n = sum((p.numel() + 3) & ~3 for p in bucket)
         buf = torch.zeros(n, device=dev)
         dist.all_reduce(buf)
         torch.cuda.synchronize()

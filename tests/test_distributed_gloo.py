@@ -180,7 +180,7 @@ def test_gradsync_with_deferred_async_work_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, outs_a, ref_a, loc_a, nb_a), (_, outs_b, ref_b, loc_b, nb_b) = res
-    assert nb_a == nb_b == 4 * (8 * 16 + 16 + 16 * 16 + 16 + 16 * 4 + 4)
+    assert nb_a == nb_b == 4 * (8 * 16 + 16 + 16 * 16 + 16 + 16 * 4 + 4)          # (every tensor here is a multiple of 4 floats)
     for (ra, ga), (rb, gb) in zip(outs_a, outs_b):
         for x, y, ma, mb in zip(ra, rb, ga, gb):
             mean = (x + y) / 2

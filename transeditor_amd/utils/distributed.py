@@ -107,11 +107,13 @@ class GradSync:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
         self._slot = {}                                   # param -> (bucket index, offset)
+        self._size = []
         for bi, bucket in enumerate(self.buckets):
             off = 0
             for p in bucket:
                 self._slot[p] = (bi, off)
-                off += p.numel()
+                off += (p.numel() + 3) & ~3               # 16-byte aligned slots: the optimiser kernel reads them with 16-byte loads
+            self._size.append(off)
         self._seen = [set() for _ in self.buckets]
         self._work = [None] * len(self.buckets)
         # parameters observed to receive no gradient (the generator's `noise.weight`s): learnt at the first
@@ -126,7 +128,7 @@ class GradSync:
     # ---- bookkeeping
     def bytes_per_call(self):
         """bytes this rank hands to the all-reduce in one all_reduce() call (all buckets)"""
-        return sum(p.numel() * p.element_size() for p in self.params)
+        return sum(n * self.params[0].element_size() for n in self._size)
 
     def remove_hooks(self):
         for h in self._handles:
@@ -136,10 +138,10 @@ class GradSync:
     # ---- internals
     def _buffer(self, bi):
         bucket = self.buckets[bi]
-        n = sum(p.numel() for p in bucket)
+        n = self._size[bi]
         flat = self._flat[bi]
         if flat is None or flat.numel() != n or flat.device != bucket[0].device:
-            flat = self._flat[bi] = torch.empty(n, device=bucket[0].device, dtype=bucket[0].dtype)
+            flat = self._flat[bi] = torch.zeros(n, device=bucket[0].device, dtype=bucket[0].dtype)     # (alignment gaps stay zero)
         return flat
 
     def _install_hooks(self):
