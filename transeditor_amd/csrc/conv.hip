@@ -33,15 +33,22 @@ namespace {
 #ifndef T2KC0
 #define T2KC0 16
 #endif
+// TE_CONV_DB (experiment): two LDS stage buffers of half the channels each and ONE workgroup barrier per stage: a wave commits
+// the next stage into the other buffer right after its own MFMAs, while slower waves are still computing.
+#ifdef TE_CONV_DB
+#define KCD(v) ((v) / 2)
+#else
+#define KCD(v) (v)
+#endif
 template <int KIND, int TC> struct Cfg;
-template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
-template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = KCD(T2KC0), NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = KCD(16), NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = KCD(16), NSP = 1; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 
@@ -70,6 +77,7 @@ struct ConvArgs {
         int tapmask;             // taps that can contribute in this region (thin T2 edge regions need 3 of 9)
     } reg[3];
     int nreg;
+    int stage_floats;        // TE_CONV_DB: floats of one LDS stage buffer (weights + input tile)
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
@@ -174,53 +182,46 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     float xreg[NSP][KC];
     float sreg[(HAS_ISC && MS) ? NSP : 1][KC];   // style scales of the staged channels (applied when the tile is written to LDS)
 
-    // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
-    // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
     const int kbeg = blockIdx.z * p.kchunk, kend = min(p.Kp, kbeg + p.kchunk);
-    for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
-        if (k0 >= kbeg) {
-            __syncthreads();              // every wave finished reading the previous stage
+    auto commit = [&](float* wlb, float* xlb) {          // prefetched registers -> one LDS stage buffer
 #pragma unroll
-            for (int r = 0; r < WLDR; ++r) {
-                const int idx = tid + NTHREADS * r;
-                if (WEVEN || idx < WSTAGE / 4) *reinterpret_cast<f32x4*>(wl + idx * 4) = wreg[r];
-            }
-#pragma unroll
-            for (int r = 0; r < NSP; ++r) {
-                if (loff[r] >= 0) {
-#pragma unroll
-                    for (int kk = 0; kk < KC; ++kk)
-                        xl[kk * g.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
-                }
-            }
-            __syncthreads();
+        for (int r = 0; r < WLDR; ++r) {
+            const int idx = tid + NTHREADS * r;
+            if (WEVEN || idx < WSTAGE / 4) *reinterpret_cast<f32x4*>(wlb + idx * 4) = wreg[r];
         }
-        const int kn = k0 + KC;
-        if (kn < kend) {
 #pragma unroll
-            for (int r = 0; r < WLDR; ++r) {
-                int idx = tid + NTHREADS * r;          // float4 index inside the stage
-                if (!WEVEN && idx >= WSTAGE / 4) idx = WSTAGE / 4 - 1;      // clamped duplicate load, never committed
-                const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
-                const int tap = row / KC, kk = row - tap * KC;
-                wreg[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(tap * p.Kp + kn + kk) * p.Mp + m0 + c4 * 4));
-            }
+        for (int r = 0; r < NSP; ++r) {
+            if (loff[r] >= 0) {
 #pragma unroll
-            for (int r = 0; r < NSP; ++r) {
-#pragma unroll
-                for (int kk = 0; kk < KC; ++kk) {
-                    // unconditional buffer loads: zero padding and the channel tail come back as 0 from the hardware
-                    // range check, so nothing depends on the loaded value until the tile is committed to LDS
-                    const int k = kn + kk;
-                    const unsigned koff = k < p.K ? (unsigned)k * plane4 : OOBH;
-                    xreg[r][kk] = buf_load(irs, goff[r] + koff);
-                    if (HAS_ISC && (MS || r == 0))
-                        sreg[MS ? r : 0][kk] = p.isc[(MS ? sb[r] : b0) * p.K + (k < p.K ? k : p.K - 1)];
-                }
+                for (int kk = 0; kk < KC; ++kk)
+                    xlb[kk * g.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
             }
         }
-        if (k0 < kbeg) continue;
-
+    };
+    auto issue = [&](int kn) {                            // global loads of the stage starting at channel kn -> registers
+#pragma unroll
+        for (int r = 0; r < WLDR; ++r) {
+            int idx = tid + NTHREADS * r;          // float4 index inside the stage
+            if (!WEVEN && idx >= WSTAGE / 4) idx = WSTAGE / 4 - 1;      // clamped duplicate load, never committed
+            const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
+            const int tap = row / KC, kk = row - tap * KC;
+            wreg[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(tap * p.Kp + kn + kk) * p.Mp + m0 + c4 * 4));
+        }
+#pragma unroll
+        for (int r = 0; r < NSP; ++r) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                // unconditional buffer loads: zero padding and the channel tail come back as 0 from the hardware
+                // range check, so nothing depends on the loaded value until the tile is committed to LDS
+                const int k = kn + kk;
+                const unsigned koff = k < p.K ? (unsigned)k * plane4 : OOBH;
+                xreg[r][kk] = buf_load(irs, goff[r] + koff);
+                if (HAS_ISC && (MS || r == 0))
+                    sreg[MS ? r : 0][kk] = p.isc[(MS ? sb[r] : b0) * p.K + (k < p.K ? k : p.K - 1)];
+            }
+        }
+    };
+    auto compute = [&](const float* wlb, const float* xlb) {
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
 #pragma unroll
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 else toff = ky * g.TIWP + kx;
                 float a[MBW];
 #pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) a[mb] = wl[(tp * KC + kk) * BM + aoff + mb * 32];
+                for (int mb = 0; mb < MBW; ++mb) a[mb] = wlb[(tp * KC + kk) * BM + aoff + mb * 32];
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb) {
-                    const float bv = xl[kk * g.CS + boff[nb] + toff];
+                    const float bv = xlb[kk * g.CS + boff[nb] + toff];
                     const int j = IS_T2 ? nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0) : nb;
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb)
@@ -245,7 +246,42 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 }
             }
         }
+    };
+#ifdef TE_CONV_DB
+    // double-buffered stages, one barrier per stage: MFMAs of stage s, then commit stage s+1 (its loads were issued one
+    // stage ago) into the other buffer, issue the loads of stage s+2, barrier
+    if (kbeg < kend) {
+        issue(kbeg);
+        commit(smem, smem + WSTAGE);
+        if (kbeg + KC < kend) issue(kbeg + KC);
+        __syncthreads();
+        int st = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += KC, st ^= 1) {
+            const float* cur = smem + st * p.stage_floats;
+            compute(cur, cur + WSTAGE);
+            if (k0 + KC < kend) {
+                float* nxt = smem + (st ^ 1) * p.stage_floats;
+                commit(nxt, nxt + WSTAGE);
+                if (k0 + 2 * KC < kend) issue(k0 + 2 * KC);
+            }
+            __syncthreads();
+        }
     }
+#else
+    // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
+    // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
+    for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
+        if (k0 >= kbeg) {
+            __syncthreads();              // every wave finished reading the previous stage
+            commit(wl, xl);
+            __syncthreads();
+        }
+        const int kn = k0 + KC;
+        if (kn < kend) issue(kn);
+        if (k0 < kbeg) continue;
+        compute(wl, xl);
+    }
+#endif
 
     // ---- epilogue: osc, bias, activation, store.  C/D layout of the 32x32 tile:
     //      col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -490,6 +526,10 @@ int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s)
         if (rc) return rc;
     }
     if (nblocks == 0) return 0;
+#ifdef TE_CONV_DB
+    a.stage_floats = (int)lds_floats;
+    lds_floats *= 2;
+#endif
     if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s);
     else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s);
     else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s);
@@ -550,7 +590,7 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
     if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
     pl.tc = tc;
-    const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
+    const int KC = KCD(t2k ? (tc == 0 ? T2KC0 : 16) : 8);
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
     // split count comes from the real tile geometry of the main region and is shared by every region of the launch
