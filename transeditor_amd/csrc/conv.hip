@@ -33,22 +33,15 @@ namespace {
 #ifndef T2KC0
 #define T2KC0 16
 #endif
-// TE_CONV_DB (experiment): two LDS stage buffers of half the channels each and ONE workgroup barrier per stage: a wave commits
-// the next stage into the other buffer right after its own MFMAs, while slower waves are still computing.
-#ifdef TE_CONV_DB
-#define KCD(v) ((v) / 2)
-#else
-#define KCD(v) (v)
-#endif
 template <int KIND, int TC> struct Cfg;
-template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = KCD(8), NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
-template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = KCD(T2KC0), NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = KCD(16), NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = KCD(16), NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 
@@ -77,7 +70,6 @@ struct ConvArgs {
         int tapmask;             // taps that can contribute in this region (thin T2 edge regions need 3 of 9)
     } reg[3];
     int nreg;
-    int stage_floats;        // TE_CONV_DB: floats of one LDS stage buffer (weights + input tile)
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
@@ -247,27 +239,6 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             }
         }
     };
-#ifdef TE_CONV_DB
-    // double-buffered stages, one barrier per stage: MFMAs of stage s, then commit stage s+1 (its loads were issued one
-    // stage ago) into the other buffer, issue the loads of stage s+2, barrier
-    if (kbeg < kend) {
-        issue(kbeg);
-        commit(smem, smem + WSTAGE);
-        if (kbeg + KC < kend) issue(kbeg + KC);
-        __syncthreads();
-        int st = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += KC, st ^= 1) {
-            const float* cur = smem + st * p.stage_floats;
-            compute(cur, cur + WSTAGE);
-            if (k0 + KC < kend) {
-                float* nxt = smem + (st ^ 1) * p.stage_floats;
-                commit(nxt, nxt + WSTAGE);
-                if (k0 + 2 * KC < kend) issue(k0 + 2 * KC);
-            }
-            __syncthreads();
-        }
-    }
-#else
     // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
     // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
     for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
@@ -281,7 +252,6 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         if (k0 < kbeg) continue;
         compute(wl, xl);
     }
-#endif
 
     // ---- epilogue: osc, bias, activation, store.  C/D layout of the 32x32 tile:
     //      col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -526,10 +496,6 @@ int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s)
         if (rc) return rc;
     }
     if (nblocks == 0) return 0;
-#ifdef TE_CONV_DB
-    a.stage_floats = (int)lds_floats;
-    lds_floats *= 2;
-#endif
     if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s);
     else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s);
     else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s);
@@ -590,7 +556,7 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
     if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
     pl.tc = tc;
-    const int KC = KCD(t2k ? (tc == 0 ? T2KC0 : 16) : 8);
+    const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
     // split the channel loop when the image is too small to give every CU a tile (4x4 ... 16x16 layers); the
     // split count comes from the real tile geometry of the main region and is shared by every region of the launch
