@@ -152,6 +152,36 @@ def gen_ops(M):
     npz('attention_block', **d)
 
 
+def gen_modconv_down(M):
+    """ModulatedConv2d(downsample=True), model_spatial_query.py:270-276, 323-329 (not instantiated by the generator; part
+    of the class's call surface).  Same contents per case as the modulated_conv2d fixture."""
+    d = {}
+    for name, (B, cin, cout, k, H, demod) in {'down3': (2, 6, 5, 3, 8, True), 'down3_wide': (2, 40, 36, 3, 12, True),
+                                                'down1': (2, 8, 6, 1, 8, True), 'down3_nodemod': (3, 5, 7, 3, 6, False)}.items():
+        m = M.ModulatedConv2d(cin, cout, k, 16, demodulate=demod, downsample=True)
+        for kk, t in m.state_dict().items():
+            if 'blur' not in kk:
+                t.copy_(synth.normal(tuple(t.shape), f'mcd.{name}.{kk}') * (0.3 if 'bias' in kk else 1.0)
+                        + (1.0 if 'modulation.bias' in kk else 0.0))
+        x = synth.normal((B, cin, H, H), f'mcd.{name}.x').requires_grad_(True)
+        s = synth.normal((B, 16), f'mcd.{name}.s').requires_grad_(True)
+        y = m(x, s)
+        wy = synth.normal(tuple(y.shape), f'mcd.{name}.wy')
+        params = [m.weight, m.modulation.weight, m.modulation.bias]
+        g = torch.autograd.grad((y * wy).sum(), [x, s] + params, create_graph=True)
+        pl = g[1].pow(2).sum()
+        g2 = torch.autograd.grad(pl, [x] + params, allow_unused=True)
+        g2 = [torch.zeros_like(t) if gi is None else gi for gi, t in zip(g2, [x] + params)]
+        yo = O.modulated_conv2d(x, s, m.weight, m.modulation.weight, m.modulation.bias, demod, downsample=True)
+        note('modulated_conv2d_down.' + name, rel_err(yo, y))
+        d.update({f'{name}.x': x, f'{name}.s': s, f'{name}.y': y, f'{name}.wy': wy,
+                  f'{name}.weight': m.weight, f'{name}.mod_w': m.modulation.weight, f'{name}.mod_b': m.modulation.bias,
+                  f'{name}.gx': g[0], f'{name}.gs': g[1], f'{name}.gw': g[2], f'{name}.gmw': g[3], f'{name}.gmb': g[4],
+                  f'{name}.pl': pl, f'{name}.pl_gx': g2[0], f'{name}.pl_gw': g2[1], f'{name}.pl_gmw': g2[2],
+                  f'{name}.pl_gmb': g2[3], f'{name}.cfg': np.array([demod, k])})
+    npz('modulated_conv2d_down', **d)
+
+
 # ------------------------------------------------------------------------------- full generator
 
 def build_ref_generator(M, size, seed):
@@ -470,6 +500,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     M = ref_import.import_reference()
+    if len(sys.argv) > 2 and sys.argv[1] == '--only':          # regenerate one fixture, REPORT.txt gets the lines appended
+        globals()['gen_' + sys.argv[2]](M)
+        with open(os.path.join(OUT, 'REPORT.txt'), 'a') as f:
+            f.write('\n'.join(REPORT) + '\n')
+        print('\n'.join(REPORT))
+        return
     gen_schema(M)
     gen_ops(M)
     gen_generator(M)
@@ -478,6 +514,7 @@ def main():
     gen_train_step(M)
     gen_train_grads(M)
     gen_spatial_regu(M)
+    gen_modconv_down(M)
     with open(os.path.join(OUT, 'REPORT.txt'), 'w') as f:
         f.write('golden fixtures generated by oracle/gen_golden.py from the imported reference\n')
         f.write(f'torch {torch.__version__}, numpy {np.__version__}\n')

@@ -87,8 +87,8 @@ def equal_linear(x, weight, bias, lr_mul=1.0, activation=False):
 
 
 def modulated_conv2d(x, style, weight, mod_w, mod_b, demodulate=True, upsample=False,
-                     blur_taps=(1, 3, 3, 1)):
-    """ModulatedConv2d.forward, model_spatial_query.py:296-337 (downsample branch unused by G).
+                     blur_taps=(1, 3, 3, 1), downsample=False):
+    """ModulatedConv2d.forward, model_spatial_query.py:296-337 (the downsample branch, :323-329, is not used by G).
     weight: [1, Cout, Cin, k, k]; per-sample weights, grouped conv with groups=batch."""
     B, Cin, H, W = x.shape
     _, Cout, _, k, _ = weight.shape
@@ -104,6 +104,12 @@ def modulated_conv2d(x, style, weight, mod_w, mod_b, demodulate=True, upsample=F
         p = (len(blur_taps) - 2) - (k - 1)                                   # :264-266
         pad = ((p + 1) // 2 + 1, p // 2 + 1)
         return upfirdn2d(y, fir_kernel(blur_taps, 4.0).to(y), pad=pad)       # Blur, :137-153 (gain = factor**2)
+    if downsample:
+        p = (len(blur_taps) - 2) + (k - 1)                                   # :270-276
+        x = upfirdn2d(x, fir_kernel(blur_taps).to(x), pad=((p + 1) // 2, p // 2))          # :324
+        y = F.conv2d(x.reshape(1, B * Cin, x.shape[2], x.shape[3]), w.reshape(B * Cout, Cin, k, k), padding=0, stride=2,
+                     groups=B)                                               # :327
+        return y.reshape(B, Cout, y.shape[2], y.shape[3])
     y = F.conv2d(x.reshape(1, B * Cin, H, W), w.reshape(B * Cout, Cin, k, k), padding=k // 2, groups=B)
     return y.reshape(B, Cout, H, W)
 

@@ -335,6 +335,44 @@ def test_modulated_conv2d_module_golden(golden, name):
             assert rel_err(got, want) < 5e-4, key
 
 
+@pytest.mark.parametrize('name', ['down3', 'down3_wide', 'down1', 'down3_nodemod'])
+def test_modulated_conv2d_downsample_golden(golden, name):
+    """ModulatedConv2d(downsample=True) (model_spatial_query.py:270-276, 323-329) vs the reference's outputs, first grads
+    and the second-order term: blur + the strided kernel with style scale / demodulation."""
+    from transeditor_amd.model_spatial_query import ModulatedConv2d
+    g = golden('modulated_conv2d_down')
+    demod, k = bool(g[f'{name}.cfg'][0]), int(g[f'{name}.cfg'][1])
+    w = g[f'{name}.weight']
+    m = ModulatedConv2d(w.shape[2], w.shape[1], k, 16, demodulate=demod, downsample=True).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.modulation.weight.copy_(g[f'{name}.mod_w'])
+        m.modulation.bias.copy_(g[f'{name}.mod_b'])
+    x = g[f'{name}.x'].to(DEV).requires_grad_(True)
+    s = g[f'{name}.s'].to(DEV).requires_grad_(True)
+    y = m(x, s)
+    assert y.shape == g[f'{name}.y'].shape
+    assert rel_err(y, g[f'{name}.y']) < 1e-4
+    params = [m.weight, m.modulation.weight, m.modulation.bias]
+    gr = torch.autograd.grad((y * g[f'{name}.wy'].to(DEV)).sum(), [x, s] + params, create_graph=True)
+    for got, key in zip(gr, ('gx', 'gs', 'gw', 'gmw', 'gmb')):
+        assert rel_err(got, g[f'{name}.{key}']) < 2e-4, key
+    pl = gr[1].pow(2).sum()
+    assert abs(float(pl) - float(g[f'{name}.pl'])) / float(g[f'{name}.pl']) < 2e-4
+    g2 = torch.autograd.grad(pl, [x] + params, allow_unused=True)
+    for got, key in zip(g2, ('pl_gx', 'pl_gw', 'pl_gmw', 'pl_gmb')):
+        want = g[f'{name}.{key}']
+        if float(want.abs().max()) == 0:
+            assert got is None or float(got.abs().max()) < 1e-6
+        else:
+            assert rel_err(got, want) < 5e-4, key
+    # first-order backward through the fused node (no create_graph): same gradients
+    y2 = m(x, s)
+    gr1 = torch.autograd.grad((y2 * g[f'{name}.wy'].to(DEV)).sum(), [x, s] + params)
+    for got, key in zip(gr1, ('gx', 'gs', 'gw', 'gmw', 'gmb')):
+        assert rel_err(got, g[f'{name}.{key}']) < 2e-4, key
+
+
 # ------------------------------------------------------------------------------------------------ F2
 def test_attention_core_vs_torch():
     from transeditor_amd.op.attention import attention_core, _torch_expr

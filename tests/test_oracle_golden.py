@@ -96,6 +96,19 @@ def test_modulated_conv2d(golden, name):
         assert rel_err(got, g[f'{name}.{key}']) < TOL or float(g[f'{name}.{key}'].abs().max()) == 0, key
 
 
+@pytest.mark.parametrize('name', ['down3', 'down3_wide', 'down1', 'down3_nodemod'])
+def test_modulated_conv2d_downsample(golden, name):
+    g = golden('modulated_conv2d_down')
+    x = g[f'{name}.x'].clone().requires_grad_(True)
+    s = g[f'{name}.s'].clone().requires_grad_(True)
+    w, mw, mb = (g[f'{name}.{k}'].clone().requires_grad_(True) for k in ('weight', 'mod_w', 'mod_b'))
+    y = O.modulated_conv2d(x, s, w, mw, mb, bool(g[f'{name}.cfg'][0]), downsample=True)
+    assert rel_err(y, g[f'{name}.y']) < TOL
+    gr = torch.autograd.grad((y * g[f'{name}.wy']).sum(), (x, s, w, mw, mb))
+    for got, key in zip(gr, ('gx', 'gs', 'gw', 'gmw', 'gmb')):
+        assert rel_err(got, g[f'{name}.{key}']) < TOL, key
+
+
 def attention_block_params(name, cin, cp, device='cpu'):
     """Weights of the attention-block fixture (same rule as oracle/gen_golden.py)."""
     shapes = {'atten.q_transform.weight': (128, cp), 'atten.q_transform.bias': (128,),

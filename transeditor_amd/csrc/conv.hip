@@ -33,6 +33,16 @@ namespace {
 #ifndef T2KC0
 #define T2KC0 16
 #endif
+// FAST kernels (K a multiple of the stage depth, big tile class): knobs for A/B measurements
+#ifndef TE_CONV_FAST         // 0: never dispatch to the FAST kernels
+#define TE_CONV_FAST 1
+#endif
+#ifndef TE_FAST_PF           // LDS operands of step s+1 are read before the MFMAs of step s
+#define TE_FAST_PF 1
+#endif
+#ifndef TE_FAST_IL           // the global loads of the next stage are spread over the MFMA steps of this one
+#define TE_FAST_IL 1
+#endif
 template <int KIND, int TC> struct Cfg;
 template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
 template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
@@ -82,7 +92,10 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // MBW: 32-row M blocks per wave (block M tile = 2*MBW*32 = 128 -> MBW = 2)
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
 // MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
-template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
+// FAST: every stage is a full one (K % KC == 0, host-checked): stage loads take scalar channel offsets and are spread over
+// the MFMA steps, the LDS operands are read one step ahead, and T2 runs all nine taps in every region without per-tap
+// branches, its four shifted B fragments shared by the taps (the thin edge regions then multiply some zero padding).
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
 __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KIND, TC>;
     constexpr int NBW = C::NBW, MBW = C::MBW, KC = C::KC, WM = C::WM, WN = 4 / C::WM, NSP = C::NSP;
@@ -190,6 +203,30 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             }
         }
     };
+    // FAST: weights through a buffer descriptor with per-thread byte offsets fixed over the K loop; a stage advances scalar offsets
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.wp, (unsigned)NTAP * p.Kp * p.Mp * 4u);
+    unsigned woff[FAST ? WLDR : 1];
+    if (FAST) {
+#pragma unroll
+        for (int r = 0; r < WLDR; ++r) {
+            int idx = tid + NTHREADS * r;          // float4 index inside the stage
+            if (!WEVEN && idx >= WSTAGE / 4) idx = WSTAGE / 4 - 1;      // clamped duplicate load, never committed
+            const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
+            const int tap = row / KC, kk = row - tap * KC;
+            woff[r] = ((unsigned)(tap * p.Kp + kk) * p.Mp + m0 + c4 * 4) * 4u;
+        }
+    }
+    constexpr int NPIECE = WLDR + NSP * KC;       // load instructions per thread and stage
+    auto load_piece = [&](int kn, int i) {        // i is a compile-time constant after unrolling
+        if (i < WLDR) {
+            wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[FAST ? i : 0], (unsigned)kn * p.Mp * 4u, 0));
+        } else {
+            const int r = (i - WLDR) / KC, kk = (i - WLDR) % KC;
+            // zero padding (goff = OOBH) fails the hardware range check whatever the scalar channel offset is
+            xreg[r][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, goff[r], (unsigned)(kn + kk) * plane4, 0));
+            if (HAS_ISC && (MS || r == 0)) sreg[MS ? r : 0][kk] = p.isc[(MS ? sb[r] : b0) * p.K + kn + kk];
+        }
+    };
     auto issue = [&](int kn) {                            // global loads of the stage starting at channel kn -> registers
 #pragma unroll
         for (int r = 0; r < WLDR; ++r) {
@@ -213,44 +250,144 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             }
         }
     };
+    // one (channel pair, tap) step: A fragments of the wave's M blocks, B fragments of its cell blocks
+    auto operands = [&](const float* wlb, const float* xlb, int kk, int tp, float (&a)[MBW], float (&bv)[NBW]) {
+        const int ky = tp / 3, kx = tp % 3;
+        int toff;
+        if (KIND == TE_CONV_1X1) toff = 0;
+        else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? g.TIWP : 0) - (kx == 2 ? 1 : 0);
+        else if (KIND == TE_CONV_S2) toff = ky * g.TIWP + (kx == 1 ? g.TW + 1 : (kx >> 1));
+        else toff = ky * g.TIWP + kx;
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) a[mb] = wlb[(tp * KC + kk) * BM + aoff + mb * 32];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) bv[nb] = xlb[kk * g.CS + boff[nb] + toff];
+    };
+    auto mfmas = [&](int tp, const float (&a)[MBW], const float (&bv)[NBW]) {
+        const int ky = tp / 3, kx = tp % 3;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int j = IS_T2 ? nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0) : nb;
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+                acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bv[nb], acc[mb][j], 0, 0, 0);
+        }
+    };
     auto compute = [&](const float* wlb, const float* xlb) {
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
 #pragma unroll
             for (int tp = 0; tp < NTAP; ++tp) {
                 if (IS_T2 && !((g.tapmask >> tp) & 1)) continue;      // block-uniform: skipped taps only see zero padding
-                const int ky = tp / 3, kx = tp % 3;
-                int toff;
-                if (KIND == TE_CONV_1X1) toff = 0;
-                else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? g.TIWP : 0) - (kx == 2 ? 1 : 0);
-                else if (KIND == TE_CONV_S2) toff = ky * g.TIWP + (kx == 1 ? g.TW + 1 : (kx >> 1));
-                else toff = ky * g.TIWP + kx;
-                float a[MBW];
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) a[mb] = wlb[(tp * KC + kk) * BM + aoff + mb * 32];
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) {
-                    const float bv = xlb[kk * g.CS + boff[nb] + toff];
-                    const int j = IS_T2 ? nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0) : nb;
-#pragma unroll
-                    for (int mb = 0; mb < MBW; ++mb)
-                        acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bv, acc[mb][j], 0, 0, 0);
-                }
+                float a[MBW], bv[NBW];
+                operands(wlb, xlb, kk, tp, a, bv);
+                mfmas(tp, a, bv);
             }
         }
     };
-    // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
-    // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
-    for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
-        if (k0 >= kbeg) {
+    // FAST form of the stage: the step list (channel pair x tap) is walked with the LDS operands of the next step already
+    // requested, and the load instructions of stage `kn` are dealt out over the first three quarters of the steps, so no wave
+    // queues 25 loads at the texture addresser at once and the last of them has time to land before the commit
+    auto compute_fast = [&](const float* wlb, const float* xlb, int kn) {
+        constexpr int NSTEP = (KC / 2) * NTAP;
+        constexpr int SPAN = TE_FAST_IL ? (NSTEP * 3) / 4 : 1;     // steps that carry loads
+        auto pieces = [&](int st) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i)
+                if ((i * SPAN) / NPIECE == st) load_piece(kn, i);
+        };
+        if (!IS_T2) {
+            float a0[MBW], b0[NBW];
+            operands(wlb, xlb, 0, 0, a0, b0);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int kk = (st / NTAP) * 2, tp = st % NTAP;
+                float a1[MBW], b1[NBW];
+                if (TE_FAST_PF) {
+                    if (st + 1 < NSTEP) operands(wlb, xlb, ((st + 1) / NTAP) * 2, (st + 1) % NTAP, a1, b1);
+                } else {
+                    operands(wlb, xlb, kk, tp, a0, b0);
+                }
+                pieces(st);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(tp, a0, b0);
+                if (TE_FAST_PF && st + 1 < NSTEP) {
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) a0[mb] = a1[mb];
+#pragma unroll
+                    for (int nb = 0; nb < NBW; ++nb) b0[nb] = b1[nb];
+                }
+            }
+        } else {
+            // T2: the B fragment of a tap depends on (ky == 2, kx == 2) only -> four shifted fragments per channel pair,
+            // shared by the nine taps; those of the next pair arrive one per tap while this pair is multiplied
+            static_assert(!IS_T2 || MBW == 1, "T2 tile classes use one M block per wave");
+            auto bfrag = [&](int kk, int sh, int nb) {
+                return xlb[kk * g.CS + boff[nb] - ((sh >> 1) ? g.TIWP : 0) - (sh & 1)];
+            };
+            float bs[4][NBW], bn[4][NBW];
+#pragma unroll
+            for (int sh = 0; sh < 4; ++sh)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) bs[sh][nb] = bfrag(0, sh, nb);
+            float a0 = wlb[aoff];
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 2) {
+#pragma unroll
+              for (int tp = 0; tp < NTAP; ++tp) {
+                const int st = (kk / 2) * NTAP + tp;
+                const int ky = tp / 3, kx = tp % 3;
+                float a1 = 0.f;
+                if (st + 1 < NSTEP) a1 = wlb[(((st + 1) % NTAP) * KC + ((st + 1) / NTAP) * 2) * BM + aoff];
+                if (kk + 2 < KC) {          // 4 * NBW fragments of the next pair over the 9 taps of this one
+#pragma unroll
+                    for (int q = 0; q < 4 * NBW; ++q)
+                        if ((q * NTAP) / (4 * NBW) == tp) bn[q / NBW][q % NBW] = bfrag(kk + 2, q / NBW, q % NBW);
+                }
+                pieces(st);
+                __builtin_amdgcn_sched_barrier(0);
+                const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const int j = nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[sh][nb], acc[0][j], 0, 0, 0);
+                }
+                a0 = a1;
+              }
+              if (kk + 2 < KC) {
+#pragma unroll
+                  for (int sh2 = 0; sh2 < 4; ++sh2)
+#pragma unroll
+                      for (int nb = 0; nb < NBW; ++nb) bs[sh2][nb] = bn[sh2][nb];
+              }
+            }
+        }
+    };
+    if (FAST) {
+        // prologue: stage kbeg straight to registers; every iteration commits its stage, then multiplies it while the loads
+        // of the next one are dealt out (the last iteration re-requests its own stage: never committed, always in range)
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) load_piece(kbeg, i);
+        for (int k0 = kbeg; k0 < kend; k0 += KC) {
             __syncthreads();              // every wave finished reading the previous stage
             commit(wl, xl);
             __syncthreads();
+            compute_fast(wl, xl, min(k0 + KC, kend - KC));
         }
-        const int kn = k0 + KC;
-        if (kn < kend) issue(kn);
-        if (k0 < kbeg) continue;
-        compute(wl, xl);
+    } else {
+        // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
+        // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
+        for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
+            if (k0 >= kbeg) {
+                __syncthreads();              // every wave finished reading the previous stage
+                commit(wl, xl);
+                __syncthreads();
+            }
+            const int kn = k0 + KC;
+            if (kn < kend) issue(kn);
+            if (k0 < kbeg) continue;
+            compute(wl, xl);
+        }
     }
 
     // ---- epilogue: osc, bias, activation, store.  C/D layout of the 32x32 tile:
@@ -466,13 +603,25 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
 
 constexpr int conv_occ() { return 3; }      // waves per SIMD the plain 3x3 128-row tile is compiled for (2 measured slower)
 
-template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
-void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
+void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     constexpr int BM = tile_bm<KIND, TC>();
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC>, 128 * 1024);
+    te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST>, 128 * 1024);
     dim3 grid((unsigned)nblocks, (unsigned)te::cdiv(a.M, BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+}
+
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
+void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+    // FAST kernels exist for the 128-row tile class of the 3x3 family with one sample per tile (the layers that carry the
+    // FLOPs); they need whole stages: K and the split-K chunk multiples of the stage depth
+    constexpr bool HAVE_FAST = TE_CONV_FAST && TC == 0 && !MS && KIND != TE_CONV_1X1;
+    constexpr int KC = Cfg<KIND, TC>::KC;
+    if (HAVE_FAST && a.K % KC == 0 && a.K == a.Kp && (a.ksplit == 1 || a.kchunk % KC == 0))
+        launch_f<KIND, TC, HAS_ISC, MS, OCC, HAVE_FAST>(a, nblocks, lds_floats, s);
+    else
+        launch_f<KIND, TC, HAS_ISC, MS, OCC, false>(a, nblocks, lds_floats, s);
 }
 
 template <int KIND, int TC, bool HAS_ISC, bool MS>

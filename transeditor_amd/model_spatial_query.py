@@ -175,11 +175,9 @@ class ModulatedConv2d(nn.Module):                                               
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
                  downsample=False, blur_kernel=[1, 3, 3, 1]):
         super().__init__()
-        if downsample:
-            raise NotImplementedError('ModulatedConv2d(downsample=True) is not on the generator path (never '
-                                      'instantiated by the reference scripts); not built in the MI355X port')
-        if kernel_size not in (1, 3) or (upsample and kernel_size != 3):
-            raise NotImplementedError('MI355X kernels exist for 3x3, 3x3 upsample and 1x1 modulated convolutions')
+        if kernel_size not in (1, 3) or (upsample and kernel_size != 3) or (upsample and downsample):
+            raise NotImplementedError('MI355X kernels exist for 3x3, 3x3 upsample, 3x3 / 1x1 downsample and 1x1 modulated '
+                                      'convolutions')
         self.eps = 1e-8
         self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
         self.upsample, self.downsample = upsample, downsample
@@ -187,6 +185,9 @@ class ModulatedConv2d(nn.Module):                                               
             factor = 2
             p = (len(blur_kernel) - factor) - (kernel_size - 1)
             self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:                                                               # :270-276
+            p = (len(blur_kernel) - 2) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
         self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
         self.padding = kernel_size // 2
         self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
@@ -199,6 +200,8 @@ class ModulatedConv2d(nn.Module):                                               
 
     @property
     def kind(self):
+        if self.downsample and self.kernel_size == 3:
+            return 'down'
         return 'up' if self.upsample else ('3x3' if self.kernel_size == 3 else '1x1')
 
     def scales(self, style):
@@ -215,6 +218,14 @@ class ModulatedConv2d(nn.Module):                                               
         s = self.modulation(style)
         w = self.weight.view(self.weight.shape[1:])
         eps = self.eps if self.demodulate else None          # demodulation is computed inside the modconv node
+        if self.downsample:                                  # :323-329: blur, then the stride-2 convolution without padding
+            if self.kernel_size == 1:                        # a 1x1 stride-2 conv reads every second blurred pixel only
+                input = upfirdn2d(input, self.blur.kernel, down=2, pad=self.blur.pad)
+                return modconv(input, w, s, None, bias, act, '1x1', self.scale, demod_eps=eps)
+            input = self.blur(input)                         # (H+1)x(W+1); the strided kernel takes (2h+1)x(2w+1):
+            if input.shape[2] % 2 == 0 or input.shape[3] % 2 == 0:       # a last row / column no output tap reaches
+                input = input[:, :, :input.shape[2] - 1 + input.shape[2] % 2, :input.shape[3] - 1 + input.shape[3] % 2]
+            return modconv(input, w, s, None, bias, act, 'down', self.scale, demod_eps=eps)
         if not self.upsample:
             return modconv(input, w, s, None, bias, act, self.kind, self.scale, demod_eps=eps)
         out = modconv(input, w, s, None, None, False, 'up', self.scale, demod_eps=eps)

@@ -311,13 +311,13 @@ class _ModConvFused(Function):
         gw = gisc = gosc = None
         if need[1] or (need[2] and isc is not None) or (need[3] and osc is not None):
             slabs = _lib.rgb_wgrad_slabs(g, x) if ctx.rgb else _wgrad_raw(g, x, kind)
-            if kind == 'down':
-                if isc is not None or osc is not None:
-                    raise RuntimeError("kind 'down' carries no style modulation (discriminator path)")
+            if kind == 'down' and isc is None and osc is None:        # the discriminator's convolutions
                 gw = _slab_sum(slabs, kind).reshape(w.shape) if need[1] else None
                 if gw is not None and wscale != 1.0:
                     gw = gw * wscale
                 return gx, gw, None, None, g_bias, None, None, None, None
+            if kind == 'down':       # modulated (ModulatedConv2d(downsample=True)): slabs come as [B,S,Ci,Co,taps]
+                slabs = slabs.sum(dim=1).transpose(1, 2).contiguous().unsqueeze(1)
             w3 = w.reshape(w.shape[0], w.shape[1], -1)
             dm = ctx.demod is not None
             gw, gisc, gosc = _lib.wgrad_reduce(slabs, w3, wscale, isc, osc,
