@@ -43,15 +43,22 @@ namespace {
 #ifndef TE_FAST_IL           // the global loads of the next stage are spread over the MFMA steps of this one
 #define TE_FAST_IL 1
 #endif
+#ifdef TE_CONV_PROF
+// experimental builds: per-phase cycle counts of wave 0 of every block (s_memtime), read back with te_debug_conv_prof
+__device__ unsigned long long te_conv_prof_buf[8192 * 8];
+#define PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define PROF_T(v)
+#endif
 template <int KIND, int TC> struct Cfg;
-template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1); };
-template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1); };
+template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = (KIND == TE_CONV_S2) ? 5 : 2; };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = 1; };
+template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = 1; };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
-template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
-template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1; };
+template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1, NQ = 3; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 1; };
+template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 1; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 
@@ -76,6 +83,8 @@ struct ConvArgs {
                                  // would not fit the staging budget: the remaining cells of the tile stay unused)
         int tiles_x, tiles_y;    // tiles per sample group
         int TIH, TIW, TIWP, SS, CS;  // input tile: rows, cols, row stride, per-sample stride, per-channel stride (floats)
+        int nseg, xo, OD;        // FAST staging: 16-byte segments per tile row, LDS column of tile column 0; S2: LDS column of
+                                 // the first odd input column (even columns first)
         int first_block;         // blockIdx.x of the region's first tile
         int tapmask;             // taps that can contribute in this region (thin T2 edge regions need 3 of 9)
     } reg[3];
@@ -93,8 +102,8 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // NBW: 32-cell N blocks per wave.  T2 keeps 4 phase accumulators per cell block.
 // MS: the cell tile spans several samples (small images) -> style scales are fetched per staged element
 // FAST: every stage is a full one (K % KC == 0, host-checked): stage loads take scalar channel offsets and are spread over
-// the MFMA steps, the LDS operands are read one step ahead, and T2 runs all nine taps in every region without per-tap
-// branches, its four shifted B fragments shared by the taps (the thin edge regions then multiply some zero padding).
+// the MFMA steps, the LDS operands are read one step ahead, input tiles are staged as 16-byte row segments, and the four
+// shifted B fragments of T2 are shared by its taps.
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
 __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KIND, TC>;
@@ -107,10 +116,13 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     constexpr int WSTAGE = NTAP * KC * BM;        // floats of packed weights per stage
     constexpr int WLDR = (WSTAGE / 4 + NTHREADS - 1) / NTHREADS;   // 16-byte weight loads per thread per stage
     constexpr bool WEVEN = (WSTAGE / 4) % NTHREADS == 0;
+    constexpr int NQ = Cfg<KIND, TC>::NQ;        // FAST: (row segment, channel) pairs per thread and stage
+    constexpr bool TAP_PIECES = FAST && IS_T2 && (KC * BM / 4 == NTHREADS);   // weight piece r of a thread == tap r
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;            // [NTAP][KC][BM]
-    float* xl = smem + WSTAGE;   // [KC][CS]
+    float* iscl = smem + WSTAGE; // FAST with style scales: those of the block's sample [Kp]
+    float* xl = iscl + ((FAST && HAS_ISC) ? p.Kp : 0);   // [KC][CS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -138,21 +150,50 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     unsigned goff[NSP];      // byte offset of channel 0 relative to the tile's first sample, or OOBH for zero padding
     int loff[NSP], sb[NSP];  // LDS offset (or -1: no element for this thread), sample index
     const unsigned plane4 = (unsigned)p.Hi * p.Wi * 4u;
+    if (!FAST) {
 #pragma unroll
-    for (int r = 0; r < NSP; ++r) {
-        const int e = tid + NTHREADS * r;
-        goff[r] = OOBH; loff[r] = -1; sb[r] = 0;
-        if (e < n_sp) {
-            const int s = e / tile_sp, rem = e - s * tile_sp;
-            const int ry = rem / g.TIW, rx = rem - ry * g.TIW;
-            const int b = b0 + s, gy = oy + ry, gx = ox + rx;
-            // S2 keeps even and odd input columns of a row apart ([TW+1 even | TW odd]) so the stride-2 B-fragment
-            // reads below touch consecutive LDS words (32 banks: a stride of 2 words is a 2-way conflict)
-            const int rxl = (KIND == TE_CONV_S2) ? ((rx & 1) ? g.TW + 1 + (rx >> 1) : (rx >> 1)) : rx;
-            loff[r] = s * g.SS + ry * g.TIWP + rxl;
-            sb[r] = b < p.B ? b : 0;
-            if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
-                goff[r] = (unsigned)s * p.K * plane4 + (unsigned)(gy * p.Wi + gx) * 4u;
+        for (int r = 0; r < NSP; ++r) {
+            const int e = tid + NTHREADS * r;
+            goff[r] = OOBH; loff[r] = -1; sb[r] = 0;
+            if (e < n_sp) {
+                const int s = e / tile_sp, rem = e - s * tile_sp;
+                const int ry = rem / g.TIW, rx = rem - ry * g.TIW;
+                const int b = b0 + s, gy = oy + ry, gx = ox + rx;
+                // S2 keeps even and odd input columns of a row apart ([even | odd]) so the stride-2 B-fragment
+                // reads below touch consecutive LDS words (32 banks: a stride of 2 words is a 2-way conflict)
+                const int rxl = (KIND == TE_CONV_S2) ? ((rx & 1) ? g.OD + (rx >> 1) : (rx >> 1)) : rx;
+                loff[r] = s * g.SS + ry * g.TIWP + g.xo + rxl;
+                sb[r] = b < p.B ? b : 0;
+                if (b < p.B && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi)
+                    goff[r] = (unsigned)s * p.K * plane4 + (unsigned)(gy * p.Wi + gx) * 4u;
+            }
+        }
+    }
+    // FAST: the tile of one channel is TIH rows of nseg 16-byte segments; segment sg of a row starts at input column
+    // ox - xo + 4 sg (xo = 3 for the kinds with a left halo column, so a segment lies either wholly left of the image or
+    // starts inside it: no negative offsets).  A thread owns NQ (segment, channel-of-the-stage) pairs; the stage's first
+    // channel comes in through the scalar offset of the load.
+    unsigned qgo[FAST ? NQ : 1];     // byte offset incl. the pair's channel, or OOBH (row outside the image / no pair)
+    int qlo[FAST ? NQ : 1];          // LDS float offset incl. the channel, or -1
+    int qkk[FAST ? NQ : 1];          // channel of the pair inside the stage
+    unsigned qvm[FAST ? NQ : 1];     // bit j: component j lies inside the image horizontally
+    if (FAST) {
+        const int nitems = g.TIH * g.nseg;
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) {
+            const int q = tid + NTHREADS * r;
+            const int kk = q / nitems, item = q - kk * nitems;
+            const int ry = item / g.nseg, sg = item - ry * g.nseg;
+            const int gy = oy + ry, gx0 = ox - g.xo + 4 * sg;
+            qgo[r] = OOBH; qlo[r] = -1; qkk[r] = 0; qvm[r] = 0;
+            if (kk < KC) {
+                qkk[r] = kk;
+                qlo[r] = kk * g.CS + ry * g.TIWP + (KIND == TE_CONV_S2 ? 2 * sg : 4 * sg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qvm[r] |= (gx0 + j >= 0 && gx0 + j < p.Wi) ? (1u << j) : 0u;
+                if (gy >= 0 && gy < p.Hi && qvm[r] != 0)          // qvm != 0 implies gx0 >= 0 (see above)
+                    qgo[r] = (unsigned)kk * plane4 + (unsigned)(gy * p.Wi + gx0) * 4u;
+            }
         }
     }
     // input of the samples of this tile through one buffer descriptor: 32-bit offsets, hardware zero fill
@@ -170,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         if (KIND == TE_CONV_S2) o = 2 * ty * g.TIWP + tx;
         else if (KIND == TE_CONV_T2) o = (ty + 1) * g.TIWP + tx + 1;
         else o = ty * g.TIWP + tx;
-        boff[nb] = s * g.SS + o + half * g.CS;
+        boff[nb] = s * g.SS + o + g.xo + half * g.CS;
     }
     const int aoff = half * BM + wm * (MBW * 32) + l31;   // A-fragment base inside wl
 
@@ -184,22 +225,44 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 
     // ---- register prefetch buffers
     f32x4 wreg[WLDR];
-    float xreg[NSP][KC];
-    float sreg[(HAS_ISC && MS) ? NSP : 1][KC];   // style scales of the staged channels (applied when the tile is written to LDS)
+    float xreg[FAST ? 1 : NSP][FAST ? 1 : KC];
+    float sreg[(HAS_ISC && MS) ? NSP : 1][FAST ? 1 : KC];   // style scales of the staged channels (applied when the tile is written to LDS)
+    f32x4 xq[FAST ? NQ : 1];     // FAST: one 16-byte segment per (segment, channel) pair
+    float sq[FAST ? NQ : 1];     //       and the style scale of its channel
 
     const int kbeg = blockIdx.z * p.kchunk, kend = min(p.Kp, kbeg + p.kchunk);
     auto commit = [&](float* wlb, float* xlb) {          // prefetched registers -> one LDS stage buffer
 #pragma unroll
         for (int r = 0; r < WLDR; ++r) {
             const int idx = tid + NTHREADS * r;
-            if (WEVEN || idx < WSTAGE / 4) *reinterpret_cast<f32x4*>(wlb + idx * 4) = wreg[r];
+            if ((WEVEN || idx < WSTAGE / 4) && (!TAP_PIECES || ((g.tapmask >> r) & 1))) *reinterpret_cast<f32x4*>(wlb + idx * 4) = wreg[r];
         }
+        if (!FAST) {
 #pragma unroll
-        for (int r = 0; r < NSP; ++r) {
-            if (loff[r] >= 0) {
+            for (int r = 0; r < NSP; ++r) {
+                if (loff[r] >= 0) {
 #pragma unroll
-                for (int kk = 0; kk < KC; ++kk)
-                    xlb[kk * g.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
+                    for (int kk = 0; kk < KC; ++kk)
+                        xlb[kk * g.CS + loff[r]] = HAS_ISC ? xreg[r][kk] * sreg[MS ? r : 0][kk] : xreg[r][kk];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NQ; ++r) {
+                if (qlo[r] >= 0) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = HAS_ISC ? xq[r][j] * sq[r] : xq[r][j];
+                        v[j] = ((qvm[r] >> j) & 1) ? v[j] : 0.f;          // columns outside the image (the load wrapped into a neighbouring row)
+                    }
+                    float* d = xlb + qlo[r];
+                    if (KIND == TE_CONV_S2) {         // even columns | odd columns
+                        d[0] = v[0]; d[1] = v[2]; d[g.OD] = v[1]; d[g.OD + 1] = v[3];
+                    } else {
+                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
+                }
             }
         }
     };
@@ -216,15 +279,18 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             woff[r] = ((unsigned)(tap * p.Kp + kk) * p.Mp + m0 + c4 * 4) * 4u;
         }
     }
-    constexpr int NPIECE = WLDR + NSP * KC;       // load instructions per thread and stage
+    constexpr int NPIECE = WLDR + NQ;             // load instructions per thread and stage
     auto load_piece = [&](int kn, int i) {        // i is a compile-time constant after unrolling
         if (i < WLDR) {
-            wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[FAST ? i : 0], (unsigned)kn * p.Mp * 4u, 0));
+            // T2 at this tile class: one piece is one tap (KC * BM / 4 == NTHREADS), so the thin edge regions neither load
+            // nor commit the weights of the taps they skip (block-uniform)
+            if (!TAP_PIECES || ((g.tapmask >> i) & 1))
+                wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[FAST ? i : 0], (unsigned)kn * p.Mp * 4u, 0));
         } else {
-            const int r = (i - WLDR) / KC, kk = (i - WLDR) % KC;
-            // zero padding (goff = OOBH) fails the hardware range check whatever the scalar channel offset is
-            xreg[r][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, goff[r], (unsigned)(kn + kk) * plane4, 0));
-            if (HAS_ISC && (MS || r == 0)) sreg[MS ? r : 0][kk] = p.isc[(MS ? sb[r] : b0) * p.K + kn + kk];
+            const int r = FAST ? i - WLDR : 0;
+            // rows outside the image (qgo = OOBH) fail the hardware range check whatever the scalar channel offset is
+            xq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, qgo[r], (unsigned)kn * plane4, 0));
+            if (HAS_ISC) sq[r] = iscl[kn + qkk[r]];
         }
     };
     auto issue = [&](int kn) {                            // global loads of the stage starting at channel kn -> registers
@@ -256,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         int toff;
         if (KIND == TE_CONV_1X1) toff = 0;
         else if (KIND == TE_CONV_T2) toff = -(ky == 2 ? g.TIWP : 0) - (kx == 2 ? 1 : 0);
-        else if (KIND == TE_CONV_S2) toff = ky * g.TIWP + (kx == 1 ? g.TW + 1 : (kx >> 1));
+        else if (KIND == TE_CONV_S2) toff = ky * g.TIWP + (kx == 1 ? g.OD : (kx >> 1));
         else toff = ky * g.TIWP + kx;
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) a[mb] = wlb[(tp * KC + kk) * BM + aoff + mb * 32];
@@ -347,10 +413,12 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 pieces(st);
                 __builtin_amdgcn_sched_barrier(0);
                 const int sh = (ky == 2 ? 2 : 0) + (kx == 2 ? 1 : 0);
+                if ((g.tapmask >> tp) & 1) {       // block-uniform: the thin edge regions skip the taps that only see zero padding
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) {
-                    const int j = nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[sh][nb], acc[0][j], 0, 0, 0);
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        const int j = nb * 4 + ((ky == 1) ? 2 : 0) + ((kx == 1) ? 1 : 0);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[sh][nb], acc[0][j], 0, 0, 0);
+                    }
                 }
                 a0 = a1;
               }
@@ -364,16 +432,48 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         }
     };
     if (FAST) {
+        if (HAS_ISC) {
+            for (int k = tid; k < p.Kp; k += NTHREADS) iscl[k] = k < p.K ? p.isc[(size_t)b0 * p.K + k] : 0.f;
+            __syncthreads();
+        }
         // prologue: stage kbeg straight to registers; every iteration commits its stage, then multiplies it while the loads
         // of the next one are dealt out (the last iteration re-requests its own stage: never committed, always in range)
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) load_piece(kbeg, i);
+#ifdef TE_CONV_PROF
+        unsigned long long pc[5] = {0, 0, 0, 0, 0};
+        const unsigned long long pstart = __builtin_readcyclecounter();
+        const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int k0 = kbeg; k0 < kend; k0 += KC) {
+            PROF_T(t0);
             __syncthreads();              // every wave finished reading the previous stage
+            PROF_T(t1);
+#ifdef TE_CONV_PROF
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): separate "waiting for the stage loads" from the LDS writes
+            const unsigned long long t1b = __builtin_readcyclecounter();
+            pc[4] += t1b - t1;
+#endif
             commit(wl, xl);
+            PROF_T(t2);
             __syncthreads();
+            PROF_T(t3);
             compute_fast(wl, xl, min(k0 + KC, kend - KC));
+#ifdef TE_CONV_PROF
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            pc[0] += t1 - t0; pc[1] += t2 - t1; pc[2] += t3 - t2; pc[3] += t4 - t3;
+#endif
         }
+#ifdef TE_CONV_PROF
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((tid & 63) == 0 && lin < 8192 / 4) {
+            unsigned long long* d = te_conv_prof_buf + ((size_t)lin * 4 + wid) * 8;
+            d[0] = pc[0]; d[1] = pc[1]; d[2] = pc[2]; d[3] = pc[3]; d[4] = pstart; d[5] = __builtin_readcyclecounter();
+            d[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            d[7] = (kend - kbeg) / KC; d[6] = pc[4];
+            d[0] = pc[0] + (((unsigned long long)(__builtin_amdgcn_s_memrealtime() - rstart)) << 32);   // high half: 100 MHz ticks of the K loop
+        }
+#endif
     } else {
         // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
         // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
@@ -554,7 +654,7 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
 }
 
 template <int KIND, int TC>
-int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms, bool force_single) {
+int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size_t& lds_floats, bool& ms, bool force_single, bool fast) {
     if (rh <= 0 || rw <= 0) return 0;
     constexpr int KC = Cfg<KIND, TC>::KC, BM = tile_bm<KIND, TC>();
     constexpr int NTILE = tile_cells<KIND, TC>();
@@ -567,35 +667,46 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
         if (KIND == TE_CONV_T2) return (th + 1) * (tw + 1);
         return th * tw;
     };
+    constexpr int NSP = Cfg<KIND, TC>::NSP, NQ = Cfg<KIND, TC>::NQ;
+    auto in_rows = [](int th) { return KIND == TE_CONV_3X3 ? th + 2 : (KIND == TE_CONV_S2 ? 2 * th + 1 : (KIND == TE_CONV_T2 ? th + 1 : th)); };
+    auto in_cols = [](int tw) { return KIND == TE_CONV_3X3 ? tw + 2 : (KIND == TE_CONV_S2 ? 2 * tw + 1 : (KIND == TE_CONV_T2 ? tw + 1 : tw)); };
     g.TW = std::min(32, pow2ceil(rw));
     g.TH = std::min(pow2ceil(rh), NTILE / g.TW);
-    while (g.TH > 1 && tile_in(g.TH, g.TW) > NSP_ * NTHREADS) g.TH >>= 1;   // thin edge regions: one sample must fit
+    g.xo = 0; g.nseg = 0;
+    if (!fast) {
+        while (g.TH > 1 && tile_in(g.TH, g.TW) > NSP_ * NTHREADS) g.TH >>= 1;   // thin edge regions: one sample must fit
+    } else {
+        // FAST staging: rows of 16-byte segments; the kinds with a left halo column start their rows 3 columns early so
+        // that no segment straddles the left image border.  NQ (segment, channel) pairs per thread must cover a stage.
+        g.xo = ((KIND == TE_CONV_3X3 || KIND == TE_CONV_T2) && rj0 == 0) ? 3 : 0;   // regions off the left border never reach column -1
+        g.nseg = (g.xo + in_cols(g.TW) + 3) / 4;
+        while (g.TH > 1 && in_rows(g.TH) * g.nseg * KC > NQ * NTHREADS) g.TH >>= 1;
+        if (in_rows(g.TH) * g.nseg * KC > NQ * NTHREADS)
+            return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile of %d rows x %d segments exceeds the staging budget", in_rows(g.TH), g.nseg);
+    }
     g.NS = NTILE / (g.TW * g.TH);
     g.lgTW = ilog2(g.TW); g.lgTH = ilog2(g.TH);
     g.tiles_x = (rw + g.TW - 1) / g.TW;
     g.tiles_y = (rh + g.TH - 1) / g.TH;
-    if (KIND == TE_CONV_3X3) { g.TIH = g.TH + 2; g.TIW = g.TW + 2; }
-    else if (KIND == TE_CONV_S2) { g.TIH = 2 * g.TH + 1; g.TIW = 2 * g.TW + 1; }
-    else if (KIND == TE_CONV_T2) { g.TIH = g.TH + 1; g.TIW = g.TW + 1; }
-    else { g.TIH = g.TH; g.TIW = g.TW; }
-    g.TIWP = g.TIW;
+    g.TIH = in_rows(g.TH); g.TIW = in_cols(g.TW);
+    g.TIWP = fast ? 4 * g.nseg : g.TIW;
+    g.OD = fast ? 2 * g.nseg : g.TW + 1;
     g.SS = g.TIH * g.TIWP;
     g.CS = g.NS * g.SS;
-    constexpr int NSP = Cfg<KIND, TC>::NSP;
     // edge regions of a single-sample launch stay single-sample, so the whole launch keeps the cheap scalar
     // style-scale path (MS = false); their tiles are merely less full
     g.NSv = force_single ? 1 : g.NS;
-    while (g.NSv > 1 && g.NSv * g.TIH * g.TIW > NSP * NTHREADS) g.NSv >>= 1;
+    while (!fast && g.NSv > 1 && g.NSv * g.TIH * g.TIW > NSP * NTHREADS) g.NSv >>= 1;
     if ((int64_t)g.NSv * a.K * a.Hi * a.Wi * 4 >= (int64_t)OOBH)
         return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: %d samples x %d channels x %dx%d exceed 1 GiB per tile group", g.NSv, a.K, a.Hi, a.Wi);
-    if (g.NSv * g.TIH * g.TIW > NSP * NTHREADS)
+    if (!fast && g.NSv * g.TIH * g.TIW > NSP * NTHREADS)
         return te::fail(TE_ERR_UNSUPPORTED, "te_conv_f32: input tile %dx%dx%d exceeds the staging budget", g.NSv, g.TIH, g.TIW);
     g.first_block = nblocks;
     g.tapmask = 0x1FF;
     if (KIND == TE_CONV_T2 && ri0 == a.H && rh == 1) g.tapmask = 0x1C0;            // last output row: only ky == 2 reaches it
     if (KIND == TE_CONV_T2 && rj0 == a.W && rw == 1) g.tapmask = 0x124;            // last output column: only kx == 2
     nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NSv - 1) / g.NSv);
-    lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS);
+    lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS + (size_t)((fast && a.isc) ? a.Kp : 0));
     ms = ms || g.NSv > 1;
     a.nreg++;
     return 0;
@@ -612,42 +723,50 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
     conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
 }
 
+template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && TC == 0 && KIND != TE_CONV_1X1; }
+
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
-void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
-    // FAST kernels exist for the 128-row tile class of the 3x3 family with one sample per tile (the layers that carry the
-    // FLOPs); they need whole stages: K and the split-K chunk multiples of the stage depth
-    constexpr bool HAVE_FAST = TE_CONV_FAST && TC == 0 && !MS && KIND != TE_CONV_1X1;
-    constexpr int KC = Cfg<KIND, TC>::KC;
-    if (HAVE_FAST && a.K % KC == 0 && a.K == a.Kp && (a.ksplit == 1 || a.kchunk % KC == 0))
-        launch_f<KIND, TC, HAS_ISC, MS, OCC, HAVE_FAST>(a, nblocks, lds_floats, s);
-    else
-        launch_f<KIND, TC, HAS_ISC, MS, OCC, false>(a, nblocks, lds_floats, s);
+void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
+    constexpr bool HAVE_FAST = have_fast<KIND, TC>() && !MS;
+    if (HAVE_FAST && fast) launch_f<KIND, TC, HAS_ISC, MS, OCC, HAVE_FAST>(a, nblocks, lds_floats, s);
+    else launch_f<KIND, TC, HAS_ISC, MS, OCC, false>(a, nblocks, lds_floats, s);
 }
 
 template <int KIND, int TC, bool HAS_ISC, bool MS>
-void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
+void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
     // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168)
     constexpr bool CAN3 = (KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS);
-    if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2>(a, nblocks, lds_floats, s);
-    else launch_o<KIND, TC, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s);
+    if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2>(a, nblocks, lds_floats, s, fast);
+    else launch_o<KIND, TC, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s, fast);
 }
 
 // regions: list of {ri0, rj0, rh, rw}
 template <int KIND, int TC>
 int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s) {
+    constexpr int KC = Cfg<KIND, TC>::KC;
     int nblocks = 0;
     size_t lds_floats = 0;
     bool ms = false;
-    a.nreg = 0;
-    for (int i = 0; i < n; ++i) {
-        const int rc = add_region<KIND, TC>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms,
-                                        i > 0 && a.nreg > 0 && a.reg[0].NSv == 1);
-        if (rc) return rc;
+    // FAST kernels exist for the 128-row tile class of the 3x3 family with one sample per tile (the layers that carry the
+    // FLOPs); they need whole stages (K and the split-K chunk multiples of the stage depth).  Their input-tile layout
+    // differs, so the regions are laid out twice when the first pass shows that the launch qualifies.
+    bool fast = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        nblocks = 0; lds_floats = 0; ms = false; a.nreg = 0;
+        for (int i = 0; i < n; ++i) {
+            const int rc = add_region<KIND, TC>(a, regions[i][0], regions[i][1], regions[i][2], regions[i][3], nblocks, lds_floats, ms,
+                                            fast || (i > 0 && a.nreg > 0 && a.reg[0].NSv == 1), fast);
+            if (rc) return rc;
+        }
+        if (pass == 1 || nblocks == 0) break;
+        fast = have_fast<KIND, TC>() && !ms && a.K == a.Kp && a.K % KC == 0 && (a.ksplit == 1 || a.kchunk % KC == 0) &&
+               a.reg[0].NS == 1 && a.reg[0].TW >= 4;      // TW >= 4: row segments never straddle the left image border
+        if (!fast) break;
     }
     if (nblocks == 0) return 0;
-    if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s);
-    else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s);
-    else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s);
+    if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s, fast);
+    else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s, fast);
+    else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s, fast);
     return 0;
 }
 
@@ -663,6 +782,12 @@ int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_
 }
 
 }  // namespace
+
+#ifdef TE_CONV_PROF
+extern "C" int te_debug_conv_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_conv_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize) {
     const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
