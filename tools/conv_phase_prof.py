@@ -61,8 +61,36 @@ def run(kind, K, M, H, B=16):
     print(f'   K loop {loop.mean():.0f} of {tot.mean():.0f} cycles per block ({100 * loop.mean() / tot.mean():.1f} %); per stage {(loop / st).mean():.0f}')
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'conv' in sys.argv:
     run('T2', 512, 256, 64)
     run('T2', 256, 128, 128)
     run('3X3', 256, 256, 128)
     run('S2', 256, 512, 64)
+
+
+def run_wgrad(kind, K, M, H, B=16):
+    torch.manual_seed(0)
+    code = _lib.CONV_T2 if kind == 'WT2' else _lib.CONV_3X3
+    g = torch.randn(B, M, 2 * H + 1, 2 * H + 1, device=DEV) if kind == 'WT2' else torch.randn(B, M, H, H, device=DEV)
+    x = torch.randn(B, K, H, H, device=DEV)
+    for _ in range(3):
+        _lib.wgrad_slabs(g, x, code, H, H)
+    torch.cuda.synchronize()
+    buf = np.zeros(8192 * 8, dtype=np.uint64)
+    L = _lib.lib()
+    L.te_debug_wgrad_prof.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    assert L.te_debug_wgrad_prof(buf.ctypes.data, buf.nbytes) == 0
+    d = buf.reshape(-1, 8).astype(np.float64)
+    d = d[d[:, 7] > 0]
+    nt = d[:, 7]
+    print(f'{kind} {K}->{M} @{H}: {len(d)} wave records, tiles/block {nt.mean():.1f}')
+    for i, n in enumerate(('barrier', 'commit', '-', 'issue loads', 'mfma steps', 'first operands')):
+        per = d[:, i] / nt
+        print(f'   {n:11s}: mean {per.mean():8.0f}  p10 {np.percentile(per, 10):8.0f}  p90 {np.percentile(per, 90):8.0f}   cycles per tile')
+    print(f'   total per tile {(d[:, 6] / nt).mean():.0f}')
+
+
+if __name__ == '__main__':
+    run_wgrad('W3X3', 128, 128, 256)
+    run_wgrad('W3X3', 256, 256, 128)
+    run_wgrad('WT2', 512, 256, 64)

@@ -59,6 +59,14 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+#ifdef TE_CONV_PROF
+// experimental builds: per-phase cycle counts (s_memtime) of every wave, read back with te_debug_wgrad_prof
+__device__ unsigned long long te_wgrad_prof_buf[8192 * 8];
+#define WPROF(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pc[i] += t_ - tlast; tlast = t_; }
+#else
+#define WPROF(i)
+#endif
+
 template <int KIND, int NWP>
 __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p) {
     constexpr int NTHREADS = NWP * 128;
@@ -115,89 +123,108 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     // lane bases inside the LDS tiles: g is the A operand, x the B operand
     const int a_ch = (GSHIFT ? qb : pb) * 32 + l31;     // co of this lane inside the block tile
     const int b_ch = (GSHIFT ? pb : qb) * 32 + l31;     // ci of this lane inside the block tile
-    const float* g_l = (GSHIFT ? ql : pl) + a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half);
-    const float* x_l = (GSHIFT ? pl : ql) + b_ch * (GSHIFT ? p.PS : p.QS) + half;
 
     const int n_tiles = p.tiles_x * p.tiles_y;
     const int t_begin = (int)((int64_t)n_tiles * s_chunk / p.S), t_end = (int)((int64_t)n_tiles * (s_chunk + 1) / p.S);
 
     float preg[NP], qreg[NQ];
-    for (int tl = t_begin - 1; tl < t_end; ++tl) {
-        constexpr bool QVEC = (KIND != TE_CONV_T2);     // the shifted operand of T2 has odd row width: scalar loads
-        constexpr int NP4 = NP / 4, NQ4 = (KIND == TE_CONV_3X3) ? (NQ - 1) / 4 : NQ / 4;
-        constexpr bool TVEC = (KIND == TE_CONV_T2);
-        if (TVEC && tl >= t_begin && p.vec) {
-            __syncthreads();
+#ifdef TE_CONV_PROF
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long pstart = tlast;
+#endif
+    // ---- tile loop, double-buffered LDS (two [plain | shifted] operand images, <= 2 x 68 KB): while the MFMAs of tile t run
+    // on one image, tile t+1 (already in registers) is written to the other and the loads of tile t+2 are issued, so a
+    // tile costs ONE workgroup barrier and no phase in which the matrix pipe waits for staging.
+    constexpr bool QVEC = (KIND != TE_CONV_T2);     // the shifted operand of T2 has odd row width: scalar loads
+    constexpr int NP4 = NP / 4, NQ4 = (KIND == TE_CONV_3X3) ? (NQ - 1) / 4 : NQ / 4;
+    constexpr bool TVEC = (KIND == TE_CONV_T2);
+    const int bufsz = PCH * p.PS + QCH * p.QS;      // floats of one operand image
+    // ---- 16-byte staging path (p.vec: full 32-cell rows, NC == NCELL): every stride is a compile-time constant and a thread's
+    // loads differ by uniform steps, so a tile costs a handful of vector-ALU instructions of address work (each of them has to
+    // find an issue slot between the other wave's MFMAs: ~50 cycles apiece when the matrix pipe is saturated).
+    //   plain operand  : float4 index tid + NTHREADS * r -> channel step CSTEP per r, same cells
+    //   shifted operand: 8 threads per channel (sub = tid & 7), load r = tile row r (T2: row r >> 1, half r & 1), segment sub
+    constexpr int NCV = WK<KIND>::NCELL, THV = NCV / 32, PSV = NCV | 1;
+    constexpr int QHV = (KIND == TE_CONV_3X3) ? THV + 2 : (KIND == TE_CONV_T2 ? 2 * THV + 1 : THV);
+    constexpr int QWV = (KIND == TE_CONV_3X3) ? 34 : (KIND == TE_CONV_T2 ? 65 : 32);
+    constexpr int QSV = (QHV * QWV) | 1;
+    constexpr int FP4 = NCV / 4, CSTEP = NTHREADS / FP4;            // plain: float4 per channel, channels per sweep
+    constexpr int QSW = (QCH * 8 + NTHREADS - 1) / NTHREADS;        // shifted: sweeps of NTHREADS / 8 channels
+    constexpr int QRL = (KIND == TE_CONV_T2) ? 2 * QHV : QHV;       // 16-byte loads per thread and sweep
+    static_assert(NP4 * CSTEP == PCH && QSW * QRL * 4 + (KIND == TE_CONV_1X1 ? 0 : QSW) <= NQ, "staging registers");
+    const int v_chl0 = tid / FP4, v_c4 = (tid % FP4) * 4;
+    const int v_pgo = ((pc0 + v_chl0) * pH + (v_c4 >> 5)) * pW + (v_c4 & 31);        // elements, tile origin excluded
+    const int v_plo = v_chl0 * PSV + v_c4;
+    const int v_qch = tid >> 3, v_sub = tid & 7;
+    const int v_qgo = (qc0 + v_qch) * qH * qW + 4 * v_sub;
+    const int v_qlo = v_qch * QSV + ((KIND == TE_CONV_3X3) ? 1 : 0) + 4 * v_sub;
+    auto issue_vec = [&](int tn) {
+        const int ty0 = (tn / p.tiles_x) * p.TH, tx0 = (tn % p.tiles_x) * p.TW;   // first cell of the tile
+        const int qy0 = (KIND == TE_CONV_3X3) ? ty0 - 1 : (KIND == TE_CONV_T2 ? 2 * ty0 : ty0);
+        const int qx0 = (KIND == TE_CONV_T2) ? 2 * tx0 : tx0;
+        const int pb4 = (v_pgo + ty0 * pW + tx0) * 4;
 #pragma unroll
-            for (int r = 0; r < NP4; ++r) {
-                int it = tid + NTHREADS * r;
-                asm volatile("" : "+v"(it));
-                const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
-                if (chl < PCH) {
+        for (int r = 0; r < NP4; ++r) {
+            const f32x4 v = buf_load4(prs, (unsigned)(pb4 + r * CSTEP * pH * pW * 4));     // channels past pC: beyond num_records -> 0
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pl[chl * p.PS + cell + j] = preg[4 * r + j];
-                }
+            for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
+        }
+        const int qb = v_qgo + qy0 * qW + qx0;          // may be "negative" (row -1 of channel 0): only used when the row is valid
+#pragma unroll
+        for (int sw = 0; sw < QSW; ++sw) {
+#pragma unroll
+            for (int r = 0; r < QRL; ++r) {
+                const int ry = (KIND == TE_CONV_T2) ? (r >> 1) : r, hx = (KIND == TE_CONV_T2) ? 32 * (r & 1) : 0;
+                const bool rok = (unsigned)(qy0 + ry) < (unsigned)qH;                       // wave-uniform
+                const f32x4 v = buf_load4(qrs, rok ? (unsigned)((qb + sw * (NTHREADS / 8) * qH * qW + ry * qW + hx) * 4) : OOB);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qreg[4 * (sw * QRL + r) + j] = v[j];
             }
+        }
+        if (KIND == TE_CONV_3X3) {        // the two halo columns of every (channel, row): thread sub -> (row sub >> 1, side sub & 1)
+            const int ry = v_sub >> 1, side = v_sub & 1;
+            const bool ok = (unsigned)(qy0 + ry) < (unsigned)qH && (side ? tx0 + 32 < qW : tx0 > 0);
 #pragma unroll
-            for (int r = 0; r < NQ / 4; ++r) {
-                unsigned it = tid + NTHREADS * r;
-                asm volatile("" : "+v"(it));
-                const unsigned chl = __umulhi(it, p.magic_q16), rem = it - chl * (p.QH * 16);
-                if (chl < QCH) {
+            for (int sw = 0; sw < QSW; ++sw)
+                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + ry * qW + (side ? 32 : -1)) * 4) : OOB);
+        } else if (KIND == TE_CONV_T2) {  // column 64 of the 65-wide rows: threads with sub < 3 take row sub
+            const bool ok = v_sub < QHV;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ql[chl * p.QS + (rem >> 4) * p.QW + 4 * (rem & 15) + j] = qreg[4 * r + j];
-                }
+            for (int sw = 0; sw < QSW; ++sw)
+                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + v_sub * qW + 64) * 4) : OOB);
+        }
+    };
+    auto commit_vec = [&](float* pl, float* ql) {
+#pragma unroll
+        for (int r = 0; r < NP4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pl[v_plo + r * CSTEP * PSV + j] = preg[4 * r + j];
+#pragma unroll
+        for (int sw = 0; sw < QSW; ++sw) {
+#pragma unroll
+            for (int r = 0; r < QRL; ++r) {
+                const int ry = (KIND == TE_CONV_T2) ? (r >> 1) : r, hx = (KIND == TE_CONV_T2) ? 32 * (r & 1) : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ql[v_qlo + sw * (NTHREADS / 8) * QSV + ry * QWV + hx + j] = qreg[4 * (sw * QRL + r) + j];
             }
-            {
-                const unsigned it = tid, chl = __umulhi(it, p.magic_q1), ry = it - chl * p.QH;
-                if (chl < QCH) ql[chl * p.QS + ry * p.QW + 64] = qreg[NQ - 1];
+        }
+        if (KIND == TE_CONV_3X3) {
+            const int ry = v_sub >> 1, side = v_sub & 1;
+#pragma unroll
+            for (int sw = 0; sw < QSW; ++sw)
+                ql[(v_qch + sw * (NTHREADS / 8)) * QSV + ry * QWV + (side ? QWV - 1 : 0)] = qreg[4 * QSW * QRL + sw];
+        } else if (KIND == TE_CONV_T2) {
+            if (v_sub < QHV) {
+#pragma unroll
+                for (int sw = 0; sw < QSW; ++sw) ql[(v_qch + sw * (NTHREADS / 8)) * QSV + v_sub * QWV + 64] = qreg[4 * QSW * QRL + sw];
             }
-            __syncthreads();
-        } else if (QVEC && tl >= t_begin && p.vec) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < NP4; ++r) {
-                int it = tid + NTHREADS * r;
-                asm volatile("" : "+v"(it));
-                const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
-                if (chl < PCH) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pl[chl * p.PS + cell + j] = preg[4 * r + j];
-                }
-            }
-            if (QVEC) {
-                const int halo = (KIND == TE_CONV_3X3) ? 1 : 0;
-#pragma unroll
-                for (int r = 0; r < NQ4; ++r) {
-                    unsigned it = tid + NTHREADS * r;
-                    asm volatile("" : "+v"(it));
-                    const unsigned chl = __umulhi(it, p.magic_q8), rem = it - chl * (p.QH * 8);
-                    const unsigned ry = rem >> 3, seg = rem & 7;
-                    if (chl < QCH) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) ql[chl * p.QS + ry * p.QW + halo + 4 * seg + j] = qreg[4 * r + j];
-                    }
-                }
-                if (KIND == TE_CONV_3X3) {
-#pragma unroll
-                    for (int e = 0; e < 512 / NTHREADS; ++e) {        // the QCH * QH * 2 = 512 halo columns
-                        unsigned it = tid + NTHREADS * e;
-                        const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
-                        if (chl < QCH) ql[chl * p.QS + (rem >> 1) * p.QW + ((rem & 1) ? p.QW - 1 : 0)] = qreg[4 * NQ4 + e];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < NQ; ++r) {
-                    unsigned e = tid + NTHREADS * r;
-                    asm volatile("" : "+v"(e));
-                    const unsigned ch = __umulhi(e, p.magic_qt), rem = e - ch * q_tile;
-                    if (ch < QCH) ql[ch * p.QS + rem] = qreg[r];
-                }
-            }
-            __syncthreads();
-        } else if (tl >= t_begin) {
-            __syncthreads();
+        }
+    };
+    auto commit = [&](float* pl, float* ql) {       // staged registers -> one LDS image
+        if (p.vec) {
+            commit_vec(pl, ql);
+        } else {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 int e = tid + NTHREADS * r;
@@ -212,91 +239,16 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 const unsigned ch = __umulhi(e, p.magic_qt), rem = e - ch * q_tile;
                 if (ch < QCH) ql[ch * p.QS + rem] = qreg[r];       // tile stored [row][col] with stride QW == linear rem
             }
-            __syncthreads();
         }
-        const int tn = tl + 1;
-        if (tn < t_end) {
-            const int ty0 = (tn / p.tiles_x) * p.TH, tx0 = (tn % p.tiles_x) * p.TW;   // first cell of the tile
-            int qy0, qx0;
-            if (KIND == TE_CONV_3X3) { qy0 = ty0 - 1; qx0 = tx0 - 1; }
-            else if (KIND == TE_CONV_T2) { qy0 = 2 * ty0; qx0 = 2 * tx0; }
-            else { qy0 = ty0; qx0 = tx0; }
-            if (TVEC && p.vec) {
-#pragma unroll
-                for (int r = 0; r < NP4; ++r) {
-                    int it = tid + NTHREADS * r;
-                    asm volatile("" : "+v"(it));
-                    const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
-                    const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
-                    const bool ok = chl < PCH && y < p.H && ch < pC;
-                    const f32x4 v = buf_load4(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
-                }
-#pragma unroll
-                for (int r = 0; r < NQ / 4; ++r) {     // 16-byte loads at 4-byte alignment (rows are 2W+1 wide)
-                    unsigned it = tid + NTHREADS * r;
-                    asm volatile("" : "+v"(it));
-                    const unsigned chl = __umulhi(it, p.magic_q16), rem = it - chl * (p.QH * 16);
-                    const int y = qy0 + (int)(rem >> 4), xx = qx0 + 4 * (int)(rem & 15), ch = qc0 + (int)chl;
-                    const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && ch < qC;
-                    const f32x4 v = buf_load4(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qreg[4 * r + j] = v[j];
-                }
-                {
-                    const unsigned it = tid, chl = __umulhi(it, p.magic_q1), ry = it - chl * p.QH;
-                    const int y = qy0 + (int)ry, xx = qx0 + 64, ch = qc0 + (int)chl;
-                    const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
-                    qreg[NQ - 1] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
-                }
-            } else if (QVEC && p.vec) {
-#pragma unroll
-                for (int r = 0; r < NP4; ++r) {
-                    int it = tid + NTHREADS * r;
-                    asm volatile("" : "+v"(it));
-                    const int chl = it >> (p.lgNC - 2), cell = (it & ((p.NC >> 2) - 1)) << 2;
-                    const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
-                    const bool ok = chl < PCH && y < p.H && ch < pC;
-                    const f32x4 v = buf_load4(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
-                }
-                if (QVEC) {
-#pragma unroll
-                    for (int r = 0; r < NQ4; ++r) {
-                        unsigned it = tid + NTHREADS * r;
-                        asm volatile("" : "+v"(it));
-                        const unsigned chl = __umulhi(it, p.magic_q8), rem = it - chl * (p.QH * 8);
-                        const int y = qy0 + (int)(rem >> 3), xx = tx0 + 4 * (int)(rem & 7), ch = qc0 + (int)chl;
-                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && ch < qC;
-                        const f32x4 v = buf_load4(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) qreg[4 * r + j] = v[j];
-                    }
-                    if (KIND == TE_CONV_3X3) {     // the two halo columns of every (channel, row)
-#pragma unroll
-                        for (int e = 0; e < 512 / NTHREADS; ++e) {
-                            unsigned it = tid + NTHREADS * e;
-                            const unsigned chl = __umulhi(it, p.magic_q2), rem = it - chl * (p.QH * 2);
-                            const int y = qy0 + (int)(rem >> 1), xx = (rem & 1) ? tx0 + p.TW : tx0 - 1, ch = qc0 + (int)chl;
-                            const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
-                            qreg[4 * NQ4 + e] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < NQ; ++r) {
-                        unsigned e = tid + NTHREADS * r;
-                        asm volatile("" : "+v"(e));
-                        const unsigned chl = __umulhi(e, p.magic_qt), rem = e - chl * q_tile;
-                        const unsigned ry = __umulhi(rem, p.magic_qw), rx = rem - ry * p.QW;
-                        const int y = qy0 + (int)ry, xx = qx0 + (int)rx, ch = qc0 + (int)chl;
-                        const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
-                        qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
-                    }
-                }
-            } else {
+    };
+    auto issue = [&](int tn) {                      // global loads of tile tn -> registers
+        if (p.vec) { issue_vec(tn); return; }
+        const int ty0 = (tn / p.tiles_x) * p.TH, tx0 = (tn % p.tiles_x) * p.TW;   // first cell of the tile
+        int qy0, qx0;
+        if (KIND == TE_CONV_3X3) { qy0 = ty0 - 1; qx0 = tx0 - 1; }
+        else if (KIND == TE_CONV_T2) { qy0 = 2 * ty0; qx0 = 2 * tx0; }
+        else { qy0 = ty0; qx0 = tx0; }
+        {
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 int e = tid + NTHREADS * r;
@@ -317,32 +269,32 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
             }
             }
-        }
-        if (tl < t_begin) continue;
+    };
 
-        // ---- MFMAs over the cells of the staged tile (2 cells per k-step: lane half h takes cell 2*ks + h);
-        //      operands of step ks+1 are read from LDS before the MFMAs of step ks are issued
-        const int nks = p.NC >> 1;
-        float a_c[GSHIFT ? NT : 1], b_c[GSHIFT ? 1 : NT];
-        auto pos_shift = [&](int ks) {
-            const int c0 = 2 * ks, cy = c0 >> p.lgTW, cx = c0 & (p.TW - 1);
-            return (KIND == TE_CONV_T2) ? 2 * cy * p.QW + 2 * cx : cy * p.QW + cx;
-        };
-        {
-            const int k0 = min(kw, nks - 1);
-            const int sh = pos_shift(k0);
-            if (!GSHIFT) {
-                a_c[0] = g_l[2 * k0];
+    // ---- MFMAs over the cells of a staged tile (2 cells per k-step: lane half h takes cell 2*ks + h);
+    //      operands of step ks+1 are read from LDS before the MFMAs of step ks are issued
+    const int nks = p.NC >> 1;
+    float a_c[GSHIFT ? NT : 1], b_c[GSHIFT ? 1 : NT];
+    auto pos_shift = [&](int ks) {
+        const int c0 = 2 * ks, cy = c0 >> p.lgTW, cx = c0 & (p.TW - 1);
+        return (KIND == TE_CONV_T2) ? 2 * cy * p.QW + 2 * cx : cy * p.QW + cx;
+    };
+    auto first_operands = [&](const float* g_l, const float* x_l) {
+        const int k0 = min(kw, nks - 1);
+        const int sh = pos_shift(k0);
+        if (!GSHIFT) {
+            a_c[0] = g_l[2 * k0];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b_c[t] = x_l[sh + ((NT == 1) ? 0 : (t / 3) * p.QW + (t % 3))];
-            } else {
-                b_c[0] = x_l[2 * k0];
+            for (int t = 0; t < NT; ++t) b_c[t] = x_l[sh + ((NT == 1) ? 0 : (t / 3) * p.QW + (t % 3))];
+        } else {
+            b_c[0] = x_l[2 * k0];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a_c[t] = g_l[sh + (t / 3) * p.QW + (t % 3)];
-            }
+            for (int t = 0; t < NT; ++t) a_c[t] = g_l[sh + (t / 3) * p.QW + (t % 3)];
         }
+    };
+    auto steps = [&](const float* g_l, const float* x_l, int ks_from, int ks_to) {      // k-steps ks_from <= ks < ks_to
 #pragma unroll 2
-        for (int ks = kw; ks < nks; ks += kstride) {
+        for (int ks = ks_from; ks < ks_to; ks += kstride) {
             float a_n[GSHIFT ? NT : 1], b_n[GSHIFT ? 1 : NT];
             const int kn = (ks + kstride < nks) ? ks + kstride : ks;          // last step re-reads itself (harmless)
             const int sh = pos_shift(kn);
@@ -366,7 +318,51 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 for (int t = 0; t < NT; ++t) a_c[t] = a_n[t];
             }
         }
+    };
+
+    const int g_off = a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half) + (GSHIFT ? PCH * p.PS : 0);   // inside an image
+    const int x_off = b_ch * (GSHIFT ? p.PS : p.QS) + half + (GSHIFT ? 0 : PCH * p.PS);
+    if (t_begin < t_end) {
+        issue(t_begin);
+        commit(smem, smem + PCH * p.PS);
+        if (t_begin + 1 < t_end) issue(t_begin + 1);
     }
+    __syncthreads();
+    // split points of the k-step range (multiples of kstride past kw)
+    const int nst = (nks - kw + kstride - 1) / kstride;
+    const int ks1 = kw + (nst / 4) * kstride, ks2 = kw + (nst / 2) * kstride;      // (offsetting the split points between the two
+                                                                                      // waves of a SIMD measured slower: 124 vs 130 TFLOP/s)
+    for (int tl = t_begin; tl < t_end; ++tl) {
+        WPROF(5)
+        float* cur = smem + ((tl - t_begin) & 1) * bufsz;
+        float* nxt = smem + (((tl - t_begin) & 1) ^ 1) * bufsz;
+        const float* g_l = cur + g_off;
+        const float* x_l = cur + x_off;
+        first_operands(g_l, x_l);
+        steps(g_l, x_l, kw, ks1);
+        WPROF(4)
+        if (tl + 1 < t_end) commit(nxt, nxt + PCH * p.PS);      // tile tl+1: loaded while tile tl-1 was multiplied
+        WPROF(1)
+        steps(g_l, x_l, ks1, ks2);
+        WPROF(4)
+        if (tl + 2 < t_end) issue(tl + 2);
+        WPROF(3)
+        steps(g_l, x_l, ks2, nks);
+        WPROF(4)
+        __syncthreads();                    // everyone is done reading `cur` and writing `nxt`
+        WPROF(0)
+    }
+#ifdef TE_CONV_PROF
+    {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lane == 0 && lin * (NTHREADS / 64) + wid < 8192) {
+            unsigned long long* d = te_wgrad_prof_buf + ((size_t)lin * (NTHREADS / 64) + wid) * 8;
+            for (int i = 0; i < 6; ++i) d[i] = pc[i];
+            d[6] = __builtin_readcyclecounter() - pstart;
+            d[7] = t_end - t_begin;
+        }
+    }
+#endif
 
     if constexpr (NWP == 2) {
         if (kstride > 1) {        // block-uniform: combine the K-split partial tiles, one round per extra share
@@ -437,7 +433,7 @@ bool fill_geometry(WgArgs& a) {
     a.magic_q1 = magic((unsigned)a.QH);
     // the 16-byte staging path needs full 32-cell rows whose global rows are 16 B aligned, and its one edge pass
     // (QCH * QH * 2 = 512 scalars at the full 64-cell tile) takes 512 / NTHREADS sweeps of the block
-    a.vec = (a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && QCH * a.QH * 2 <= 512 &&
+    a.vec = (a.TW == 32 && a.W % 32 == 0 && a.NC == WK<KIND>::NCELL && a.H % a.TH == 0 && QCH * a.QH * 2 <= 512 &&
              (((uintptr_t)a.g | (uintptr_t)a.x) & 15) == 0) ? 1 : 0;
     return QCH * a.QH * a.QW <= WK<KIND>::NQ8 * 512 && a.NC <= WK<KIND>::NCELL;
 }
@@ -447,10 +443,10 @@ inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
-    size_t lds = sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);
+    size_t lds = 2 * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);      // two operand images (double buffering)
     if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 128 * 1024);
+    te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);
     dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
     wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);
@@ -745,6 +741,12 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
 }
 
 }  // namespace
+
+#ifdef TE_CONV_PROF
+extern "C" int te_debug_wgrad_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_wgrad_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
