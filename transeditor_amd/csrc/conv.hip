@@ -173,25 +173,37 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     // ox - xo + 4 sg (xo = 3 for the kinds with a left halo column, so a segment lies either wholly left of the image or
     // starts inside it: no negative offsets).  A thread owns NQ (segment, channel-of-the-stage) pairs; the stage's first
     // channel comes in through the scalar offset of the load.
-    unsigned qgo[FAST ? NQ : 1];     // byte offset incl. the pair's channel, or OOBH (row outside the image / no pair)
-    int qlo[FAST ? NQ : 1];          // LDS float offset incl. the channel, or -1
+    unsigned qgo[FAST ? NQ : 1];     // byte offset incl. the pair's channel, or OOBH (nothing of it lies inside the image / no pair)
+    int qlo[FAST ? NQ : 1];          // LDS float offset incl. the channel (threads without a pair: a dump slot behind the tile)
     int qkk[FAST ? NQ : 1];          // channel of the pair inside the stage
     unsigned qvm[FAST ? NQ : 1];     // bit j: component j lies inside the image horizontally
+    // Columns the MFMAs read are LDS columns [xo, xo + TIW) of a row.  Those outside the image must hold 0; when they start
+    // on a segment boundary (the usual case: image widths and tile origins are multiples of 4) whole segments fail the range
+    // check and nothing needs masking at commit time; otherwise (block-uniform) the commit zeroes by component.
+    bool need_mask = false;
     if (FAST) {
         const int nitems = g.TIH * g.nseg;
+        const int c_lo = g.xo - ox;                  // LDS column of input column 0
+        const int c_hi = c_lo + p.Wi;                // LDS column of the first input column past the image
+        need_mask = (c_lo > g.xo && (c_lo & 3)) || (c_hi < g.xo + g.TIW && (c_hi & 3));
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
             const int q = tid + NTHREADS * r;
             const int kk = q / nitems, item = q - kk * nitems;
             const int ry = item / g.nseg, sg = item - ry * g.nseg;
             const int gy = oy + ry, gx0 = ox - g.xo + 4 * sg;
-            qgo[r] = OOBH; qlo[r] = -1; qkk[r] = 0; qvm[r] = 0;
+            qgo[r] = OOBH; qlo[r] = KC * g.CS; qkk[r] = 0; qvm[r] = 0;
             if (kk < KC) {
                 qkk[r] = kk;
                 qlo[r] = kk * g.CS + ry * g.TIWP + (KIND == TE_CONV_S2 ? 2 * sg : 4 * sg);
+                unsigned used = 0;                   // components that are read AND inside the image
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qvm[r] |= (gx0 + j >= 0 && gx0 + j < p.Wi) ? (1u << j) : 0u;
-                if (gy >= 0 && gy < p.Hi && qvm[r] != 0)          // qvm != 0 implies gx0 >= 0 (see above)
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = gx0 + j >= 0 && gx0 + j < p.Wi;
+                    qvm[r] |= in ? (1u << j) : 0u;
+                    used |= (in && 4 * sg + j >= g.xo && 4 * sg + j < g.xo + g.TIW) ? (1u << j) : 0u;
+                }
+                if (gy >= 0 && gy < p.Hi && used != 0)           // used != 0 implies gx0 >= 0 (see above)
                     qgo[r] = (unsigned)kk * plane4 + (unsigned)(gy * p.Wi + gx0) * 4u;
             }
         }
@@ -249,19 +261,20 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
         } else {
 #pragma unroll
             for (int r = 0; r < NQ; ++r) {
-                if (qlo[r] >= 0) {
-                    float v[4];
+                float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = HAS_ISC ? xq[r][j] * sq[r] : xq[r][j];
-                        v[j] = ((qvm[r] >> j) & 1) ? v[j] : 0.f;          // columns outside the image (the load wrapped into a neighbouring row)
-                    }
-                    float* d = xlb + qlo[r];
-                    if (KIND == TE_CONV_S2) {         // even columns | odd columns
-                        d[0] = v[0]; d[1] = v[2]; d[g.OD] = v[1]; d[g.OD + 1] = v[3];
-                    } else {
-                        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
-                    }
+                for (int j = 0; j < 4; ++j) v[j] = HAS_ISC ? xq[r][j] * sq[r] : xq[r][j];
+                if (need_mask) {          // block-uniform, rare: a segment straddles the image border
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = ((qvm[r] >> j) & 1) ? v[j] : 0.f;
+                }
+                float* d = xlb + qlo[r];
+                if (KIND == TE_CONV_S2) {         // even columns | odd columns (row stride and OD are even: 8-byte aligned)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[2]};
+                    *reinterpret_cast<f32x2*>(d + g.OD) = f32x2{v[1], v[3]};
+                } else {
+                    *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
                 }
             }
         }
@@ -706,7 +719,7 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     if (KIND == TE_CONV_T2 && ri0 == a.H && rh == 1) g.tapmask = 0x1C0;            // last output row: only ky == 2 reaches it
     if (KIND == TE_CONV_T2 && rj0 == a.W && rw == 1) g.tapmask = 0x124;            // last output column: only kx == 2
     nblocks += g.tiles_x * g.tiles_y * ((a.B + g.NSv - 1) / g.NSv);
-    lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS + (size_t)((fast && a.isc) ? a.Kp : 0));
+    lds_floats = std::max(lds_floats, (size_t)Kind<KIND>::NT * KC * BM + (size_t)KC * g.CS + (size_t)(fast ? 64 : 0) /* dump slot of threads without a staging pair */ + (size_t)((fast && a.isc) ? a.Kp : 0));
     ms = ms || g.NSv > 1;
     a.nreg++;
     return 0;
