@@ -37,6 +37,9 @@ namespace {
 #ifndef TE_CONV_FAST         // 0: never dispatch to the FAST kernels
 #define TE_CONV_FAST 1
 #endif
+#ifndef TE_CONV_XCD          // XCD-aware block -> (tile, M block) mapping (0: M block major, as the plain 2-D grid did)
+#define TE_CONV_XCD 1
+#endif
 #ifndef TE_FAST_PF           // LDS operands of step s+1 are read before the MFMAs of step s
 #define TE_FAST_PF 1
 #endif
@@ -89,6 +92,7 @@ struct ConvArgs {
         int tapmask;             // taps that can contribute in this region (thin T2 edge regions need 3 of 9)
     } reg[3];
     int nreg;
+    int ntiles, mblocks;     // grid: ceil(ntiles / 8) * 8 * mblocks blocks along x (see the kernel's block -> work mapping)
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
@@ -129,13 +133,24 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     const int wm = wid / WN, wn = wid % WN;
 
     // ---- region + tile coordinates
-    const int ridx = (p.nreg > 1 && (int)blockIdx.x >= p.reg[1].first_block) + (p.nreg > 2 && (int)blockIdx.x >= p.reg[2].first_block);
+    // ---- block -> (cell tile, M block).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so
+    // the j-th block of XCD x takes tile (j / mblocks) * 8 + x and M block j % mblocks: the M blocks of a tile run on ONE XCD at
+    // the same time and share its input tile through that L2, tiles are walked in order (the short edge tiles of T2 come last
+    // for every M block, which is what a greedy dispatcher wants at the tail), and a tile id past the end exits.
+#if TE_CONV_XCD
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tile_id = (jx / p.mblocks) * 8 + xcd, mblk = jx % p.mblocks;
+    if (tile_id >= p.ntiles) return;
+#else
+    const int tile_id = blockIdx.x % p.ntiles, mblk = blockIdx.x / p.ntiles;
+#endif
+    const int ridx = (p.nreg > 1 && tile_id >= p.reg[1].first_block) + (p.nreg > 2 && tile_id >= p.reg[2].first_block);
     const ConvArgs::Region g = p.reg[ridx];
-    int t = blockIdx.x - g.first_block;
+    int t = tile_id - g.first_block;
     const int tx_i = t % g.tiles_x; t /= g.tiles_x;
     const int ty_i = t % g.tiles_y; t /= g.tiles_y;
     const int b0 = t * g.NSv;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = mblk * BM;
     const int ci0 = g.ri0 + ty_i * g.TH, cj0 = g.rj0 + tx_i * g.TW;   // first cell of the tile
     // origin of the input tile in input coordinates
     int oy, ox;
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 #endif
         }
 #ifdef TE_CONV_PROF
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int lin = blockIdx.x + gridDim.x * blockIdx.z;
         if ((tid & 63) == 0 && lin < 8192 / 4) {
             unsigned long long* d = te_conv_prof_buf + ((size_t)lin * 4 + wid) * 8;
             d[0] = pc[0]; d[1] = pc[1]; d[2] = pc[2]; d[3] = pc[3]; d[4] = pstart; d[5] = __builtin_readcyclecounter();
@@ -732,8 +747,14 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
     constexpr int BM = tile_bm<KIND, TC>();
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST>, 128 * 1024);
-    dim3 grid((unsigned)nblocks, (unsigned)te::cdiv(a.M, BM), (unsigned)a.ksplit);
-    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(a);
+    ConvArgs b = a;
+    b.ntiles = nblocks; b.mblocks = (int)te::cdiv(a.M, BM);
+#if TE_CONV_XCD
+    dim3 grid((unsigned)(te::cdiv(nblocks, 8) * 8 * b.mblocks), 1u, (unsigned)a.ksplit);
+#else
+    dim3 grid((unsigned)(nblocks * b.mblocks), 1u, (unsigned)a.ksplit);
+#endif
+    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(b);
 }
 
 template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && TC == 0 && KIND != TE_CONV_1X1; }
