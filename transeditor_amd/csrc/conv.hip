@@ -40,6 +40,9 @@ namespace {
 #ifndef TE_CONV_XCD          // XCD-aware block -> (tile, M block) mapping (0: M block major, as the plain 2-D grid did)
 #define TE_CONV_XCD 1
 #endif
+#ifndef TE_CONV_FAST_NARROW  // FAST kernels for the 64- and 32-row tile classes too (narrow layers of the 512 / 1024 px models)
+#define TE_CONV_FAST_NARROW 1
+#endif
 #ifndef TE_FAST_PF           // LDS operands of step s+1 are read before the MFMAs of step s
 #define TE_FAST_PF 1
 #endif
@@ -55,13 +58,13 @@ __device__ unsigned long long te_conv_prof_buf[8192 * 8];
 #endif
 template <int KIND, int TC> struct Cfg;
 template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = (KIND == TE_CONV_S2) ? 5 : 2; };
-template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = 1; };
-template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = 1; };
+template <int KIND> struct Cfg<KIND, 1> { static constexpr int WM = 2, MBW = 1, NBW = (KIND == TE_CONV_S2) ? 2 : 4, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = (KIND == TE_CONV_S2) ? 5 : 4; };
+template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 5 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = (KIND == TE_CONV_S2) ? 10 : 4; };
 // transposed conv: 4 phase accumulators per cell block -> 64 x 128 cells per block and 16 channels per stage keep the
 // MFMA work per staged weight byte equal to the plain 3x3 kernel; 32 x 128 cells for narrow outputs
 template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1, NQ = 3; };
-template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 1; };
-template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 1; };
+template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 2; };
+template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 3; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 
@@ -757,7 +760,7 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
     conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(b);
 }
 
-template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && TC == 0 && KIND != TE_CONV_1X1; }
+template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && (TC == 0 || TE_CONV_FAST_NARROW) && KIND != TE_CONV_1X1; }
 
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {

@@ -332,23 +332,33 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int nst = (nks - kw + kstride - 1) / kstride;
     const int ks1 = kw + (nst / 4) * kstride, ks2 = kw + (nst / 2) * kstride;      // (offsetting the split points between the two
                                                                                       // waves of a SIMD measured slower: 124 vs 130 TFLOP/s)
+    // 1x1 (one MFMA per k-step): the tile's MFMAs are too few to hide anything behind, and one 50 KB image lets several blocks
+    // share a CU instead, so it keeps a single image and two barriers per tile
+    constexpr bool DB = (KIND != TE_CONV_1X1);
     for (int tl = t_begin; tl < t_end; ++tl) {
         WPROF(5)
-        float* cur = smem + ((tl - t_begin) & 1) * bufsz;
-        float* nxt = smem + (((tl - t_begin) & 1) ^ 1) * bufsz;
+        float* cur = smem + (DB ? ((tl - t_begin) & 1) * bufsz : 0);
+        float* nxt = smem + (DB ? (((tl - t_begin) & 1) ^ 1) * bufsz : 0);
         const float* g_l = cur + g_off;
         const float* x_l = cur + x_off;
         first_operands(g_l, x_l);
-        steps(g_l, x_l, kw, ks1);
-        WPROF(4)
-        if (tl + 1 < t_end) commit(nxt, nxt + PCH * p.PS);      // tile tl+1: loaded while tile tl-1 was multiplied
-        WPROF(1)
-        steps(g_l, x_l, ks1, ks2);
-        WPROF(4)
-        if (tl + 2 < t_end) issue(tl + 2);
-        WPROF(3)
-        steps(g_l, x_l, ks2, nks);
-        WPROF(4)
+        if (DB) {
+            steps(g_l, x_l, kw, ks1);
+            WPROF(4)
+            if (tl + 1 < t_end) commit(nxt, nxt + PCH * p.PS);      // tile tl+1: loaded while tile tl-1 was multiplied
+            WPROF(1)
+            steps(g_l, x_l, ks1, ks2);
+            WPROF(4)
+            if (tl + 2 < t_end) issue(tl + 2);
+            WPROF(3)
+            steps(g_l, x_l, ks2, nks);
+            WPROF(4)
+        } else {
+            steps(g_l, x_l, kw, nks);
+            __syncthreads();                // everyone is done reading the image
+            if (tl + 1 < t_end) commit(nxt, nxt + PCH * p.PS);
+            if (tl + 2 < t_end) issue(tl + 2);
+        }
         __syncthreads();                    // everyone is done reading `cur` and writing `nxt`
         WPROF(0)
     }
@@ -443,7 +453,7 @@ inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
-    size_t lds = 2 * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);      // two operand images (double buffering)
+    size_t lds = (KIND == TE_CONV_1X1 ? 1 : 2) * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);      // two operand images (double buffering)
     if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
