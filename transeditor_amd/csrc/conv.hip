@@ -65,6 +65,9 @@ template <int KIND> struct Cfg<KIND, 2> { static constexpr int WM = 1, MBW = 1, 
 template <> struct Cfg<TE_CONV_T2, 0> { static constexpr int WM = 2, MBW = 1, NBW = 2, KC = T2KC0, NSP = 1, NQ = 3; };
 template <> struct Cfg<TE_CONV_T2, 1> { static constexpr int WM = 2, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 2; };
 template <> struct Cfg<TE_CONV_T2, 2> { static constexpr int WM = 1, MBW = 1, NBW = 1, KC = 16, NSP = 1, NQ = 3; };
+// 1x1 with deep stages (FAST only: 64 channels per stage = 128 MFMAs per wave and stage instead of 16; the skip convolutions
+// of the discriminator's ResBlocks and their data gradients)
+template <> struct Cfg<TE_CONV_1X1, 3> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 64, NSP = 1, NQ = 8; };
 template <int KIND, int TC> constexpr int tile_bm() { return Cfg<KIND, TC>::WM * Cfg<KIND, TC>::MBW * 32; }
 template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, TC>::WM) * Cfg<KIND, TC>::NBW * 32; }
 
@@ -760,7 +763,7 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
     conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(b);
 }
 
-template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && (TC == 0 || TE_CONV_FAST_NARROW) && KIND != TE_CONV_1X1; }
+template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && (TC == 3 || ((TC == 0 || TE_CONV_FAST_NARROW) && KIND != TE_CONV_1X1)); }
 
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
@@ -801,6 +804,7 @@ int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s)
         if (!fast) break;
     }
     if (nblocks == 0) return 0;
+    if (TC == 3 && !fast) return launch_regions_tc<KIND, 0>(a, regions, n, s);      // the deep-stage class exists as a FAST kernel only
     if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s, fast);
     else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s, fast);
     else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s, fast);
@@ -811,6 +815,9 @@ inline int tile_class(int M) { return M >= 96 ? 0 : (M >= 48 ? 1 : 2); }
 
 template <int KIND>
 int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_t s, int tc) {
+    if constexpr (KIND == TE_CONV_1X1) {
+        if (tc == 3) return launch_regions_tc<KIND, 3>(a, regions, n, s);
+    }
     switch (tc) {
         case 0: return launch_regions_tc<KIND, 0>(a, regions, n, s);
         case 1: return launch_regions_tc<KIND, 1>(a, regions, n, s);
@@ -882,6 +889,8 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     pl.ksplit = std::max(1, ks);
     pl.kchunk = (int)te::cdiv(stages, pl.ksplit) * KC;
     pl.ksplit = (int)te::cdiv(Kp, pl.kchunk);
+    // 1x1 on images that fill the chip, channel count a multiple of 64: the deep-stage FAST class
+    if (TE_CONV_FAST && kind == TE_CONV_1X1 && tc == 0 && pl.ksplit == 1 && NS == 1 && K % 64 == 0) pl.tc = 3;
     return pl;
 }
 
