@@ -43,6 +43,9 @@ namespace {
 #ifndef TE_CONV_FAST_NARROW  // FAST kernels for the 64- and 32-row tile classes too (narrow layers of the 512 / 1024 px models)
 #define TE_CONV_FAST_NARROW 1
 #endif
+#ifndef TE_CONV_DEEP1X1      // 0: never pick the deep-stage 1x1 class
+#define TE_CONV_DEEP1X1 1
+#endif
 #ifndef TE_FAST_PF           // LDS operands of step s+1 are read before the MFMAs of step s
 #define TE_FAST_PF 1
 #endif
@@ -890,7 +893,7 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     pl.kchunk = (int)te::cdiv(stages, pl.ksplit) * KC;
     pl.ksplit = (int)te::cdiv(Kp, pl.kchunk);
     // 1x1 on images that fill the chip, channel count a multiple of 64: the deep-stage FAST class
-    if (TE_CONV_FAST && kind == TE_CONV_1X1 && tc == 0 && pl.ksplit == 1 && NS == 1 && K % 64 == 0) pl.tc = 3;
+    if (TE_CONV_FAST && TE_CONV_DEEP1X1 && kind == TE_CONV_1X1 && tc == 0 && pl.ksplit == 1 && NS == 1 && K % 64 == 0) pl.tc = 3;
     return pl;
 }
 

@@ -332,9 +332,10 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int nst = (nks - kw + kstride - 1) / kstride;
     const int ks1 = kw + (nst / 4) * kstride, ks2 = kw + (nst / 2) * kstride;      // (offsetting the split points between the two
                                                                                       // waves of a SIMD measured slower: 124 vs 130 TFLOP/s)
-    // 1x1 (one MFMA per k-step): the tile's MFMAs are too few to hide anything behind, and one 50 KB image lets several blocks
-    // share a CU instead, so it keeps a single image and two barriers per tile
-    constexpr bool DB = (KIND != TE_CONV_1X1);
+    // 1x1 (one MFMA per k-step: too few to hide anything behind) and the 4-wave tile of the narrow layers (two images would
+    // leave room for ONE block = one wave per SIMD on a CU; measured 1.17 vs 0.89 ms at 64 -> 64 @512^2) keep a single image and
+    // two barriers per tile, so that several blocks share a CU instead
+    constexpr bool DB = (KIND != TE_CONV_1X1) && (NWP == 4);
     for (int tl = t_begin; tl < t_end; ++tl) {
         WPROF(5)
         float* cur = smem + (DB ? ((tl - t_begin) & 1) * bufsz : 0);
@@ -453,7 +454,7 @@ inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 template <int KIND, int NWP>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
-    size_t lds = (KIND == TE_CONV_1X1 ? 1 : 2) * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);      // two operand images (double buffering)
+    size_t lds = ((KIND == TE_CONV_1X1 || NWP == 2) ? 1 : 2) * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);   // 8-wave 3x3 / T2: two operand images
     if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
