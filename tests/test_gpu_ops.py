@@ -137,7 +137,10 @@ def _in_hw(kind, H, W):
 CONV_SHAPES = [  # B, K(ci), M(co), H, W
     (3, 6, 5, 7, 7), (2, 40, 36, 12, 12), (2, 136, 130, 33, 20), (16, 128, 128, 4, 4), (4, 64, 256, 8, 8),
     (2, 32, 64, 16, 16), (1, 24, 16, 64, 64), (2, 8, 8, 5, 3), (1, 16, 32, 40, 72),
-    (2, 40, 128, 17, 31), (1, 16, 96, 64, 32), (3, 24, 200, 18, 65)]     # wide 'up' layers on > 16 x 16 cells: conv_t2p.hip
+    (2, 40, 128, 17, 31), (1, 16, 96, 64, 32), (3, 24, 200, 18, 65),
+    # FAST kernels (K % 16 == 0, one sample per tile) on widths whose last tile straddles the image border inside a 16-byte
+    # segment (block-uniform mask path), narrow / wide M, and enough tiles for the deep-stage 1x1 class (K % 64 == 0)
+    (1, 16, 128, 24, 42), (2, 32, 48, 20, 38), (16, 64, 256, 32, 42)]
 
 
 @pytest.mark.parametrize('kind', ['3x3', '1x1', 'up', 'down'])
