@@ -1,0 +1,32 @@
+"""Differential fuzz of the MFMA convolution family (forward incl. fused scales / bias / activation, and the weight
+gradient) against the framework's GPU convolutions on random shapes: whole-stage and ragged channel counts, one- and
+multi-sample tiles, split-K, odd image sizes, every tile class.  tools/conv_fuzz.py is the long form (2 000 cases: 0 above
+2e-5, worst 1.8e-6)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+
+
+@pytest.mark.parametrize('seed', [11, 12])
+def test_conv_family_vs_framework_convolutions(seed):
+    import conv_fuzz
+    torch.backends.cudnn.allow_tf32 = False
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    worst = (0.0, '')
+    for i in range(120):
+        kind = ('3X3', '1X1', 'T2', 'S2')[i % 4]
+        try:
+            err, e, ew, desc = conv_fuzz.one(g, kind)
+        except RuntimeError as ex:            # shapes the library refuses loudly (1-pixel-wide images in the weight gradient)
+            assert 'unsupported image size' in str(ex), ex
+            continue
+        if err > worst[0]:
+            worst = (err, desc)
+    assert worst[0] < 2e-5, worst
