@@ -875,7 +875,10 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     int tc = tile_class(M);
     // transposed conv on small images (<= 1024 of the 64 x 128 tiles): the 64 x 64 tile class fits 3 waves per SIMD and
     // gives the chip more, shorter blocks (512->512 @32: 87 -> 100 TFLOP/s, @16: 57 -> 83)
-    if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= 1024 * 128) tc = 1;
+#ifndef TE_T2_TC1_LIMIT
+#define TE_T2_TC1_LIMIT (1024 * 128)
+#endif
+    if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= (int64_t)TE_T2_TC1_LIMIT) tc = 1;
     pl.tc = tc;
     const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
