@@ -53,6 +53,15 @@ const char* te_arch(void);
 int te_bias_act_f32(float* out, const float* x, const float* b, const float* ref, int act, int grad,
                     float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
                     te_stream_t stream);
+/* The reference dispatches this op over half / float / double (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * fused_bias_act_kernel.cu:79) and converts its float `alpha` / `scale` to scalar_t; same here.  Half buffers are IEEE
+ * binary16 (`__half` / torch.float16) passed as void*; arithmetic in fp32 with one rounding at the store. */
+int te_bias_act_f16(void* out, const void* x, const void* b, const void* ref, int act, int grad,
+                    float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
+                    te_stream_t stream);
+int te_bias_act_f64(double* out, const double* x, const double* b, const double* ref, int act, int grad,
+                    float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,
+                    te_stream_t stream);
 
 /* Backward of the fused lrelu in ONE pass — replaces FusedLeakyReLUFunctionBackward.forward,
  * utils/op/fused_act.py:18-38 (kernel call + grad_input.sum(dim)):
@@ -76,6 +85,14 @@ int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, 
                      int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                      int pad_x1, int pad_y0, int pad_y1, const float* b, int64_t size_b, int act,
                      float alpha, float scale, te_stream_t stream);
+/* half / double forms of the same op (upfirdn2d_kernel.cu:57-58 dispatches over both): every (up, down, taps), no fused
+ * epilogue (the reference op has none); taps in the tensors' own type; accumulation in fp32 / double. */
+int te_upfirdn2d_f16(void* out, const void* x, const void* k, int64_t major, int in_h, int in_w,
+                     int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                     int pad_x1, int pad_y0, int pad_y1, te_stream_t stream);
+int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t major, int in_h, int in_w,
+                     int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                     int pad_x1, int pad_y0, int pad_y1, te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F1  modulated convolution family (reference: ModulatedConv2d.forward, model_spatial_query.py:

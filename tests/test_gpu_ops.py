@@ -600,3 +600,57 @@ def test_attention_stack_fused_vs_single_ops(N, nb):
     assert rel_err(torch.autograd.grad(gx.square().sum(), w)[0], torch.autograd.grad(gxr.square().sum(), w)[0]) < 1e-4
     with torch.no_grad():                                   # inference: no save buffers
         assert rel_err(A.attention_stack(x0, p0, p, prm, 0.01, scale), y_ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ K1 / K2 in half and double
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-13), (torch.float16, 3e-3)])
+def test_fused_leaky_relu_other_dtypes(dtype, tol):
+    """The reference dispatches fused_bias_act over half / float / double (fused_bias_act_kernel.cu:79) with its float alpha /
+    scale converted to scalar_t: forward, gradient and gradient of the gradient through te_bias_act_f16 / _f64."""
+    import numpy as np
+    from transeditor_amd.op import fused_leaky_relu
+    alpha, scale = float(np.float32(0.2)), float(np.float32(2 ** 0.5))          # what a C float argument holds
+    x = synth.normal((3, 5, 6, 7), 'k1o.x').double()
+    b = (synth.normal((5,), 'k1o.b') * 0.3).double()
+    if dtype == torch.float16:
+        x, b = x.half().double(), b.half().double()                              # representable inputs
+    x.requires_grad_(True); b.requires_grad_(True)
+    y_ref = O.fused_leaky_relu(x, b, alpha, scale)
+    gy = synth.normal(tuple(y_ref.shape), 'k1o.g').double()
+    gx_ref, gb_ref = torch.autograd.grad((y_ref * gy).sum(), (x, b), create_graph=True)
+    u = synth.normal(tuple(x.shape), 'k1o.u').double()
+    xd = x.detach().to(DEV, dtype).requires_grad_(True)
+    bd = b.detach().to(DEV, dtype).requires_grad_(True)
+    gyd = gy.to(DEV, dtype).requires_grad_(True)
+    y = fused_leaky_relu(xd, bd, 0.2, 2 ** 0.5)
+    assert y.dtype == dtype
+    assert rel_err(y.double(), y_ref) < tol
+    gx, gb = torch.autograd.grad((y * gyd).sum(), (xd, bd), create_graph=True)
+    assert rel_err(gx.double(), gx_ref) < tol and rel_err(gb.double(), gb_ref) < 10 * tol
+    ggy, = torch.autograd.grad((gx * u.to(DEV, dtype)).sum(), gyd)               # grad-grad path (mode 31 on the saved output)
+    gy_leaf = gy.clone().requires_grad_(True)
+    gx2, = torch.autograd.grad((O.fused_leaky_relu(x, b, alpha, scale) * gy_leaf).sum(), x, create_graph=True)
+    ggy_ref, = torch.autograd.grad((gx2 * u).sum(), gy_leaf)
+    assert rel_err(ggy.double(), ggy_ref) < tol
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-13), (torch.float16, 3e-3)])
+@pytest.mark.parametrize('up,down,pad,taps', [(1, 1, (2, 1), (1, 3, 3, 1)), (2, 1, (2, 1), (1, 3, 3, 1)), (1, 2, (1, 1), (1, 3, 3, 1)),
+                                               (3, 2, (3, 2), (1, 2, 3, 2, 1))])
+def test_upfirdn2d_other_dtypes(dtype, tol, up, down, pad, taps):
+    """te_upfirdn2d_f16 / _f64 (upfirdn2d_kernel.cu:57-58 dispatches over both), forward and adjoint."""
+    from transeditor_amd.op import upfirdn2d
+    k = O.fir_kernel(taps, float(up * up)).double()
+    x = synth.normal((2, 3, 9, 11), 'k2o.x').double()
+    if dtype == torch.float16:
+        x, k = x.half().double(), k.half().double()
+    x.requires_grad_(True)
+    y_ref = O.upfirdn2d(x, k, up, down, pad)
+    gy = synth.normal(tuple(y_ref.shape), 'k2o.g').double()
+    gx_ref, = torch.autograd.grad((y_ref * gy).sum(), x)
+    xd = x.detach().to(DEV, dtype).requires_grad_(True)
+    y = upfirdn2d(xd, k.to(DEV, dtype), up, down, pad)
+    assert y.dtype == dtype and tuple(y.shape) == tuple(y_ref.shape)
+    assert rel_err(y.double(), y_ref) < tol
+    gx, = torch.autograd.grad((y * gy.to(DEV, dtype)).sum(), xd)
+    assert rel_err(gx.double(), gx_ref) < tol

@@ -22,9 +22,13 @@ _SIGNATURES = {
     'te_last_error_string': (C.c_char_p, []),
     'te_arch': (C.c_char_p, []),
     'te_bias_act_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_f16': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_f64': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_bwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _L, _L, _L, _P]),
     'te_upfirdn2d_f32': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                    _P, _L, _I, _F, _F, _P]),
+    'te_upfirdn2d_f16': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_upfirdn2d_f64': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_packed_numel': (C.c_int64, [_I, _I, _I, _I]),
     'te_conv_pack_weights_f32': (C.c_int, [_P, _P, _F, _I, _I, _I, _I, _P]),
     'te_conv_pack_weights2_f32': (C.c_int, [_P, _I, _P, _I, _P, _F, _I, _I, _I, _P]),
@@ -128,9 +132,31 @@ def _stream():
 
 
 # --------------------------------------------------------------------------------------------- K1
+_OTHER = {torch.float16: 'f16', torch.float64: 'f64'}       # K1 / K2 also exist in the reference's other two dispatch types
+
+
+def _ptr_as(t, dtype):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise RuntimeError(f'te_hip: expected a contiguous {dtype} tensor on the GPU, got {t.dtype} {t.device} '
+                           f'contiguous={t.is_contiguous()} (no CPU path exists)')
+    _on_current_device(t)
+    return t.data_ptr()
+
+
 def bias_act(x, b, ref, act, grad, alpha, scale):
     """out = act(x + b[channel]) * scale; channel = dim 1 (step_b = prod(shape[2:]))."""
     x = x.contiguous()
+    if x.dtype in _OTHER:
+        out = torch.empty_like(x)
+        step_b = 1
+        for d in x.shape[2:]:
+            step_b *= d
+        fn = getattr(lib(), 'te_bias_act_' + _OTHER[x.dtype])
+        _check(fn(_ptr_as(out, x.dtype), _ptr_as(x, x.dtype), _ptr_as(b, x.dtype), _ptr_as(ref, x.dtype), act, grad, alpha, scale,
+                  x.numel(), step_b, b.numel() if b is not None else 1, _stream()), 'te_bias_act_' + _OTHER[x.dtype])
+        return out
     out = torch.empty_like(x)
     step_b = 1
     for d in x.shape[2:]:
@@ -142,6 +168,9 @@ def bias_act(x, b, ref, act, grad, alpha, scale):
 
 def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
     g = g.contiguous()
+    if g.dtype in _OTHER:       # the reference's two steps (fused_act.py:18-38): the kernel in grad mode, then the bias sum
+        gi = bias_act(g, None, ref, 3, 1, alpha, scale)
+        return gi, (gi.sum(dim=[0] + list(range(2, gi.ndim))) if want_bias else None)
     gi = torch.empty_like(g)
     Cn = g.shape[1]
     inner = 1
@@ -165,6 +194,13 @@ def upfirdn2d_raw(x, k, up, down, pad, bias=None, act=0, alpha=0.2, scale=1.0):
     if oh <= 0 or ow <= 0:
         raise RuntimeError(f'upfirdn2d: empty output {oh}x{ow}')
     out = torch.empty(B, Cn, oh, ow, device=x.device, dtype=x.dtype)
+    if x.dtype in _OTHER:
+        if bias is not None or act:
+            raise RuntimeError('upfirdn2d: the fused bias / activation epilogue exists in fp32 only')
+        fn = getattr(lib(), 'te_upfirdn2d_' + _OTHER[x.dtype])
+        _check(fn(_ptr_as(out, x.dtype), _ptr_as(x, x.dtype), _ptr_as(k.to(x.dtype).contiguous(), x.dtype), B * Cn, H, W, 1, kh, kw,
+                  up[0], up[1], down[0], down[1], px0, px1, py0, py1, _stream()), 'te_upfirdn2d_' + _OTHER[x.dtype])
+        return out
     _check(lib().te_upfirdn2d_f32(_ptr(out), _ptr(x), _ptr(k.contiguous()), B * Cn, H, W, 1, kh, kw, up[0], up[1],
                                   down[0], down[1], px0, px1, py0, py1, _ptr(bias),
                                   bias.numel() if bias is not None else 1, act, alpha, scale, _stream()),

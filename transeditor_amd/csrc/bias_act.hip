@@ -5,6 +5,7 @@
 // Semantics follow the reference op (fused_bias_act_kernel.cu:26-47); the channel index of flat
 // element i is (i / step_b) % size_b with integer arithmetic.
 #include "te_common.h"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -139,7 +140,61 @@ __global__ __launch_bounds__(256) void bias_act_bwd_2d_kernel(float* __restrict_
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// The reference dispatches the op over half / float / double (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// fused_bias_act_kernel.cu:79) and converts its float alpha / scale arguments to scalar_t.  The model runs in fp32 (the
+// streaming kernels above); the other two types take this element-per-lane kernel: arithmetic in T's own precision for
+// double, in fp32 for half (one rounding at the store).
+template <typename T> struct AccOf { typedef T type; };
+template <> struct AccOf<__half> { typedef float type; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_any_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ b,
+                                                           const T* __restrict__ ref, int mode, float alpha_, float scale_,
+                                                           int64_t n, int64_t step_b, int64_t size_b) {
+    typedef typename AccOf<T>::type A;
+    const A alpha = (A)(T)alpha_, scale = (A)(T)scale_;          // float -> scalar_t, as the reference's kernel arguments
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        A v = (A)x[i];
+        if (b) v += (A)b[(i / step_b) % size_b];
+        const A r = ref ? (A)ref[i] : (A)0;
+        A y;
+        switch (mode) {
+            case 30: y = v > (A)0 ? v : v * alpha; break;
+            case 31: y = r > (A)0 ? v : v * alpha; break;
+            case 12:
+            case 32: y = (A)0; break;
+            default: y = v;
+        }
+        out[i] = (T)(y * scale);
+    }
+}
+
+template <typename T>
+int bias_act_any(T* out, const T* x, const T* b, const T* ref, int act, int grad, float alpha, float scale, int64_t size_x,
+                 int64_t step_b, int64_t size_b, te_stream_t stream_, const char* what) {
+    TE_REQUIRE(out && x, TE_ERR_NULL, "%s: out/x is NULL", what);
+    TE_REQUIRE(size_x >= 0, TE_ERR_SHAPE, "%s: size_x < 0", what);
+    TE_REQUIRE(!b || (step_b > 0 && size_b > 0), TE_ERR_SHAPE, "%s: bias given but step_b/size_b <= 0", what);
+    if (size_x == 0) return 0;
+    const int grid = (int)std::min<int64_t>(te::cdiv(size_x, 256), te::kNumCU * 8);
+    bias_act_any_kernel<T><<<grid, 256, 0, (hipStream_t)stream_>>>(out, x, b, ref, act * 10 + grad, alpha, scale, size_x,
+                                                                   b ? step_b : 1, b ? size_b : 1);
+    return te::launch_status(what);
+}
+
 }  // namespace
+
+extern "C" int te_bias_act_f16(void* out, const void* x, const void* b, const void* ref, int act, int grad, float alpha,
+                               float scale, int64_t size_x, int64_t step_b, int64_t size_b, te_stream_t stream) {
+    return bias_act_any<__half>((__half*)out, (const __half*)x, (const __half*)b, (const __half*)ref, act, grad, alpha, scale,
+                                size_x, step_b, size_b, stream, "te_bias_act_f16");
+}
+
+extern "C" int te_bias_act_f64(double* out, const double* x, const double* b, const double* ref, int act, int grad, float alpha,
+                               float scale, int64_t size_x, int64_t step_b, int64_t size_b, te_stream_t stream) {
+    return bias_act_any<double>(out, x, b, ref, act, grad, alpha, scale, size_x, step_b, size_b, stream, "te_bias_act_f64");
+}
 
 extern "C" int te_bias_act_f32(float* out, const float* x, const float* b, const float* ref, int act, int grad,
                                float alpha, float scale, int64_t size_x, int64_t step_b, int64_t size_b,

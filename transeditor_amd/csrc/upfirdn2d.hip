@@ -10,6 +10,7 @@
 //     fused bias + leaky-ReLU epilogue.  Instantiated for the configurations the model uses.
 //   * fir_direct_kernel: any (up, down, kernel, minor); one output per thread straight from global/L2.
 #include "te_common.h"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -469,6 +470,71 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
         fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
     }
     return te::launch_status("te_blur_actgrad_f32");
+}
+
+// half / double (the reference dispatches its kernel over AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:57-58,
+// 187-189): the direct form for every (up, down, taps); accumulation in fp32 for half, in double for double.
+namespace {
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void fir_direct_any_kernel(T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ k,
+                                                             const FirParams p) {
+    const int64_t total = p.major * p.out_h * p.out_w * p.minor;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int64_t r = e;
+        const int mn = (int)(r % p.minor); r /= p.minor;
+        const int ox = (int)(r % p.out_w); r /= p.out_w;
+        const int oy = (int)(r % p.out_h);
+        const int64_t mj = r / p.out_h;
+        const int mid_x = ox * p.down_x + p.up_x - 1 - p.pad_x0, mid_y = oy * p.down_y + p.up_y - 1 - p.pad_y0;
+        const int ix0 = fdiv(mid_x, p.up_x), iy0 = fdiv(mid_y, p.up_y);
+        const int jx0 = (ix0 + 1) * p.up_x - mid_x - 1, jy0 = (iy0 + 1) * p.up_y - mid_y - 1;
+        A acc = (A)0;
+        for (int jy = jy0, iy = iy0; jy < p.kh; jy += p.up_y, ++iy) {
+            if (iy < 0 || iy >= p.in_h) continue;
+            for (int jx = jx0, ix = ix0; jx < p.kw; jx += p.up_x, ++ix) {
+                if (ix < 0 || ix >= p.in_w) continue;
+                acc += (A)x[(((size_t)mj * p.in_h + iy) * p.in_w + ix) * p.minor + mn] *
+                       (A)k[(p.kh - 1 - jy) * p.kw + (p.kw - 1 - jx)];
+            }
+        }
+        out[e] = (T)acc;
+    }
+}
+
+template <typename T, typename A>
+int upfirdn2d_any(T* out, const T* x, const T* k, int64_t major, int in_h, int in_w, int minor, int kh, int kw, int up_x, int up_y,
+                  int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, te_stream_t stream_, const char* what) {
+    TE_REQUIRE(out && x && k, TE_ERR_NULL, "%s: out/x/k is NULL", what);
+    TE_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0 && kh > 0 && kw > 0, TE_ERR_SHAPE, "%s: bad dims", what);
+    TE_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, TE_ERR_SHAPE, "%s: up/down must be > 0", what);
+    FirParams p{};
+    p.in_h = in_h; p.in_w = in_w;
+    p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+    p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+    TE_REQUIRE(p.out_h > 0 && p.out_w > 0, TE_ERR_SHAPE, "%s: empty output (%d x %d)", what, p.out_h, p.out_w);
+    p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+    p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.minor = minor; p.major = major;
+    if (major == 0) return 0;
+    const int64_t total = major * p.out_h * p.out_w * minor;
+    const int grid = (int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 16);
+    fir_direct_any_kernel<T, A><<<grid, 256, 0, (hipStream_t)stream_>>>(out, x, k, p);
+    return te::launch_status(what);
+}
+}  // namespace
+
+extern "C" int te_upfirdn2d_f16(void* out, const void* x, const void* k, int64_t major, int in_h, int in_w, int minor, int kh,
+                                int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                te_stream_t stream) {
+    return upfirdn2d_any<__half, float>((__half*)out, (const __half*)x, (const __half*)k, major, in_h, in_w, minor, kh, kw, up_x,
+                                        up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream, "te_upfirdn2d_f16");
+}
+
+extern "C" int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t major, int in_h, int in_w, int minor,
+                                int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                int pad_y1, te_stream_t stream) {
+    return upfirdn2d_any<double, double>(out, x, k, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                         pad_y0, pad_y1, stream, "te_upfirdn2d_f64");
 }
 
 extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int64_t major, int in_h, int in_w, int minor,
