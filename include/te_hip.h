@@ -14,11 +14,12 @@
  * Each entry point names the reference interface it replaces (paths relative to the
  * BillyXYB/TransEditor repository root).
  *
- * Precision: every entry point is fp32 (suffix _f32).  The reference's two CUDA ops dispatch over half / float / double
+ * Precision: the model path is fp32 (suffix _f32).  The reference's two CUDA ops dispatch over half / float / double
  * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:196); the TransEditor scripts
- * only ever run them in fp32 (no autocast / .half() anywhere on the path), so this narrowing is deliberate: the Python
- * wrappers raise on any other dtype instead of silently casting (tests/test_gpu_generator.py::
- * test_non_contiguous_and_wrong_dtype_inputs).
+ * only ever run them in fp32 (no autocast / .half() anywhere on the path), so the tuned kernels are fp32, and K1 / K2 —
+ * the two ops that ARE the reference's native boundary — also exist as te_bias_act_f16 / _f64 and te_upfirdn2d_f16 / _f64
+ * (plain kernels, same semantics).  Every other entry point is fp32 only: the Python wrappers raise on any other dtype
+ * instead of silently casting (tests/test_gpu_generator.py::test_non_contiguous_and_wrong_dtype_inputs).
  */
 #ifndef TE_HIP_H
 #define TE_HIP_H

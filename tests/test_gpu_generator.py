@@ -241,8 +241,14 @@ def test_non_contiguous_and_wrong_dtype_inputs():
     assert rel_err(fused_leaky_relu(xt, b), O.fused_leaky_relu(xt.cpu(), b.cpu())) < 1e-6
     k = O.fir_kernel((1, 3, 3, 1)).to(DEV)
     assert rel_err(upfirdn2d(xt, k, pad=(2, 1)), O.upfirdn2d(xt.cpu().contiguous(), k.cpu(), pad=(2, 1))) < 1e-5
+    # K1 / K2 exist in half and double as well (the reference's dispatch types; tests/test_gpu_ops.py::*_other_dtypes);
+    # everything else is fp32 only and fails loudly instead of silently casting
+    assert fused_leaky_relu(x.half(), b.half()).dtype == torch.float16
+    from transeditor_amd.op.modconv import conv_core
     with pytest.raises(RuntimeError, match='fp32'):
-        fused_leaky_relu(x.half(), b.half())                 # fp32 only: fails loudly instead of silently casting
+        conv_core(x.half(), synth.normal((4, 6, 3, 3), 'nc.w').to(DEV).half(), '3x3')
+    with pytest.raises(RuntimeError, match='float16'):
+        fused_leaky_relu(x.half(), b)                        # mixed dtypes are refused
 
 
 def test_generator1024_config5_shapes():
