@@ -13,10 +13,17 @@
 // all fill the tile),  K = input channels, 8 per stage, times the taps.
 // 4 waves per block as 2(M) x 2(N); each wave owns MBW x NACC accumulator tiles of 32x32.
 //
+// Two forms of the same kernel (template flag FAST): the general one takes any K / tile shape (channel tails, several small
+// images per tile, scalar staging); FAST serves every launch with whole stages and one sample per tile, i.e. all layers that
+// carry FLOPs, and is built around one measurement (tools/conv_phase_prof.py): next to a saturated matrix pipe every
+// vector-ALU / address instruction of the staging code costs ~50 cycles.  So its loads carry fixed per-thread offsets and a
+// scalar stage offset, the input tile comes in 16-byte row segments, and the loads of stage k+1 are dealt out over the MFMA
+// steps of stage k.  The grid is 1-D with an XCD-aware block -> (tile, M block) mapping.
+//
 // Kinds (include/te_hip.h):
 //   3X3  3x3 stride 1 pad 1                       (forward of plain layers; with flipped/transposed packing,
 //                                                  their data gradient)
-//   1X1  ToRGB
+//   1X1  the skip convolutions of the discriminator's ResBlocks, from-RGB, ToRGB shapes the streaming rgb.hip kernels do not cover
 //   S2   3x3 stride 2 over a (2H+1)x(2W+1) input  (data gradient of T2)
 //   T2   3x3 transposed stride 2 -> (2H+1)x(2W+1) (forward of the upsampling layers).  Written as its four
 //        output phases (row parity a, col parity b): phase (a,b) of cell (i,j) is output (2i+a, 2j+b) and
@@ -33,7 +40,7 @@ namespace {
 #ifndef T2KC0
 #define T2KC0 16
 #endif
-// FAST kernels (K a multiple of the stage depth, big tile class): knobs for A/B measurements
+// build knobs for A/B measurements (tools/exp_build.py); the defaults are the product
 #ifndef TE_CONV_FAST         // 0: never dispatch to the FAST kernels
 #define TE_CONV_FAST 1
 #endif
