@@ -42,7 +42,7 @@ def run(label):
             ks = 1 if kind == '1X1' else 3
             w = torch.randn(M, K, ks, ks, device=DEV) / (ks * K ** 0.5)
             wp = _lib.conv_pack(w, _lib.PACK_FWD, 1.0)
-            isc = 1 + 0.1 * torch.randn(B, K, device=DEV)
+            isc = None if os.environ.get('NO_ISC') else 1 + 0.1 * torch.randn(B, K, device=DEV)
             code = {'T2': _lib.CONV_T2, 'S2': _lib.CONV_S2, '3X3': _lib.CONV_3X3, '1X1': _lib.CONV_1X1}[kind]
             fn = lambda: _lib.conv(x, wp, code, M, H, H, isc, None, None, 0)
         else:
