@@ -320,6 +320,16 @@ int te_mt_adam_f32(const int64_t* table, const int32_t* chunks, int n_tensors, i
 int te_mt_ema_f32(const int64_t* table, const int32_t* chunks, int n_tensors, int n_chunks, int chunk_elems, double decay,
                   te_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-(sample, channel) scaling of an activation tensor and its adjoint: the elementwise pieces of the any-order composite
+ * of the modulated convolution (style scale on the input, demodulation on the output: model_spatial_query.py:299-304 moved
+ * from B weight copies onto the activations), used when a backward pass is recorded (path-length regulariser).
+ *   te_chan_scale_f32: out[r, j] = x[r, j] * s[r]           rows r = (sample, channel), hw pixels each
+ *   te_chan_dot_f32  : out[r]    = sum_j a[r, j] * b[r, j]   (fixed summation order)
+ */
+int te_chan_scale_f32(float* out, const float* x, const float* s, int64_t rows, int64_t hw, te_stream_t stream);
+int te_chan_dot_f32(float* out, const float* a, const float* b, int64_t rows, int64_t hw, te_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

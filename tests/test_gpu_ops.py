@@ -654,3 +654,27 @@ def test_upfirdn2d_other_dtypes(dtype, tol, up, down, pad, taps):
     assert rel_err(y.double(), y_ref) < tol
     gx, = torch.autograd.grad((y * gy.to(DEV, dtype)).sum(), xd)
     assert rel_err(gx.double(), gx_ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------ channel scale / dot pair
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 16, 8, 8), (2, 4, 64, 64), (1, 3, 1, 1), (2, 130, 33, 20)])
+def test_chan_scale_pair_any_order(shape):
+    """x * s[:, :, None, None] on te_chan_scale / te_chan_dot: values, first gradients and the gradient of a gradient
+    (what the path-length regulariser differentiates) against the framework's broadcast expression."""
+    from transeditor_amd.op.chanscale import chan_scale
+    x = synth.normal(shape, 'cs.x').double().requires_grad_(True)
+    s = (1 + 0.3 * synth.normal(shape[:2], 'cs.s')).double().requires_grad_(True)
+    gy = synth.normal(shape, 'cs.g').double().requires_grad_(True)
+    u, v = synth.normal(shape, 'cs.u').double(), synth.normal(shape[:2], 'cs.v').double()
+
+    def run(x, s, gy, f, dev, dt):
+        y = f(x, s)
+        gx, gs = torch.autograd.grad((y * gy).sum(), (x, s), create_graph=True)
+        pen = (gx * u.to(dev, dt)).sum() + (gs * v.to(dev, dt)).sum() + gs.pow(2).sum()
+        return (y, gx, gs) + torch.autograd.grad(pen, (x, s, gy))
+
+    ref = run(x, s, gy, lambda a, b: a * b[:, :, None, None], 'cpu', torch.float64)
+    xd, sd, gd = (t.detach().to(DEV, torch.float32).requires_grad_(True) for t in (x, s, gy))
+    got = run(xd, sd, gd, chan_scale, DEV, torch.float32)
+    for name, a, b in zip(('y', 'gx', 'gs', 'ppx', 'pps', 'ppg'), got, ref):
+        assert rel_err(a.double(), b) < 2e-5, name

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transeditor_amd.train_step import TrainStep, default_args      # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'path'
+if 'torchscale' in sys.argv:          # A/B: the framework's broadcast multiply in the any-order composite
+    from transeditor_amd.op import chanscale
+    chanscale.USE_KERNELS = False
 dev = 'cuda'
 ts = TrainStep(default_args(size=256, batch=16), dev)
 real = torch.randn(16, 3, 256, 256, device=dev).clamp(-1, 1)

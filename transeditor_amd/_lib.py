@@ -67,6 +67,8 @@ _SIGNATURES = {
     'te_minibatch_stddev_bwd_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     'te_mt_adam_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, _P]),
     'te_mt_ema_f32': (C.c_int, [_P, _P, _I, _I, _I, C.c_double, _P]),
+    'te_chan_scale_f32': (C.c_int, [_P, _P, _P, _L, _L, _P]),
+    'te_chan_dot_f32': (C.c_int, [_P, _P, _P, _L, _L, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -535,3 +537,22 @@ def small_gemm_batched_rs(c, a, b, nz, za, zc, zb, I, J, K, sai, sak, sbk, sbj, 
     _check(lib().te_small_gemm_batched_rs_f32(_raw(c), _raw(a), _raw(b), _raw(arowsum), zrs, rs_scale, nz, za, zc, zb, I, J, K, sai, sak,
                                               sbk, sbj, sci, scj, alpha, _stream()), 'te_small_gemm_batched_rs_f32')
     return c
+
+
+# --------------------------------------------------------------------------------------------- channel scale / dot
+def chan_scale(x, s):
+    """x [B,C,...] * s[B,C] broadcast over the trailing dims"""
+    x, s = x.contiguous(), s.contiguous()
+    rows = x.shape[0] * x.shape[1]
+    out = torch.empty_like(x)
+    _check(lib().te_chan_scale_f32(_ptr(out), _ptr(x), _ptr(s), rows, x.numel() // max(rows, 1), _stream()), 'te_chan_scale_f32')
+    return out
+
+
+def chan_dot(a, b):
+    """sum over the trailing dims of a * b -> [B,C]"""
+    a, b = a.contiguous(), b.contiguous()
+    rows = a.shape[0] * a.shape[1]
+    out = torch.empty(a.shape[0], a.shape[1], device=a.device, dtype=a.dtype)
+    _check(lib().te_chan_dot_f32(_ptr(out), _ptr(a), _ptr(b), rows, a.numel() // max(rows, 1), _stream()), 'te_chan_dot_f32')
+    return out

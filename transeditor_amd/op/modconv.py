@@ -30,6 +30,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .chanscale import chan_scale
 from .fused_act import fused_leaky_relu
 
 # Hints for the regulariser steps (R1, path length), which differentiate twice.  Both are optional: without them the
@@ -237,10 +238,10 @@ def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
     if wscale != 1.0:
         w = w * wscale
     if isc is not None:
-        x = x * isc[:, :, None, None]
+        x = chan_scale(x, isc)
     y = conv_core(x, w, kind)
     if osc is not None:
-        y = y * osc[:, :, None, None]
+        y = chan_scale(y, osc)
     if act:
         return fused_leaky_relu(y, bias, 0.2, _act_gain(act))
     if bias is not None:
