@@ -657,7 +657,8 @@ def test_upfirdn2d_other_dtypes(dtype, tol, up, down, pad, taps):
 
 
 # ------------------------------------------------------------------------------------------------ channel scale / dot pair
-@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 16, 8, 8), (2, 4, 64, 64), (1, 3, 1, 1), (2, 130, 33, 20)])
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 16, 8, 8), (2, 4, 64, 64), (1, 3, 1, 1), (2, 130, 33, 20), (1, 5, 33, 33),
+                                   (2, 6, 65, 65), (1, 2, 129, 257)])
 def test_chan_scale_pair_any_order(shape):
     """x * s[:, :, None, None] on te_chan_scale / te_chan_dot: values, first gradients and the gradient of a gradient
     (what the path-length regulariser differentiates) against the framework's broadcast expression."""

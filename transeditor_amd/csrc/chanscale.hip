@@ -22,10 +22,28 @@ __global__ __launch_bounds__(256) void chan_scale_vec4_kernel(float4* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void chan_scale_kernel(float* __restrict__ out, const float* __restrict__ x,
-                                                         const float* __restrict__ s, int64_t n, int64_t hw) {
+// rows of any length (the transposed convolution's (2H+1)^2 planes): 16 bytes per lane on the FLAT index; the four elements of a
+// vector share a row unless the vector straddles a row boundary (then the second row's scale applies from the boundary on)
+__global__ __launch_bounds__(256) void chan_scale_flat4_kernel(float4* __restrict__ out, const float4* __restrict__ x,
+                                                               const float* __restrict__ s, int64_t n4, int64_t hw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = x[i] * s[i / hw];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int64_t e = 4 * i, r = e / hw;
+        const int left = (int)(hw - (e - r * hw));           // elements of row r from e on (>= 1)
+        const float s0 = s[r], s1 = left < 4 ? s[r + 1] : s0; // hw >= 4 here: a vector touches at most two rows
+        float4 v = x[i];
+        v.x *= s0;
+        v.y *= left > 1 ? s0 : s1;
+        v.z *= left > 2 ? s0 : s1;
+        v.w *= left > 3 ? s0 : s1;
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void chan_scale_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                         const float* __restrict__ s, int64_t n, int64_t hw, int64_t first) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = x[i] * s[i / hw];
 }
 
 // one block per row; rows with few pixels (hw <= 64): one wave per row, 4 rows per block
@@ -49,12 +67,28 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(float* __restrict__ out, 
     if (vec) {
         const float4* a4 = reinterpret_cast<const float4*>(ar);
         const float4* b4 = reinterpret_cast<const float4*>(br);
-        for (int64_t j = tid; j < hw / 4; j += 256) {
-            const float4 u = a4[j], v = b4[j];
-            acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+        const int64_t n4 = hw / 4;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;      // four independent chains: eight 16-byte loads in flight per lane
+        int64_t j = tid;
+        for (; j + 768 < n4; j += 1024) {
+            const float4 u0 = a4[j], u1 = a4[j + 256], u2 = a4[j + 512], u3 = a4[j + 768];
+            const float4 v0 = b4[j], v1 = b4[j + 256], v2 = b4[j + 512], v3 = b4[j + 768];
+            c0 += u0.x * v0.x + u0.y * v0.y + u0.z * v0.z + u0.w * v0.w;
+            c1 += u1.x * v1.x + u1.y * v1.y + u1.z * v1.z + u1.w * v1.w;
+            c2 += u2.x * v2.x + u2.y * v2.y + u2.z * v2.z + u2.w * v2.w;
+            c3 += u3.x * v3.x + u3.y * v3.y + u3.z * v3.z + u3.w * v3.w;
         }
+        for (; j < n4; j += 256) {
+            const float4 u = a4[j], v = b4[j];
+            c0 += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+        }
+        acc = (c0 + c1) + (c2 + c3);
     } else {
-        for (int64_t j = tid; j < hw; j += 256) acc += ar[j] * br[j];
+        float c0 = 0.f, c1 = 0.f;
+        int64_t j = tid;
+        for (; j + 256 < hw; j += 512) { c0 += ar[j] * br[j]; c1 += ar[j + 256] * br[j + 256]; }
+        for (; j < hw; j += 256) c0 += ar[j] * br[j];
+        acc = c0 + c1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -76,9 +110,13 @@ extern "C" int te_chan_scale_f32(float* out, const float* x, const float* s, int
     if (hw % 4 == 0 && aligned16(out) && aligned16(x) && hw / 4 < (int64_t)0xFFFFFFFF) {
         const int grid = (int)std::min<int64_t>(te::cdiv(n / 4, 256), te::kNumCU * 16);
         chan_scale_vec4_kernel<<<grid, 256, 0, st>>>((float4*)out, (const float4*)x, s, n / 4, (uint32_t)(hw / 4));
+    } else if (hw >= 4 && n >= 1024 && aligned16(out) && aligned16(x)) {
+        const int grid = (int)std::min<int64_t>(te::cdiv(n / 4, 256), te::kNumCU * 16);
+        chan_scale_flat4_kernel<<<grid, 256, 0, st>>>((float4*)out, (const float4*)x, s, n / 4, hw);
+        if (n % 4) chan_scale_kernel<<<1, 64, 0, st>>>(out, x, s, n, hw, n - n % 4);
     } else {
         const int grid = (int)std::min<int64_t>(te::cdiv(n, 256), te::kNumCU * 16);
-        chan_scale_kernel<<<grid, 256, 0, st>>>(out, x, s, n, hw);
+        chan_scale_kernel<<<grid, 256, 0, st>>>(out, x, s, n, hw, 0);
     }
     return te::launch_status("te_chan_scale_f32");
 }
