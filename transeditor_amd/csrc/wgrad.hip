@@ -423,8 +423,8 @@ inline unsigned magic(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d
 template <int KIND>
 bool fill_geometry(WgArgs& a) {
     constexpr int NCELL = WK<KIND>::NCELL;
-    a.TW = std::min(32, pow2ceil(a.W));
-    if (a.TW < 2) return false;
+    a.TW = std::max(2, std::min(32, pow2ceil(a.W)));      // a k-step multiplies two horizontally adjacent cells: 1-pixel-wide
+                                                          // images get a second, masked column
     a.TH = std::max(1, std::min(pow2ceil(a.H), NCELL / a.TW));
     a.NC = a.TH * a.TW;                            // cells per stage (<= NCELL)
     a.lgTW = ilog2(a.TW);
@@ -475,7 +475,7 @@ int launch_wgrad(WgArgs a, hipStream_t s) {
 
 inline int n_cell_tiles(int kind, int H, int W) {
     const int ncell = (kind == TE_CONV_T2) ? 32 : 64;
-    const int TW = std::min(32, pow2ceil(W));
+    const int TW = std::max(2, std::min(32, pow2ceil(W)));
     const int TH = std::max(1, std::min(pow2ceil(H), ncell / TW));
     return ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
 }
