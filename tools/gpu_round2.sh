@@ -18,4 +18,6 @@ for t in train gen g1024; do python tools/rocpd_stats.py gpurun_out/prof_$t/${t}
 bash tools/pmc_round.sh > gpurun_out/r2_pmc_round.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc gpurun_out/r02 > gpurun_out/r2_pmc_summary_stdout.txt 2>&1
 rm -f gpurun_out/pmc/*.db
+( timeout 300 python tools/conv_shape_census.py ) > gpurun_out/r2_conv_shape_census.log 2>&1; echo "shape census rc=$?"
+( timeout 300 python tools/conv_fuzz.py 1000 5 ) > gpurun_out/r2_conv_fuzz.log 2>&1; echo "conv fuzz rc=$?"; tail -1 gpurun_out/r2_conv_fuzz.log
 tail -2 gpurun_out/r2_bench_n1.json | cut -c1-600
