@@ -756,7 +756,10 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
     return 0;
 }
 
-constexpr int conv_occ() { return 3; }      // waves per SIMD the plain 3x3 128-row tile is compiled for (2 measured slower)
+#ifndef TE_CONV_OCC
+#define TE_CONV_OCC 3
+#endif
+constexpr int conv_occ() { return TE_CONV_OCC; }      // waves per SIMD the plain 3x3 128-row tile is compiled for (2: 135.7 vs 140.1 TFLOP/s with the FAST kernel)
 
 template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
 void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
