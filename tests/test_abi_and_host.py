@@ -195,3 +195,13 @@ def test_upfirdn2d_geometry_matches_reference_formulas():
     # discriminator blur pad (2,2) before the stride-2 3x3: 256 -> 257; skip branch blur (1,1) with down 2: 256 -> 128
     assert _geometry((256, 256), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2))[0] == (257, 257)
     assert _geometry((256, 256), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1))[0] == (128, 128)
+
+
+def test_tools_and_entry_points_compile():
+    """the GPU-side diagnostics under tools/ (run only on the GPU box) at least parse, so a visit is never lost to a typo"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, 'tools', '*.py')) + [os.path.join(root, 'bench.py'), os.path.join(root, '__graft_entry__.py')]
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, 'exec')
