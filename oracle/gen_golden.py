@@ -477,7 +477,10 @@ def gen_spatial_regu(M):
             wrt = param.requires_grad_()
             fake_img, _, _ = G(noise, wrt)
         else:
-            wrt = G(noise, param, return_only_mapped_p=True).detach().requires_grad_()
+            # as the reference (:266-268): the mapped code is NOT detached (requires_grad_() on a non-leaf is a no-op), so the
+            # penalty's backward also reaches the spatial mapping network
+            wrt = G(noise, param, return_only_mapped_p=True)
+            wrt.requires_grad_()
             fake_img, _, _ = G(noise, wrt, use_spatial_mapping=False)
         orig = torch.randn_like
         torch.randn_like = lambda t, *a, **k: pl.to(t)

@@ -188,3 +188,92 @@ def test_gradsync_with_deferred_async_work_world2():
             assert (ma == mb).all()                              # bit-identical on both ranks
     for x, l in zip(ref_a, loc_a):                               # disabled sync leaves the local gradient untouched
         assert (x == l).all()
+
+
+class _Branchy(torch.nn.Module):
+    """`extra` sits UPSTREAM of the linear layer (its gradient is the last one backward produces) and is only used when asked"""
+
+    def __init__(self):
+        super().__init__()
+        self.extra = torch.nn.Parameter(torch.ones(8))           # registered first -> same bucket as the layer, reported last
+        self.lin = torch.nn.Linear(8, 4)
+
+    def forward(self, x, use_extra):
+        return self.lin(x * self.extra if use_extra else x)
+
+
+def _worker_masks(rank, world, port, q):
+    import torch.distributed as dist
+    from transeditor_amd.utils import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)
+        net = _Branchy()
+        D.broadcast_module(net)
+        sync = D.GradSync(net)                                   # one bucket
+        assert len(sync.buckets) == 1
+        out = {}
+
+        def run(tag, use_extra, seed):
+            for prm in net.parameters():
+                prm.grad = None
+            torch.manual_seed(seed + rank)
+            x = torch.randn(5, 8)
+            loss = net(x, use_extra).pow(2).sum()
+            ref = torch.autograd.grad(loss, [prm for prm in net.parameters()], retain_graph=True, allow_unused=True)
+            loss.backward()
+            sync.all_reduce(tag)
+            return [None if g is None else g.numpy() for g in ref], [None if prm.grad is None else prm.grad.clone().numpy()
+                                                                      for prm in net.parameters()]
+        # kind 'a': `extra` unused on every rank -> keeps .grad None, learnt as unused (the hooks stop waiting for it)
+        for i in range(3):
+            out[f'a{i}'] = run('a', False, 10 * i)
+        assert net.extra.grad is None and net.extra in sync._unused
+        # kind 'b': used on every rank, but the bucket has already left when its gradient arrives -> straggler path
+        out['b0'] = run('b', True, 100)
+        assert net.extra not in sync._unused
+        out['b1'] = run('b', True, 110)
+        out['b2'] = run('b', True, 120)                          # past the warm-up: learnt mask, no exchange
+        # kind 'c': used on rank 0 ONLY -> every rank must still get the averaged gradient (DDP's used-bitmap semantics)
+        out['c0'] = run('c', rank == 0, 200)
+        out['c1'] = run('c', rank == 0, 210)
+        out['c2'] = run('c', rank == 0, 220)
+        # a gradient nobody announced during the warm-up of its kind is refused instead of silently diverging
+        err = None
+        try:
+            run('a', True, 300)
+        except RuntimeError as e:
+            err = str(e)
+        q.put((rank, out, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_global_used_mask_and_stragglers_world2():
+    """`.grad` must not be decided from rank-local information.  A parameter used on one rank only gets the
+    averaged gradient everywhere; a parameter thought unused whose gradient arrives after its bucket was launched is reduced
+    as a straggler on every rank (same collectives everywhere); an unannounced gradient after the warm-up raises."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_masks, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, oa, ea), (_, ob, eb) = res
+    assert ea and eb and 'warm-up' in ea
+    for key in oa:
+        (ra, ga), (rb, gb) = oa[key], ob[key]
+        for i, (x, y, ma, mb) in enumerate(zip(ra, rb, ga, gb)):
+            if x is None and y is None:
+                assert ma is None and mb is None, key             # unused everywhere: .grad stays None
+                continue
+            mean = ((0 if x is None else x) + (0 if y is None else y)) / 2
+            assert ma is not None and mb is not None, (key, i)
+            assert np.abs(ma - mean).max() < 1e-6 and np.abs(mb - mean).max() < 1e-6, (key, i)
+            assert (ma == mb).all(), (key, i)

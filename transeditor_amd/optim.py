@@ -77,7 +77,23 @@ class FusedAdam(torch.optim.Optimizer):
             st['step'] = torch.tensor(0.0, dtype=torch.float32)          # torch.optim.Adam's layout (host scalar tensor)
             st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        else:
+            self._host_step(st)
         return st
+
+    @staticmethod
+    def _host_step(st):
+        """`step` as a host fp32 scalar tensor.  The reference's torch 1.7 Adam (environment.yaml:130) stores a python int, and
+        `torch.load(map_location=device)` moves a tensor `step` to the GPU, where `.item()` would synchronise once per parameter
+        and step: both are normalised here (once, at load time or at the first step after it)."""
+        s = st.get('step')
+        if s is not None and not (torch.is_tensor(s) and s.device.type == 'cpu' and s.dtype == torch.float32 and s.ndim == 0):
+            st['step'] = torch.tensor(float(s), dtype=torch.float32)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            self._host_step(st)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -87,7 +87,8 @@ class RandomSampler:
 
 
 class TrainStep:
-    def __init__(self, args, device, generator=None, discriminator=None, sampler=None):
+    def __init__(self, args, device, generator=None, discriminator=None, sampler=None, force_sync=None):
+        """`force_sync`: run the gradient exchange machinery on a process group of one rank too (GradSync(force=...))."""
         self.args, self.device = args, device
         mk = lambda: Generator(args.size, args.latent, args.latent, args.token, channel_multiplier=args.channel_multiplier,
                                n_trans=args.num_trans, pixel_norm_op_dim=args.pixel_norm_op_dim).to(device)
@@ -114,7 +115,8 @@ class TrainStep:
         self.accum = 0.5 ** (32 / (10 * 1000))
         D.broadcast_module(self.generator)
         D.broadcast_module(self.discriminator)
-        self.g_sync, self.d_sync = D.GradSync(self.generator), D.GradSync(self.discriminator)
+        self.g_sync = D.GradSync(self.generator, force=force_sync)
+        self.d_sync = D.GradSync(self.discriminator, force=force_sync)
         zero = torch.tensor(0.0, device=device)
         self.loss = {'r1': zero, 'path': zero, 'path_length': zero, 'spatial_path': zero, 'spatial_path_length': zero}
 
@@ -130,7 +132,7 @@ class TrainStep:
         self.loss.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
         Dn.zero_grad()
         d_loss.backward()
-        self.d_sync.all_reduce()
+        self.d_sync.all_reduce('d')
         self.d_optim.step()
 
     def r1_step(self, real_img):
@@ -141,7 +143,7 @@ class TrainStep:
         r1_loss = d_r1_loss(real_pred, real_img)
         Dn.zero_grad()
         (a.r1 / 2 * r1_loss * a.d_reg_every + 0 * real_pred[0]).backward()
-        self.d_sync.all_reduce()
+        self.d_sync.all_reduce('r1')
         self.d_optim.step()
         self.loss['r1'] = r1_loss.detach()
 
@@ -155,7 +157,7 @@ class TrainStep:
         self.loss['g'] = g_loss.detach()
         G.zero_grad()
         g_loss.backward()
-        self.g_sync.all_reduce()
+        self.g_sync.all_reduce('g')
         self.g_optim.step()
 
     def path_step(self):
@@ -171,7 +173,7 @@ class TrainStep:
         if a.path_batch_shrink:
             weighted = weighted + 0 * fake_img[0, 0, 0, 0]
         weighted.backward()
-        self.g_sync.all_reduce()
+        self.g_sync.all_reduce('path')
         self.g_optim.step()
         self.mean_path_length_avg = D.reduce_sum(self.mean_path_length).item() / D.get_world_size()
         self.loss.update(path=path_loss.detach(), path_length=path_lengths.mean().detach())
@@ -186,7 +188,10 @@ class TrainStep:
                 wrt = param.requires_grad_()
                 fake_img, _, _ = G(noise, wrt)
             else:
-                wrt = G(noise, param, return_only_mapped_p=True).detach().requires_grad_()
+                # :266-268 — the mapped code stays attached (requires_grad_() on a non-leaf is a no-op in the reference too),
+                # so the penalty's backward also updates the spatial mapping network
+                wrt = G(noise, param, return_only_mapped_p=True)
+                wrt.requires_grad_()
                 fake_img, _, _ = G(noise, wrt, use_spatial_mapping=False)
         loss, self.mean_spatial_path_length, lengths = g_path_regularize(
             fake_img, wrt, self.mean_spatial_path_length, self.sampler.randn_like(fake_img))
@@ -195,7 +200,7 @@ class TrainStep:
         if a.path_batch_shrink:
             weighted = weighted + 0 * fake_img[0, 0, 0, 0]
         weighted.backward()
-        self.g_sync.all_reduce()
+        self.g_sync.all_reduce('spatial')
         self.g_optim.step()
         self.mean_spatial_path_length_avg = D.reduce_sum(self.mean_spatial_path_length).item() / D.get_world_size()
         self.loss.update(spatial_path=loss.detach(), spatial_path_length=lengths.mean().detach())

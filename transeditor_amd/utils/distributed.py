@@ -83,18 +83,28 @@ class GradSync:
     flat buffer with one multi-tensor copy and its all-reduce is issued asynchronously, so RCCL traffic over xGMI overlaps
     the rest of the backward.  `all_reduce()` issues whatever is left, waits, averages and points every `.grad` at its
     slice of the bucket (no copy back; the buffers are reused by the next backward, after `.grad` has been reset).
-    Parameters that received no gradient on this rank (the unused `noise.weight`s; by symmetry unused on every rank)
-    contribute zeros to the bucket and keep `.grad = None`, which is what DistributedDataParallel with
-    find_unused_parameters=True leaves (train_spatial_query.py:494-509), so optimiser state is created for exactly the
-    same parameters as in the reference.
+
+    Unused parameters (the generator's `noise.weight`s): DistributedDataParallel with find_unused_parameters=True
+    (train_spatial_query.py:494-509) reduces a used-bitmap, hands the averaged gradient to EVERY rank when ANY rank used the
+    parameter and leaves `.grad = None` when none did.  Same here: during the first `MASK_CALLS` calls of every call kind
+    (`tag`: 'd', 'r1', 'g', 'path', ...) a used-mask is all-reduced (MAX) and decides, identically on every rank, which
+    parameters get `.grad`, which are no longer waited for by the hooks, and which stragglers (a gradient that arrived after
+    its bucket had been launched) are reduced one by one - so every rank always issues the same collectives.  After the
+    warm-up the learnt mask of the kind is used without communication; a rank whose local pattern then departs from it
+    raises instead of silently diverging (`reset_masks()` re-learns).
 
     Nothing here relies on the collective being synchronous: between `_launch` and `work.wait()` the flat buffer is
     neither read nor written by this class (tests/test_distributed_gloo.py drives it with deferred work objects).
+    `force=True` (or TE_GRADSYNC_FORCE=1) runs the whole machinery - hooks, buckets, collectives - on a group of ONE rank
+    too: tests/test_gpu_rccl_world1.py uses it to put RCCL itself under this code on a single GPU.
     """
+    MASK_CALLS = 2
 
-    def __init__(self, module, bucket_bytes=32 << 20):
+    def __init__(self, module, bucket_bytes=32 << 20, force=None):
+        import os
         self.params = [p for p in module.parameters()]
         self.enabled = True                               # False: hooks and all_reduce() do nothing (bench: no-exchange leg)
+        self.force = (os.environ.get('TE_GRADSYNC_FORCE') == '1') if force is None else bool(force)
         self.buckets, cur, cur_bytes = [], [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * p.element_size()
@@ -107,6 +117,7 @@ class GradSync:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
         self._slot = {}                                   # param -> (bucket index, offset)
+        self._index = {p: i for i, p in enumerate(self.params)}
         self._size = []
         for bi, bucket in enumerate(self.buckets):
             off = 0
@@ -116,16 +127,21 @@ class GradSync:
             self._size.append(off)
         self._seen = [set() for _ in self.buckets]
         self._work = [None] * len(self.buckets)
-        # parameters observed to receive no gradient (the generator's `noise.weight`s): learnt at the first
-        # all_reduce() and no longer waited for, so their buckets can still launch from the hooks
+        # parameters no rank gave a gradient in any learnt call kind (the generator's `noise.weight`s): no longer waited
+        # for, so their buckets can still launch from the hooks
         self._unused = set()
+        self._masks = {}                                  # tag -> (calls seen, learnt global used-mask as a tuple of bools)
         self._late = []                                   # gradients that arrived after their bucket was launched
+        self._next = 0                                    # next bucket to launch (collectives go out in bucket order)
         self._handles = []
         self.calls = 0
-        if get_world_size() > 1:
+        if self.active():
             self._install_hooks()
 
     # ---- bookkeeping
+    def active(self):
+        return get_world_size() > 1 or (self.force and _ready())
+
     def bytes_per_call(self):
         """bytes this rank hands to the all-reduce in one all_reduce() call (all buckets)"""
         return sum(n * self.params[0].element_size() for n in self._size)
@@ -134,6 +150,11 @@ class GradSync:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+    def reset_masks(self):
+        """forget the learnt used-masks (the next MASK_CALLS calls of every kind exchange them again)"""
+        self._masks.clear()
+        self._unused.clear()
 
     # ---- internals
     def _buffer(self, bi):
@@ -158,9 +179,20 @@ class GradSync:
             self._late.append(p)
             return
         self._seen[bi].add(p)
-        expected = sum(1 for q in self.buckets[bi] if q.requires_grad and q not in self._unused)
-        if len(self._seen[bi] - self._unused) >= expected:
-            self._launch(bi)
+        self._launch_ready()
+
+    def _launch_ready(self, flush=False):
+        """Launch buckets strictly in index order (every rank issues the same sequence of collectives, whatever the order or
+        the rank-local absence of gradients): the next bucket goes as soon as every parameter it still waits for has
+        reported; `flush` (from all_reduce) sends whatever is left."""
+        while self._next < len(self.buckets):
+            bi = self._next
+            bucket = self.buckets[bi]
+            if any(p.requires_grad for p in bucket):      # (a frozen bucket is skipped on every rank alike)
+                if not flush and any(q.requires_grad and q not in self._unused and q not in self._seen[bi] for q in bucket):
+                    return
+                self._launch(bi)
+            self._next += 1
 
     def _views(self, bi):
         flat = self._buffer(bi)
@@ -181,34 +213,63 @@ class GradSync:
             torch._foreach_copy_(dst, src)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
-    def all_reduce(self):
-        world = get_world_size()
-        if world == 1 or not self.enabled:
+    def _global_mask(self, tag, local):
+        """(used-mask over ALL ranks for this call, exchanged now?): exchanged during the warm-up calls of the kind, the
+        learnt one afterwards."""
+        seen, learnt = self._masks.get(tag, (0, None))
+        if seen < self.MASK_CALLS:
+            m = torch.tensor([1.0 if u else 0.0 for u in local], device=self.params[0].device)
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            glob = tuple(v > 0.5 for v in m.tolist())     # (host read-back: warm-up calls only)
+            # a parameter used in any warm-up call of the kind counts as used from then on
+            self._masks[tag] = (seen + 1, glob if learnt is None else tuple(a or b for a, b in zip(glob, learnt)))
+            return glob, True
+        bad = [i for i, (u, g) in enumerate(zip(local, learnt)) if u and not g]
+        if bad:
+            raise RuntimeError(f'GradSync: parameter #{bad[0]} received a gradient in a "{tag}" call although no rank used it '
+                               f'during the warm-up calls; the replicas would diverge (call reset_masks() when the graph changes)')
+        return learnt, False
+
+    def all_reduce(self, tag='default'):
+        if not self.active() or not self.enabled:
             return
+        world = get_world_size()
         self.calls += 1
         active = [bi for bi, b in enumerate(self.buckets) if any(p.requires_grad for p in b)]
-        had_grad = {}
-        for bi in active:
-            for p in self.buckets[bi]:
-                had_grad[p] = p.grad is not None
-                if p.requires_grad and p.grad is None:
-                    self._unused.add(p)
-                elif p in self._unused and p in self._seen[bi]:
-                    self._unused.discard(p)               # it does get gradients after all
-            if self._work[bi] is None:
-                self._launch(bi)
-        late = set(self._late)
+        if not active:
+            return
+        # fixed order of collectives on every rank: the buckets (in index order; some already left from the hooks), then the
+        # used-mask, then - only while a kind is being learnt - the straggler flags and the stragglers themselves
+        self._launch_ready(flush=True)
+        local = [p.requires_grad and (p.grad is not None) for p in self.params]
+        glob, exchanged = self._global_mask(tag, local)
+        thought_unused = self._unused
+        # unused on every rank in every kind learnt so far -> the hooks stop waiting for it
+        every = [m for _, m in self._masks.values()]
+        self._unused = {p for i, p in enumerate(self.params) if not any(m[i] for m in every)}
+        late_local = set(self._late)
         for bi in active:
             self._work[bi].wait()
             self._flat[bi].div_(world)
             for p, v in zip(self.buckets[bi], self._views(bi)):
-                if p.requires_grad and p not in late and had_grad[p]:
+                if p.requires_grad and glob[self._index[p]] and p not in late_local:
                     p.grad = v                            # the averaged gradient lives in the bucket: no copy back
-        for p in self._late:                              # rare: reduce stragglers one by one and stop treating them as unused
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-            p.grad.div_(world)
-            self._unused.discard(p)
+        # Stragglers: a parameter thought unused whose gradient arrived after its bucket had been launched.  Only possible
+        # while a kind is being learnt (afterwards _global_mask raises).  The candidates - thought unused, used by some rank
+        # now - are the same list on every rank, so the flag exchange and the one-by-one reductions are issued everywhere.
+        cands = [p for p in self.params if p in thought_unused and p.requires_grad and glob[self._index[p]]] if exchanged else []
+        if cands:
+            flags = torch.tensor([1.0 if p in late_local else 0.0 for p in cands], device=self.params[0].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            for p, f in zip(cands, flags.tolist()):
+                if f > 0.5:
+                    g = p.grad if p in late_local else torch.zeros_like(p)
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                    p.grad = g.div_(world)
+        elif late_local:
+            raise RuntimeError('GradSync: a gradient arrived after its bucket was launched outside a warm-up call')
         self._late.clear()
+        self._next = 0
         for bi in range(len(self.buckets)):
             self._seen[bi].clear()
             self._work[bi] = None
