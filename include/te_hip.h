@@ -139,6 +139,13 @@ int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, 
 int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
+/* te_conv_ws_f32 with a residual epilogue: out = act(osc * conv + bias) + res, res shaped like out (may be NULL; not for
+ * TE_CONV_T2).  It carries the sum of a ResBlock's two branches (model_spatial_query.py:796, forward) and the sum of the two
+ * gradient branches that meet at the block's input (backward) without an extra elementwise pass.  A split launch (S > 1)
+ * needs the workspace. */
+int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
+                    const float* bias, const float* res, int act, int kind, int B, int K, int M, int H, int W,
+                    te_stream_t stream);
 
 /* Weight-gradient correlation, per sample and per pixel chunk ("slabs"), NO modulation applied:
  *   slab[b][s][co][ci][tap] = sum_{pixels of chunk s} g[b,co,p (+) tap] * x[b,ci,p]
@@ -222,6 +229,14 @@ int te_attn_stack_bwd_f32(float* gx0, float* gp0, float* gp, const float* gout, 
  */
 int te_blur_actgrad_tiles(int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1);
 int te_blur_actgrad_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major, int in_h,
+                        int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
+                        te_stream_t stream);
+/* K2c  the other order, backward of "conv + bias -> leaky-ReLU * scale -> blur" (first half of the discriminator's ResBlock,
+ * model_spatial_query.py:744-768): the adjoint FIR first, the activation gradient in its epilogue —
+ *   gx = upfirdn2d(g, k, up = down = 1, pads) * (ref > 0 ? scale : alpha * scale)    g [major, in_h, in_w],
+ *   ref = the saved activation output, shaped like gx;  partial[plane][tile] = sum of the tile's gx (bias gradient).
+ * Same tile count as te_blur_actgrad_tiles; in_w >= 4. */
+int te_blur_gradact_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major, int in_h,
                         int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
                         te_stream_t stream);
 

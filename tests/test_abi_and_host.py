@@ -179,6 +179,24 @@ def test_modconv_host_argument_logic():
     with M.second_order(), M.no_weight_grads():
         assert M._STATE == {'second_order': True, 'skip_w': True}
     assert M._STATE == {'second_order': False, 'skip_w': False}
+    # forward-side hints and the frozen-weight cache are thread-local (nn.DataParallel worker threads, a sampler next to a
+    # training loop); the skip flag travels on a token the nodes keep, because backward runs on the autograd engine's thread
+    import threading
+    seen = {}
+
+    def other():
+        seen['so'] = M._STATE['second_order']
+        seen['frozen'] = M._STATE.frozen_on
+        seen['graph_is_default'] = M.current_graph() is M._DEFAULT_GRAPH
+    with M.second_order() as tok, M.frozen_weights({}):
+        assert M.current_graph() is tok and tok is not M._DEFAULT_GRAPH
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+    assert seen == {'so': False, 'frozen': False, 'graph_is_default': True}
+    with M.no_weight_grads():                       # flips the token of the forward that just ended (and the default one)
+        assert tok.skip_w and M._DEFAULT_GRAPH.skip_w
+    assert not tok.skip_w and not M._DEFAULT_GRAPH.skip_w
 
 
 def test_upfirdn2d_geometry_matches_reference_formulas():

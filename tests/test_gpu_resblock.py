@@ -1,0 +1,133 @@
+"""The discriminator's ResBlock as one autograd node (op/resblock.py; reference ResBlock.forward,
+model_spatial_query.py:780-798) and the two kernel features it stands on: the residual epilogue of te_conv_res_f32 and the
+activation-gradient epilogue of the adjoint blur (te_blur_gradact_f32).  Checked against the CPU oracle (forward, dx, every
+parameter gradient, R1-style double backward) and against the unfused route of the same module."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, rel_l2
+from oracle import te_oracle as O
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _block(cin, cout, seed):
+    from transeditor_amd.model_spatial_query import ResBlock
+    rb = ResBlock(cin, cout)
+    sd = rb.state_dict()
+    synth.fill_state_dict(sd, seed)
+    for k in sd:
+        if k.endswith('bias'):                       # FusedLeakyReLU biases start at zero: give them values
+            sd[k].copy_(0.3 * synth.normal(tuple(sd[k].shape), f'rb.b.{k}.{seed}'))
+    rb.load_state_dict(sd)
+    return rb.to(DEV), {k: v.clone() for k, v in sd.items()}
+
+
+def _oracle_block(P, x):
+    h = O.conv_layer(P, 'conv1', x, 3)
+    h = O.conv_layer(P, 'conv2', h, 3, downsample=True)
+    s = O.conv_layer(P, 'skip', x, 1, downsample=True, bias=False, activate=False)
+    return (h + s) / math.sqrt(2)
+
+
+@pytest.mark.parametrize('cin,cout,H,B', [(16, 32, 16, 3), (64, 128, 32, 2), (128, 256, 64, 2), (24, 40, 10, 2), (512, 512, 8, 4)])
+def test_resblock_node_vs_oracle(cin, cout, H, B):
+    rb, sd = _block(cin, cout, 3)
+    assert rb._standard()
+    x = synth.normal((B, cin, H, H), f'rb.x.{cin}.{H}')
+    gy = synth.normal((B, cout, H // 2, H // 2), f'rb.g.{cout}.{H}')
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'kernel' not in k else v) for k, v in sd.items()}
+    xc = x.clone().requires_grad_(True)
+    ref = _oracle_block(P, xc)
+    names = [k for k, v in P.items() if v.requires_grad]
+    gref = torch.autograd.grad((ref * gy).sum(), [xc] + [P[k] for k in names])
+    xd = x.to(DEV).requires_grad_(True)
+    out = rb(xd)
+    assert out.grad_fn is not None and 'ResBlock' in type(out.grad_fn).__name__
+    assert rel_err(out, ref) < 2e-5
+    params = dict(rb.named_parameters())
+    got = torch.autograd.grad((out * gy.to(DEV)).sum(), [xd] + [params[k] for k in names])
+    for n, a, b in zip(['dx'] + names, got, gref):
+        assert rel_l2(a, b) < 2e-5, n
+        assert rel_err(a, b) < 2e-4, n
+
+
+def test_resblock_node_frozen_weights_and_unfused_route():
+    """G step: the discriminator is frozen, only dx flows.  And the node equals the unfused route (second_order()) of the module."""
+    from transeditor_amd.op.modconv import second_order
+    rb, _ = _block(64, 128, 5)
+    x = synth.normal((2, 64, 32, 32), 'rb.x2').to(DEV)
+    gy = synth.normal((2, 128, 16, 16), 'rb.g2').to(DEV)
+    xa = x.clone().requires_grad_(True)
+    with second_order():
+        ya = rb(xa)
+    ga = torch.autograd.grad((ya * gy).sum(), [xa] + list(rb.parameters()))
+    for p in rb.parameters():
+        p.requires_grad_(False)
+    xb = x.clone().requires_grad_(True)
+    yb = rb(xb)
+    gb, = torch.autograd.grad((yb * gy).sum(), [xb])
+    assert rel_err(yb, ya) < 1e-5 and rel_l2(gb, ga[0]) < 1e-5
+
+
+def test_resblock_node_double_backward_matches_oracle():
+    """R1-style: d/dparams of || d out . gy / dx ||^2 through the node's recorded backward vs the CPU oracle."""
+    rb, sd = _block(32, 64, 7)
+    x = synth.normal((2, 32, 16, 16), 'rb.x3')
+    gy = synth.normal((2, 64, 8, 8), 'rb.g3')
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'kernel' not in k else v) for k, v in sd.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    xc = x.clone().requires_grad_(True)
+    gx, = torch.autograd.grad((_oracle_block(P, xc) * gy).sum(), xc, create_graph=True)
+    ref = torch.autograd.grad(gx.pow(2).sum(), [P[k] for k in names], allow_unused=True)
+    xd = x.to(DEV).requires_grad_(True)
+    out = rb(xd)                                               # fused node; its backward is recorded below
+    gxd, = torch.autograd.grad((out * gy.to(DEV)).sum(), xd, create_graph=True)
+    assert rel_l2(gxd, gx) < 2e-5
+    params = dict(rb.named_parameters())
+    got = torch.autograd.grad(gxd.pow(2).sum(), [params[k] for k in names], allow_unused=True)
+    for n, a, b in zip(names, got, ref):
+        if b is None or float(b.abs().max()) == 0:
+            assert a is None or float(a.abs().max()) < 1e-6, n
+            continue
+        assert rel_l2(a, b) < 1e-4, n
+
+
+@pytest.mark.parametrize('kind,K,M,H,B', [('3x3', 64, 128, 32, 2), ('1x1', 128, 256, 64, 2), ('3x3', 512, 512, 8, 4),
+                                         ('1x1', 256, 512, 4, 4), ('3x3', 20, 24, 9, 3)])
+def test_conv_residual_epilogue(kind, K, M, H, B):
+    """out = act(conv + bias) + res, on the one-pass and on the split-K (small image) route"""
+    from transeditor_amd import _lib
+    ks = 3 if kind == '3x3' else 1
+    x = synth.normal((B, K, H, H), f'cr.x.{K}.{H}')
+    w = synth.normal((M, K, ks, ks), f'cr.w.{K}.{M}') / math.sqrt(K * ks * ks)
+    b = 0.2 * synth.normal((M,), f'cr.b.{M}')
+    r = synth.normal((B, M, H, H), f'cr.r.{M}.{H}')
+    for act in (0, 3):
+        ref = F.conv2d(x, w, b, padding=ks // 2)
+        if act:
+            ref = F.leaky_relu(ref, 0.2) * math.sqrt(2)
+        ref = ref + r
+        wp = _lib.conv_pack(w.to(DEV), _lib.PACK_FWD, 1.0)
+        out = _lib.conv(x.to(DEV), wp, _lib.CONV_3X3 if ks == 3 else _lib.CONV_1X1, M, H, H, None, None, b.to(DEV), act, res=r.to(DEV))
+        assert rel_err(out, ref) < 2e-5, act
+
+
+@pytest.mark.parametrize('C,H,B', [(8, 64, 2), (5, 32, 3), (3, 128, 1), (16, 8, 2), (2, 256, 1), (4, 20, 2)])
+def test_blur_gradact_kernel(C, H, B):
+    """gx = adjoint_blur(g) * slope(ref), bias-gradient = its sum over batch and pixels (pad (2,2) blur: (H+1) -> H)"""
+    from transeditor_amd import _lib
+    k = O.fir_kernel((1, 3, 3, 1))
+    g = synth.normal((B, C, H + 1, H + 1), f'bg.g.{C}.{H}')
+    y = synth.normal((B, C, H, H), f'bg.y.{C}.{H}')
+    # forward blur pad (2,2): H -> H+1; its adjoint has pads (1,1): H+1 -> H
+    adj = O.upfirdn2d(g, torch.flip(k, [0, 1]), pad=(1, 1))
+    ref = adj * torch.where(y > 0, math.sqrt(2), 0.2 * math.sqrt(2))
+    gx, gb = _lib.blur_gradact(g.to(DEV), y.to(DEV), torch.flip(k, [0, 1]).contiguous().to(DEV), (1, 1, 1, 1), 0.2, math.sqrt(2))
+    assert rel_err(gx, ref) < 1e-5
+    assert rel_err(gb, ref.sum(dim=(0, 2, 3))) < 1e-5

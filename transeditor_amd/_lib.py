@@ -35,6 +35,7 @@ _SIGNATURES = {
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -45,6 +46,7 @@ _SIGNATURES = {
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'te_blur_actgrad_tiles': (C.c_int, [_I] * 8),
     'te_blur_actgrad_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    'te_blur_gradact_f32': (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     'te_small_gemm_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
     'te_small_gemm_batched_f32': (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _L, _L, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L,
                                              _F, _F, _I, _P]),
@@ -226,6 +228,26 @@ def blur_actgrad(g, ref, k_flipped, pad, alpha, scale):
     return gx, partial.sum(dim=(0, 2))
 
 
+def blur_gradact(g, ref, k_flipped, pad, alpha, scale):
+    """backward of 'bias + lrelu -> blur' in one pass: (upfirdn2d(g, k_flipped, pad) * slope(ref), gbias).  ref is shaped
+    like the result."""
+    g, ref = g.contiguous(), ref.contiguous()
+    B, Cn, H, W = g.shape
+    kh, kw = k_flipped.shape
+    px0, px1, py0, py1 = pad
+    oh, ow = H + py0 + py1 - kh + 1, W + px0 + px1 - kw + 1
+    if tuple(ref.shape) != (B, Cn, oh, ow):
+        raise RuntimeError(f'blur_gradact: ref {tuple(ref.shape)} is not the shape of the adjoint blur output {(B, Cn, oh, ow)}')
+    tiles = lib().te_blur_actgrad_tiles(H, W, kh, kw, px0, px1, py0, py1)
+    if tiles <= 0:
+        raise RuntimeError(f'te_blur_actgrad_tiles failed ({tiles})')
+    gx = torch.empty(B, Cn, oh, ow, device=g.device, dtype=g.dtype)
+    partial = torch.empty(B, Cn, tiles, device=g.device, dtype=g.dtype)
+    _check(lib().te_blur_gradact_f32(_ptr(gx), _ptr(partial), _ptr(g), _ptr(ref), _ptr(k_flipped.contiguous()), B * Cn, H, W,
+                                     kh, kw, px0, px1, py0, py1, alpha, scale, _stream()), 'te_blur_gradact_f32')
+    return gx, partial.sum(dim=(0, 2))
+
+
 # --------------------------------------------------------------------------------------------- F1
 def conv_pack(w, kind_pack, wscale=1.0):
     """w [Co,Ci,k,k] (model layout) -> packed Wp[tap][Kp][Mp]."""
@@ -255,18 +277,21 @@ def conv_out_shape(kind, B, M, H, W):
     return (B, M, H, W)
 
 
-def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0):
-    """H, W = LOW-resolution size (see te_hip.h).  x [B,K,Hin,Win]."""
+def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0, res=None):
+    """H, W = LOW-resolution size (see te_hip.h).  x [B,K,Hin,Win].  res: residual added after the activation."""
     x = x.contiguous()
     B, K = x.shape[0], x.shape[1]
     out = torch.empty(conv_out_shape(kind, B, M, H, W), device=x.device, dtype=x.dtype)
+    if res is not None and tuple(res.shape) != tuple(out.shape):
+        raise RuntimeError(f'te_hip: residual {tuple(res.shape)} does not match the convolution output {tuple(out.shape)}')
     S = lib().te_conv_splitk_count(kind, B, K, M, H, W)
     if S < 1:
         raise RuntimeError(f'te_conv_splitk_count failed ({S})')
     # small images split the channel loop over the grid: per-split slabs + fixed-order sum (deterministic, graph-capturable)
     ws = torch.empty((S,) + tuple(out.shape), device=x.device, dtype=x.dtype) if S > 1 else None
-    _check(lib().te_conv_ws_f32(_ptr(out), _ptr(ws), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias), act, kind, B, K, M, H, W,
-                                _stream()), 'te_conv_ws_f32')
+    _check(lib().te_conv_res_f32(_ptr(out), _ptr(ws), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias),
+                                 _ptr(res.contiguous()) if res is not None else None, act, kind, B, K, M, H, W, _stream()),
+           'te_conv_res_f32')
     return out
 
 

@@ -89,6 +89,7 @@ struct ConvArgs {
     const float* isc;
     const float* osc;
     const float* bias;
+    const float* res;        // residual [B][M][Ho][Wo] added AFTER the activation (the sum of a ResBlock / of two gradient branches), or NULL
     int B, K, M, Kp, Mp;
     int Hi, Wi, Ho, Wo;      // input / output spatial size
     int H, W;                // low-resolution size (cells of T2 live on (H+1)x(W+1))
@@ -590,7 +591,11 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 } else if (!IS_T2) {
                     float v = acc[mb][nb][r] * sc[r] + bi[r];
                     if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
-                    if (ok) obase[(size_t)ci * p.Wo + cj] = v;
+                    if (ok) {
+                        const size_t oi = (size_t)ci * p.Wo + cj;
+                        if (p.res) v += p.res[(size_t)(obase - p.out) + oi];
+                        obase[oi] = v;
+                    }
                 } else {
                     // the two column phases of a cell are adjacent outputs: one 8-byte store per row phase (rows are 2W+1
                     // wide, so the pair is only 4-byte aligned, which global stores accept)
@@ -623,7 +628,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 // epilogue of the split-K path: out = act((sum_z ws[z] | out) * osc[b,m] + bias[m]); the slabs are summed in fixed order
 __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ out, const float* __restrict__ ws, int ksplit,
                                                             const float* __restrict__ osc,
-                                                            const float* __restrict__ bias, int act, int M, int plane, int64_t total) {
+                                                            const float* __restrict__ bias, const float* __restrict__ res, int act,
+                                                            int M, int plane, int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t bm = e / plane;
         float v;
@@ -636,6 +642,7 @@ __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ 
         if (osc) v *= osc[bm];
         if (bias) v += bias[bm % M];
         if (act >= 3) v = (v > 0.f ? v : v * 0.2f) * (act == 3 ? 1.4142135623730951f : 1.f);
+        if (res) v += res[e];
         out[e] = v;
     }
 }
@@ -915,20 +922,23 @@ extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W)
     return conv_plan(kind, B, K, M, H, W).ksplit;
 }
 
-extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
-                              const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
+extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
+                               const float* bias, const float* res, int act, int kind, int B, int K, int M, int H, int W,
+                               te_stream_t stream_) {
     TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
+    TE_REQUIRE(!res || kind != TE_CONV_T2, TE_ERR_UNSUPPORTED, "te_conv_res_f32: no residual epilogue for the transposed kind");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
     TE_REQUIRE(kind >= 0 && kind <= 3, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     hipStream_t s = (hipStream_t)stream_;
     ConvArgs a{};
-    a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
+    a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
     const int tc = pl.tc;
     a.ksplit = pl.ksplit; a.kchunk = pl.kchunk;
     if (a.ksplit == 1) a.ws = nullptr;
+    TE_REQUIRE(!(res && a.ksplit > 1 && !a.ws), TE_ERR_NULL, "te_conv_res_f32: a split launch with a residual needs the workspace");
     if (a.ksplit > 1 && !a.ws) {       // no workspace: the splits accumulate into `out` with atomics (order not fixed)
         const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
         hipError_t e = hipMemsetAsync(out, 0, bytes, s);
@@ -967,10 +977,15 @@ extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const floa
     if (a.ksplit > 1 && (a.ws || osc || bias || act)) {
         const int plane = a.Ho * a.Wo;
         const int64_t total = (int64_t)B * M * plane;
-        conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, a.ws, a.ksplit, osc, bias, act,
-                                                                                                     M, plane, total);
+        conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, a.ws, a.ksplit, osc, bias, res,
+                                                                                                     act, M, plane, total);
     }
     return te::launch_status("te_conv_f32");
+}
+
+extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
+                              const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
+    return te_conv_res_f32(out, ws, in, wp, isc, osc, bias, nullptr, act, kind, B, K, M, H, W, stream_);
 }
 
 extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,

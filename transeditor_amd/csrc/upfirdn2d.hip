@@ -256,7 +256,11 @@ constexpr int BST = 128;                          // LDS row stride (floats)
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool AG, int D, bool EXT>
+// MODE 0: plain (+ bias / leaky-ReLU epilogue); 1: AG, the activation-gradient PROLOGUE (see fir_tile_kernel); 2: the
+// activation-gradient EPILOGUE: out = FIR(x) * (ref > 0 ? scale : alpha * scale) with ref the saved forward output at the
+// OUTPUT positions, and partial[plane][tile] = sum of the block's outputs (bias gradient): the backward of
+// 'conv + bias + leaky-ReLU -> blur' (the discriminator's ResBlock, model_spatial_query.py:744-768, 780-798) in one pass.
+template <int MODE, int D, bool EXT>
 __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ k,
                                                      const float* __restrict__ b, const FirParams p,
                                                      const float* __restrict__ ref = nullptr, float* __restrict__ partial = nullptr) {
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
 
     constexpr int NIT = BIH * BNQ, NLD = (NIT + 255) / 256;
     f32x4v stage[NLD];
+    constexpr bool AG = (MODE == 1);
     f32x4v rv[AG ? NLD : 1];
     // per-item geometry (the same for every plane).  Every item is ONE unconditional 16-byte buffer load (no branch between
     // the loads of a tile: they are all in flight together): items outside the image get an out-of-range offset (the
@@ -358,6 +363,26 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         constexpr int NH = EXT ? 3 : 2, NQ = EXT ? 5 : 4;
         const bool xcol = EXT && p.ext_x && blockIdx.x == gridDim.x - 1 && tx == BOW - 4;
         const bool xrow = EXT && p.ext_y && blockIdx.y == gridDim.y - 1 && ty == 15;
+        // MODE 2: the saved forward output at this lane's output positions, requested before the filter pass
+        float rf[MODE == 2 ? NH : 1][MODE == 2 ? NQ : 1];
+        if constexpr (MODE == 2) {
+            const float* rp = ref + (size_t)mj * p.out_h * p.out_w;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int oy = oy0 + 2 * ty + h;
+                const bool rowok = oy < p.out_h && !(h == 2 && !xrow);
+                const float* rrow = rp + (size_t)(rowok ? oy : 0) * p.out_w;
+                if (rowok && ox0 + tx + 3 < p.out_w) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                    const f32x4u v = *reinterpret_cast<const f32x4u*>(rrow + ox0 + tx);
+                    rf[h][0] = v[0]; rf[h][1] = v[1]; rf[h][2] = v[2]; rf[h][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rf[h][q] = (rowok && ox0 + tx + q < p.out_w) ? rrow[ox0 + tx + q] : 0.f;
+                }
+                if (EXT) rf[h][NQ - 1] = (rowok && xcol) ? rrow[ox0 + tx + 4] : 0.f;
+            }
+        }
         float res[NH][NQ];
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -382,6 +407,13 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
             }
         }
         const int ch = b ? (int)(mj % p.size_b) : 0;
+        float own2 = 0.f;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) res[h][q] *= rf[h][q] > 0.f ? p.scale : p.alpha * p.scale;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const int oy = oy0 + 2 * ty + h;
@@ -390,24 +422,40 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
             if (ox0 + tx + 3 < p.out_w) {      // one 16-byte store per lane (4-byte aligned rows are fine for global stores)
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
                 f32x4u v;
-                v[0] = epilogue<AG>(res[h][0], b, ch, p); v[1] = epilogue<AG>(res[h][1], b, ch, p);
-                v[2] = epilogue<AG>(res[h][2], b, ch, p); v[3] = epilogue<AG>(res[h][3], b, ch, p);
+                v[0] = epilogue<MODE != 0>(res[h][0], b, ch, p); v[1] = epilogue<MODE != 0>(res[h][1], b, ch, p);
+                v[2] = epilogue<MODE != 0>(res[h][2], b, ch, p); v[3] = epilogue<MODE != 0>(res[h][3], b, ch, p);
                 *reinterpret_cast<f32x4u*>(orow + ox0 + tx) = v;
-                if (EXT && xcol) orow[ox0 + tx + 4] = epilogue<AG>(res[h][NQ - 1], b, ch, p);
+                if (MODE == 2) own2 += (v[0] + v[1]) + (v[2] + v[3]);
+                if (EXT && xcol) {
+                    orow[ox0 + tx + 4] = epilogue<MODE != 0>(res[h][NQ - 1], b, ch, p);
+                    if (MODE == 2) own2 += res[h][NQ - 1];
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ox = ox0 + tx + q;
-                    if (ox < p.out_w) orow[ox] = epilogue<AG>(res[h][q], b, ch, p);
+                    if (ox < p.out_w) {
+                        orow[ox] = epilogue<MODE != 0>(res[h][q], b, ch, p);
+                        if (MODE == 2) own2 += res[h][q];
+                    }
                 }
             }
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) own2 += __shfl_down(own2, o, 64);
+            if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = own2;
+            __syncthreads();             // (the barrier at the top of the loop keeps sred intact until thread 0 has read it)
+            if (threadIdx.x == 0)
+                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                    (sred[0] + sred[1]) + (sred[2] + sred[3]);
         }
     }
 }
 
 inline int blur44_tiles(int n, int t) { return (n > t && n % t == 1) ? n / t : (int)te::cdiv(n, t); }     // the +1 rule
 
-template <bool AG>
+template <int AG>
 void launch_blur44(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s, const float* ref,
                    float* partial) {
     FirParams q = p;
@@ -463,13 +511,34 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
     TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_actgrad_f32: too many planes");
     TE_REQUIRE((int64_t)in_h * in_w * 4 < 0x7FFFFFFF, TE_ERR_UNSUPPORTED, "te_blur_actgrad_f32: plane too large");
     if (in_w >= 4) {
-        launch_blur44<true>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
+        launch_blur44<1>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
     } else {
         const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
         dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(major, tiles));
         fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
     }
     return te::launch_status("te_blur_actgrad_f32");
+}
+
+extern "C" int te_blur_gradact_f32(float* gx, float* partial, const float* g, const float* ref, const float* k, int64_t major,
+                                   int in_h, int in_w, int kh, int kw, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                   float alpha, float scale, te_stream_t stream_) {
+    TE_REQUIRE(gx && partial && g && ref && k, TE_ERR_NULL, "te_blur_gradact_f32: NULL pointer");
+    TE_REQUIRE(major >= 0 && in_h > 0 && in_w >= 4, TE_ERR_SHAPE, "te_blur_gradact_f32: bad dims (in_w >= 4)");
+    TE_REQUIRE(kh == 4 && kw == 4, TE_ERR_UNSUPPORTED, "te_blur_gradact_f32: 4x4 taps only");
+    FirParams p{};
+    p.in_h = in_h; p.in_w = in_w;
+    p.out_h = in_h + pad_y0 + pad_y1 - kh + 1;
+    p.out_w = in_w + pad_x0 + pad_x1 - kw + 1;
+    TE_REQUIRE(p.out_h > 0 && p.out_w > 0, TE_ERR_SHAPE, "te_blur_gradact_f32: empty output");
+    p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+    p.up_x = p.up_y = p.down_x = p.down_y = 1; p.minor = 1; p.major = major;
+    p.size_b = 1; p.act = 0; p.alpha = alpha; p.scale = scale;
+    if (major == 0) return 0;
+    TE_REQUIRE(major <= 0x7FFFFFFF / 4, TE_ERR_SHAPE, "te_blur_gradact_f32: too many planes");
+    TE_REQUIRE((int64_t)in_h * in_w * 4 < 0x7FFFFFFF, TE_ERR_UNSUPPORTED, "te_blur_gradact_f32: plane too large");
+    launch_blur44<2>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
+    return te::launch_status("te_blur_gradact_f32");
 }
 
 // half / double (the reference dispatches its kernel over AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:57-58,
@@ -560,7 +629,7 @@ extern "C" int te_upfirdn2d_f32(float* out, const float* x, const float* k, int6
     hipStream_t s = (hipStream_t)stream_;
     const bool sq = (up_x == up_y) && (down_x == down_y) && minor == 1;
     if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 1 && in_w >= 4 && (int64_t)in_h * in_w * 4 < 0x7FFFFFFF)
-        launch_blur44<false>(out, x, k, b, p, s, nullptr, nullptr);
+        launch_blur44<0>(out, x, k, b, p, s, nullptr, nullptr);
     else if (sq && kh == 4 && kw == 4 && up_x == 2 && down_x == 1) launch_tile<2, 1, 4, 4>(out, x, k, b, p, s);
     else if (sq && kh == 4 && kw == 4 && up_x == 1 && down_x == 2) launch_tile<1, 2, 4, 4>(out, x, k, b, p, s);
     else {

@@ -31,6 +31,7 @@ from .op.fir_act import blur_bias_act
 from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused
 from .op.modconv import modconv, _STATE as _modconv_state
+from .op.resblock import resblock
 from .op.stddev import minibatch_stddev
 from .op.style import demod
 from .op.token_mlp import token_mlp
@@ -108,7 +109,7 @@ class EqualConv2d(nn.Module):                                                   
         `presampled` (ConvLayer, 1x1 stride 2 only): the caller already kept every second row / column.
         `gain` (ResBlock): constant output factor folded into the weights (no activation) or the leaky-ReLU gain.
         The four configurations the discriminator uses run on the MI355X convolution kernels (same family as the
-        generator, no modulation); anything else falls back to the library convolution."""
+        generator, no modulation); anything else raises (no library fallback)."""
         w, ws = self.weight, self.scale
         k, cfg = self.weight.shape[2], (self.weight.shape[2], self.stride, self.padding)
         act = act_bias is not None
@@ -130,10 +131,10 @@ class EqualConv2d(nn.Module):                                                   
             if cfg == (1, 2, 0):
                 x = input if presampled else input[:, :, ::2, ::2].contiguous()
                 return modconv(x, w, None, None, bias, act, '1x1', ws)
-        if presampled:
-            raise RuntimeError('EqualConv2d(presampled=True) is only meaningful for the 1x1 stride-2 configuration on the GPU')
-        out = F.conv2d(input, w * ws, bias=self.bias, stride=self.stride, padding=self.padding)
-        return fused_leaky_relu(out, act_bias, 0.2, math.sqrt(2) if act is True else act) if act else out
+        # no library-convolution fallback: a configuration without a kernel fails loudly, like every other op of this path
+        raise RuntimeError(f'te_hip: EqualConv2d(kernel {k}, stride {self.stride}, padding {self.padding}) on {input.dtype} '
+                           f'{input.device} {tuple(input.shape)} has no MI355X kernel (covered: 3x3 s1 p1, 1x1 s1 p0, 3x3 s2 p0 on '
+                           f'odd sizes, 1x1 s2 p0; fp32 on the GPU; there is no CPU / library path)')
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},'
@@ -515,9 +516,30 @@ class ResBlock(nn.Module):                                                      
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, blur_kernel=blur_kernel, bias=False,
                               activate=False)
 
+    def _standard(self):
+        """the reference's structure (conv3x3+lrelu; blur, conv3x3 s2 + lrelu; blur, conv1x1 s2), which the fused node covers"""
+        def act_ok(a):
+            return (isinstance(a, FusedLeakyReLU) and a.bias is not None and a.negative_slope == 0.2
+                    and abs(a.scale - 2 ** 0.5) < 1e-12)
+        c1, c2, sk = list(self.conv1), list(self.conv2), list(self.skip)
+        return (len(c1) == 2 and isinstance(c1[0], EqualConv2d) and c1[0].bias is None and act_ok(c1[1])
+                and (c1[0].weight.shape[2], c1[0].stride, c1[0].padding) == (3, 1, 1)
+                and len(c2) == 3 and isinstance(c2[0], Blur) and isinstance(c2[1], EqualConv2d) and c2[1].bias is None
+                and act_ok(c2[2]) and (c2[1].weight.shape[2], c2[1].stride, c2[1].padding) == (3, 2, 0)
+                and len(sk) == 2 and isinstance(sk[0], Blur) and isinstance(sk[1], EqualConv2d) and sk[1].bias is None
+                and (sk[1].weight.shape[2], sk[1].stride, sk[1].padding) == (1, 2, 0)
+                and tuple(c2[0].kernel.shape) == (4, 4) and tuple(sk[0].kernel.shape) == (4, 4))
+
     def forward(self, input):
         # (conv2 + skip) / sqrt(2) (:796) with the constant folded into the two branches' last convolutions
         g = 1 / math.sqrt(2)
+        if (input.is_cuda and input.dtype == torch.float32 and not _modconv_state['second_order'] and input.shape[2] >= 8
+                and input.shape[3] >= 8 and input.shape[2] % 2 == 0 and input.shape[3] % 2 == 0 and self._standard()):
+            # the whole block as one autograd node (op/resblock.py): sums in convolution epilogues, conv1's activation
+            # gradient in the adjoint blur
+            c1, c2, sk = self.conv1, self.conv2, self.skip
+            return resblock(input, c1[0].weight, c1[1].bias, c2[1].weight, c2[2].bias, sk[1].weight, c2[0].kernel, sk[0].kernel,
+                            c1[0].scale, c2[1].scale, sk[1].scale, c2[0].pad, sk[0].pad, g)
         return self.conv2(self.conv1(input), gain=g) + self.skip(input, gain=g)
 
 

@@ -3,8 +3,9 @@
 Reference: EqualLinear.forward, model_spatial_query.py:213-221 (F.linear(input, weight * scale, bias * lr_mul), optional
 fused leaky-ReLU) and the residual / GELU around it in AttentionBlock.forward (:920-936).  alpha = scale, beta = lr_mul,
 so the parameters are consumed as stored (no `weight * scale` / `bias * lr_mul` launches).  Backward: dx = alpha g W and
-dW = alpha g^T x on the same kernel, db = beta * sum(g); a recorded backward (create_graph) goes through the
-equivalent torch expression.
+dW = alpha g^T x on the same kernel, db = beta * sum(g); a recorded backward (create_graph) goes through `_closed_expr`:
+the GEMM as a trio of te_small_gemm launches closed under differentiation (no library GEMM), bias / activation through the
+twice-differentiable K1 op (leaky-ReLU) or torch's elementwise GELU.
 """
 import math
 
@@ -13,6 +14,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
+from .modconv import _STATE as _modconv_state
 
 _ACT = {None: 0, 'gelu': 1, 'lrelu': 3}
 MAX_K = 1024          # widest reduction of the single-pass kernel; beyond it the split-K form (discriminator's 8192-wide linear)
@@ -32,6 +34,84 @@ def _torch_expr(x, weight, bias, alpha, beta, act, residual):
         y = F.gelu(y)
     elif act == 'lrelu':
         y = F.leaky_relu(y, 0.2) * math.sqrt(2)
+    return y if residual is None else y + residual
+
+
+def _gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha):
+    """alpha * A[I,K] B[K,J] through the strided small-GEMM kernel (split-K form for wide reductions)"""
+    if K > MAX_K:
+        S = _ksplit(K)
+        if not S:
+            raise RuntimeError(f'te_hip: reduction of {K} does not split into chunks of <= {MAX_K} that are multiples of 8')
+        return _lib.small_gemm_splitk(I, J, K, S, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
+    return _lib.small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
+
+
+# The bilinear map y = alpha * x W^T as a trio closed under differentiation (each one's backward is the other two), like the
+# convolution trio of op/modconv.py: whatever is built from it differentiates to any order on te_small_gemm_f32 alone.  The
+# recorded backward of every EqualLinear (path-length regulariser: the 20 style modulations; `--spatial_regu`: the mapping
+# and attention stacks) goes through it instead of F.linear / torch.mm (library GEMMs).
+class _LinFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, alpha):                     # x [R,K], w [N,K] -> [R,N]
+        x, w = x.contiguous(), w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.alpha = alpha
+        return _gemm(x.shape[0], w.shape[0], w.shape[1], x, x.stride(0), 1, w, 1, w.shape[1], alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = _LinDx.apply(gy, w, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = _LinDw.apply(gy, x, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class _LinDx(Function):
+    @staticmethod
+    def forward(ctx, g, w, alpha):                     # g [R,N], w [N,K] -> alpha g W  [R,K]
+        g, w = g.contiguous(), w.contiguous()
+        ctx.save_for_backward(g, w)
+        ctx.alpha = alpha
+        return _gemm(g.shape[0], w.shape[1], w.shape[0], g, g.stride(0), 1, w, w.shape[1], 1, alpha)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, w = ctx.saved_tensors
+        g_g = _LinFwd.apply(ggx, w, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_w = _LinDw.apply(g, ggx, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return g_g, g_w, None
+
+
+class _LinDw(Function):
+    @staticmethod
+    def forward(ctx, g, x, alpha):                     # g [R,N], x [R,K] -> alpha g^T x  [N,K]
+        g, x = g.contiguous(), x.contiguous()
+        ctx.save_for_backward(g, x)
+        ctx.alpha = alpha
+        return _gemm(g.shape[1], x.shape[1], g.shape[0], g, 1, g.shape[1], x, x.shape[1], 1, alpha)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        g, x = ctx.saved_tensors
+        g_g = _LinFwd.apply(x, ggw, ctx.alpha) if ctx.needs_input_grad[0] else None
+        g_x = _LinDx.apply(g, ggw, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return g_g, g_x, None
+
+
+def _closed_expr(x, weight, bias, alpha, beta, act, residual):
+    """the same function as the fused launch, built from any-order differentiable pieces that run on our kernels"""
+    N, K = weight.shape
+    y = _LinFwd.apply(x.reshape(-1, K), weight, alpha).reshape(*x.shape[:-1], N)
+    if act == 'lrelu':
+        from .fused_act import fused_leaky_relu
+        y2 = y.reshape(-1, N)
+        y = fused_leaky_relu(y2, None if bias is None else (bias * beta if beta != 1.0 else bias)).reshape(y.shape)
+    else:
+        if bias is not None:
+            y = y + (bias * beta if beta != 1.0 else bias)
+        if act == 'gelu':
+            y = F.gelu(y)
     return y if residual is None else y + residual
 
 
@@ -66,7 +146,7 @@ class _Linear(Function):
         if torch.is_grad_enabled():
             with torch.enable_grad():
                 al = [None if t is None else t.view_as(t) for t in (x, weight, bias, residual)]
-                y = _torch_expr(al[0], al[1], al[2], alpha, beta, act, al[3])
+                y = _closed_expr(al[0], al[1], al[2], alpha, beta, act, al[3])
                 ins = [t for t, n in zip(al, need[:4]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, gy, create_graph=True, allow_unused=True))
             return tuple(next(gs) if (n and t is not None) else None for t, n in zip(al, need[:4])) + (None, None, None)
@@ -100,8 +180,12 @@ class _Linear(Function):
 
 def linear_fused(x, weight, bias=None, alpha=1.0, beta=1.0, act=None, residual=None):
     """act in (None, 'gelu', 'lrelu'); reductions wider than MAX_K run the split-K form of the same kernel."""
-    if (weight.shape[1] > MAX_K and not _ksplit(weight.shape[1])) or not (x.is_cuda and x.dtype == torch.float32):
-        if not x.is_cuda:
-            raise RuntimeError('te_hip: expected a contiguous fp32 tensor on the GPU (no CPU path exists)')
-        return _torch_expr(x, weight, bias, alpha, beta, act, residual)
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError(f'te_hip: expected an fp32 tensor on the GPU, got {x.dtype} {x.device} (no CPU / library path exists)')
+    if weight.shape[1] > MAX_K and not _ksplit(weight.shape[1]):
+        raise RuntimeError(f'te_hip: linear layer with {weight.shape[1]} inputs: reductions wider than {MAX_K} must split into '
+                           f'chunks of <= {MAX_K} that are multiples of 8 (no library fallback)')
+    if _modconv_state.second_order and torch.is_grad_enabled():
+        # the caller announced a create_graph backward (regulariser steps): build the differentiable form right away
+        return _closed_expr(x, weight, bias, alpha, beta, act, residual)
     return _Linear.apply(x, weight, bias, residual, alpha, beta, act)

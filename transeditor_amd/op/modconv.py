@@ -35,32 +35,82 @@ from .fused_act import fused_leaky_relu
 
 # Hints for the regulariser steps (R1, path length), which differentiate twice.  Both are optional: without them the
 # fused Function recomputes its forward through the differentiable pieces when its backward turns out to be recorded.
-_STATE = {'second_order': False, 'skip_w': False}
+#
+# Threading: forward passes may run concurrently from several Python threads (the reference's metrics wrap the generator in
+# nn.DataParallel; te_hip.h promises thread-safe entry points), so `second_order` and the frozen-weight cache are
+# THREAD-LOCAL.  `skip_w` cannot be: it is read inside backward functions, which the autograd engine runs on its own
+# per-device thread.  It therefore lives on a small token object (`_Graph`) that every `second_order()` context creates and
+# every node built inside it keeps (`ctx.graph`); `no_weight_grads()` flips the flag on the calling thread's most recent
+# token (and on the process-wide default token that nodes built outside any `second_order()` context share).
+import threading
+
+
+class _Graph:
+    __slots__ = ('skip_w',)
+
+    def __init__(self):
+        self.skip_w = False
+
+
+_DEFAULT_GRAPH = _Graph()
+
+
+class _Local(threading.local):
+    """per-thread state with dict-style access (`_STATE['second_order']`); every thread starts from the defaults"""
+
+    def __init__(self):
+        self.second_order = False
+        self.graph = _DEFAULT_GRAPH          # token of the current / most recent second_order() context of this thread
+        self.frozen_on = False
+        self.frozen_cache = None
+
+    def __getitem__(self, k):
+        if k == 'skip_w':
+            return self.graph.skip_w or _DEFAULT_GRAPH.skip_w
+        return getattr(self, k)
+
+    def __eq__(self, other):                 # (tests compare against a plain dict)
+        return {'second_order': self.second_order, 'skip_w': self['skip_w']} == other
+
+
+_STATE = _Local()
+
+
+def current_graph():
+    """token the nodes created right now belong to (see the threading note above)"""
+    return _STATE.graph if _STATE.second_order else _DEFAULT_GRAPH
 
 
 @contextlib.contextmanager
 def second_order():
     """Forward passes inside this context are built from the any-order differentiable pieces right away (the caller knows
     a create_graph backward follows), which saves the forward recomputation inside the recorded backward."""
-    old = _STATE['second_order']
-    _STATE['second_order'] = True
+    old = (_STATE.second_order, _STATE.graph)
+    _STATE.second_order, _STATE.graph = True, _Graph()
     try:
-        yield
+        yield _STATE.graph
     finally:
-        _STATE['second_order'] = old
+        _STATE.second_order = old[0]         # (the token stays current for the no_weight_grads() that follows the forward)
+        if old[0]:
+            _STATE.graph = old[1]
 
 
 @contextlib.contextmanager
 def no_weight_grads():
     """Around `autograd.grad(..., inputs=<activations / latents>, create_graph=True)`: the first-order weight gradients
     of the convolutions are not among the requested inputs, so their correlation passes are skipped (autograd cannot tell
-    a Python Function which of its outputs are consumed).  Do NOT use around a backward that accumulates into weights."""
-    old = _STATE['skip_w']
-    _STATE['skip_w'] = True
+    a Python Function which of its outputs are consumed).  Do NOT use around a backward that accumulates into weights.
+    Applies to the graph built by this thread's most recent `second_order()` forward and to nodes built outside any such
+    context (those share one process-wide token: hint-less double backward is not meant to run concurrently)."""
+    toks = {id(t): t for t in (_STATE.graph, _DEFAULT_GRAPH)}.values()
+    old = [(t, t.skip_w) for t in toks]
+    for t in toks:
+        t.skip_w = True
     try:
         yield
     finally:
-        _STATE['skip_w'] = old
+        for t, o in old:
+            t.skip_w = o
 
 
 # Frozen-weight cache (inference-only pipeline, SURVEY §8f.3): inside `frozen_weights()` a forward that needs no gradient
@@ -68,29 +118,27 @@ def no_weight_grads():
 # the [Co,Ci,k,k] parameter on every call.  Opt-in because weights can be rewritten behind autograd's back (the reference's
 # accumulate() goes through `.data`, train_spatial_query.py:60-61, which does not touch the version counter): whoever opens
 # the context promises the weights stay put (inference.GeneratorSampler); an entry is still re-validated against the
-# parameter's version counter and storage address.
-_FROZEN = {'on': False, 'cache': None}
-
-
+# parameter's version counter and storage address.  Thread-local: a sampler in one thread does not switch the training
+# forward of another thread to cached weights.
 @contextlib.contextmanager
 def frozen_weights(cache):
     """`cache`: a dict owned by the caller (lives as long as the weights it describes)."""
-    old = (_FROZEN['on'], _FROZEN['cache'])
-    _FROZEN['on'], _FROZEN['cache'] = True, cache
+    old = (_STATE.frozen_on, _STATE.frozen_cache)
+    _STATE.frozen_on, _STATE.frozen_cache = True, cache
     try:
         yield
     finally:
-        _FROZEN['on'], _FROZEN['cache'] = old
+        _STATE.frozen_on, _STATE.frozen_cache = old
 
 
 def _frozen_entry(w, kind, wscale, want_wsq):
     base = w._base if w._base is not None else w
     key = (id(base), w.data_ptr(), tuple(w.shape), kind, float(wscale))
     stamp = (base._version, base.data_ptr())
-    ent = _FROZEN['cache'].get(key)
+    ent = _STATE.frozen_cache.get(key)
     if ent is None or ent['stamp'] != stamp:
         ent = {'stamp': stamp, 'wp': _lib.conv_pack(w, _lib.PACK_FWD, wscale), 'wsq': None, 'keep': base}
-        _FROZEN['cache'][key] = ent
+        _STATE.frozen_cache[key] = ent
     if want_wsq and ent['wsq'] is None:
         w3 = w.reshape(w.shape[0], w.shape[1], -1)
         ent['wsq'] = (w3 * wscale).square().sum(dim=2).contiguous()
@@ -181,65 +229,80 @@ def _slab_sum(slabs, kind):
     return gw.transpose(0, 1) if kind == 'down' else gw
 
 
+def _wgrad_plain(gy, x, kind, ksize, wscale):
+    """wscale * sum of the correlation slabs -> [Co, Ci, k, k] (te_wgrad_reduce_f32 without modulation; 'down' slabs come
+    transposed and go through the framework's reduction)"""
+    slabs = _wgrad_raw(gy, x, kind)
+    Co, Ci = gy.shape[1], x.shape[1]
+    if kind == 'down':
+        gw = _slab_sum(slabs, kind)
+        gw = gw * wscale if wscale != 1.0 else gw
+    else:
+        # (the reducer reads a weight operand only for the style / demodulation gradients, which are not asked for here)
+        gw, _, _ = _lib.wgrad_reduce(slabs, slabs[0, 0], wscale, None, None, want_w=True)
+    return gw.reshape(Co, Ci, ksize, ksize)
+
+
+# The plain convolution y = conv(x, wscale * w) and its two gradients: a trio closed under differentiation (each one's
+# backward is the other two, with the same constant wscale), so anything built on it differentiates to any order.
 class _ConvFwd(Function):
     @staticmethod
-    def forward(ctx, x, w, kind):
+    def forward(ctx, x, w, kind, wscale):
         ctx.save_for_backward(x, w)
-        ctx.kind = kind
-        return _fwd_raw(x, w, kind)
+        ctx.kind, ctx.wscale = kind, wscale
+        ctx.graph = current_graph()
+        return _fwd_raw(x, w, kind, wscale=wscale)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = _ConvDgrad.apply(gy, w, ctx.kind) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2]) if (ctx.needs_input_grad[1] and not _STATE['skip_w']) else None
-        return gx, gw, None
+        skip_w = ctx.graph.skip_w or _DEFAULT_GRAPH.skip_w
+        gx = _ConvDgrad.apply(gy, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2], ctx.wscale) if (ctx.needs_input_grad[1] and not skip_w) else None
+        return gx, gw, None, None
 
 
 class _ConvDgrad(Function):
     @staticmethod
-    def forward(ctx, gy, w, kind):
+    def forward(ctx, gy, w, kind, wscale):
         ctx.save_for_backward(gy, w)
-        ctx.kind = kind
-        return _dgrad_raw(gy, w, kind)
+        ctx.kind, ctx.wscale = kind, wscale
+        return _dgrad_raw(gy, w, kind, wscale=wscale)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
-        g_gy = _ConvFwd.apply(ggx, w, ctx.kind) if ctx.needs_input_grad[0] else None
-        g_w = _ConvWgrad.apply(gy, ggx, ctx.kind, w.shape[2]) if ctx.needs_input_grad[1] else None
-        return g_gy, g_w, None
+        g_gy = _ConvFwd.apply(ggx, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+        g_w = _ConvWgrad.apply(gy, ggx, ctx.kind, w.shape[2], ctx.wscale) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None
 
 
 class _ConvWgrad(Function):
     @staticmethod
-    def forward(ctx, gy, x, kind, ksize):
+    def forward(ctx, gy, x, kind, ksize, wscale):
         ctx.save_for_backward(gy, x)
-        ctx.kind = kind
-        slabs = _wgrad_raw(gy, x, kind)
-        Co, Ci = gy.shape[1], x.shape[1]
-        return _slab_sum(slabs, kind).reshape(Co, Ci, ksize, ksize)
+        ctx.kind, ctx.wscale = kind, wscale
+        return _wgrad_plain(gy, x, kind, ksize, wscale)
 
     @staticmethod
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
-        g_gy = _ConvFwd.apply(x, ggw, ctx.kind) if ctx.needs_input_grad[0] else None
-        g_x = _ConvDgrad.apply(gy, ggw, ctx.kind) if ctx.needs_input_grad[1] else None
-        return g_gy, g_x, None, None
+        g_gy = _ConvFwd.apply(x, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+        g_x = _ConvDgrad.apply(gy, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[1] else None
+        return g_gy, g_x, None, None, None
 
 
-def conv_core(x, w, kind='3x3'):
-    """Plain convolution y = conv(x, w) (w [Co,Ci,k,k]), differentiable to any order."""
-    return _ConvFwd.apply(x, w, kind)
+def conv_core(x, w, kind='3x3', wscale=1.0):
+    """Plain convolution y = conv(x, wscale * w) (w [Co,Ci,k,k]), differentiable to any order."""
+    return _ConvFwd.apply(x, w, kind, float(wscale))
 
 
 def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
-    """The same function as the fused kernel, built from any-order differentiable pieces."""
-    if wscale != 1.0:
-        w = w * wscale
+    """The same function as the fused kernel, built from any-order differentiable pieces (the equalised-lr constant rides
+    in the weight packing of the trio: no `w * wscale` pass, no scaling pass for its gradient)."""
     if isc is not None:
         x = chan_scale(x, isc)
-    y = conv_core(x, w, kind)
+    y = conv_core(x, w, kind, wscale)
     if osc is not None:
         y = chan_scale(y, osc)
     if act:
@@ -293,7 +356,7 @@ class _ModConvFused(Function):
                     al[3] = _demod(al[1], al[2], wscale, ctx.demod[0])
                     need = tuple(need[:3]) + (False,) + tuple(need[4:])
                 y = _composite(al[0], al[1], al[2], al[3], al[4], act, kind, wscale)
-                if _STATE['skip_w']:
+                if _DEFAULT_GRAPH.skip_w:        # (a node of the fused path was built outside second_order(): default token)
                     need = (need[0], False) + tuple(need[2:])
                 ins = [t for t, n in zip(al, need[:5]) if n and t is not None]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
@@ -344,13 +407,13 @@ def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1
             raise RuntimeError('modconv: demod_eps needs isc and excludes an explicit osc')
         from .style import demod as _demod
         osc, demod_eps = _demod(w, isc, float(wscale), demod_eps), None      # shapes the demod kernels do not cover
-    if _STATE['second_order'] and torch.is_grad_enabled():
+    if _STATE.second_order and torch.is_grad_enabled():
         if demod_eps is not None:
             from .style import demod as _demod
             osc = _demod(w, isc, float(wscale), demod_eps)
         return _composite(x, w, isc, osc, bias, act, kind, float(wscale))
     isc = isc.contiguous() if isc is not None else None
     osc = osc.contiguous() if osc is not None else None
-    if _FROZEN['on'] and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, isc, osc, bias))):
+    if _STATE.frozen_on and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, isc, osc, bias))):
         return _modconv_frozen(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
     return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
