@@ -179,6 +179,12 @@ int te_rgb_fwd_f32(float* out, const float* x, const float* w, const float* isc,
                    int K, int HW, te_stream_t stream);
 int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const float* isc, float wscale, int B, int K, int HW,
                      te_stream_t stream);
+/* The same streaming form as the FORWARD of a 1x1 convolution from 3 channels (the discriminator's from-RGB stem,
+ * ConvLayer(3, C, 1), model_spatial_query.py:815): out[b,k,p] = act(wscale * sum_o w[o,k] x3[b,o,p] + bias[k]),
+ * w [3,K] (the [K,3] model weight transposed), bias [K] or NULL, act as te_conv_f32.  Its data gradient is te_rgb_fwd_f32,
+ * its weight gradient te_rgb_wgrad_f32 with the two operands exchanged. */
+int te_rgb_expand_f32(float* out, const float* x3, const float* w, const float* bias, int act, float wscale, int B, int K,
+                      int HW, te_stream_t stream);
 int te_rgb_wgrad_slab_count(int B, int K, int HW);
 int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream);
 

@@ -131,3 +131,30 @@ def test_blur_gradact_kernel(C, H, B):
     gx, gb = _lib.blur_gradact(g.to(DEV), y.to(DEV), torch.flip(k, [0, 1]).contiguous().to(DEV), (1, 1, 1, 1), 0.2, math.sqrt(2))
     assert rel_err(gx, ref) < 1e-5
     assert rel_err(gb, ref.sum(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('C,H,B', [(128, 64, 2), (64, 32, 3), (512, 8, 2)])
+def test_from_rgb_stem_streaming_path(C, H, B):
+    """ConvLayer(3, C, 1) (the discriminator's first layer, model_spatial_query.py:815) on the streaming kernels
+    (te_rgb_expand_f32 forward, te_rgb_fwd_f32 data gradient, te_rgb_wgrad_f32 weight gradient) vs the CPU oracle."""
+    from transeditor_amd.model_spatial_query import ConvLayer
+    layer = ConvLayer(3, C, 1)
+    sd = layer.state_dict()
+    synth.fill_state_dict(sd, 17)
+    sd['1.bias'].copy_(0.3 * synth.normal((C,), f'stem.b.{C}'))
+    layer.load_state_dict(sd)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = synth.normal((B, 3, H, H), f'stem.x.{H}')
+    gy = synth.normal((B, C, H, H), f'stem.g.{C}.{H}')
+    xc = x.clone().requires_grad_(True)
+    ref = O.conv_layer({'s.0.weight': P['0.weight'], 's.1.bias': P['1.bias']}, 's', xc, 1)
+    gy = gy * (ref.detach().abs() > 1e-4)                      # no upstream gradient at the leaky-ReLU kink
+    gref = torch.autograd.grad((ref * gy).sum(), [xc, P['0.weight'], P['1.bias']])
+    layer = layer.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = layer(xd)
+    assert rel_err(out, ref) < 1e-5
+    params = dict(layer.named_parameters())
+    got = torch.autograd.grad((out * gy.to(DEV)).sum(), [xd, params['0.weight'], params['1.bias']])
+    for n, a, b in zip(('dx', 'dW', 'db'), got, gref):
+        assert rel_l2(a, b) < 2e-5 and rel_err(a, b) < 2e-4, n

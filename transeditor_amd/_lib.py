@@ -42,6 +42,7 @@ _SIGNATURES = {
     'te_rgb_supported': (C.c_int, [_I, _I, _I]),
     'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    'te_rgb_expand_f32': (C.c_int, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
     'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'te_blur_actgrad_tiles': (C.c_int, [_I] * 8),
@@ -345,6 +346,17 @@ def rgb_dgrad(g, w, isc, K, wscale=1.0):
     _check(lib().te_rgb_dgrad_f32(_ptr(gx), _ptr(g), _ptr(w.contiguous()), _ptr(isc), wscale, B, K, H * W, _stream()),
            'te_rgb_dgrad_f32')
     return gx
+
+
+def rgb_expand(x3, w3k, bias, act, wscale=1.0):
+    """from-RGB stem: x3 [B,3,H,W], w3k [3,K] -> act(wscale * sum_o w3k[o,k] x3[b,o] + bias[k])  [B,K,H,W]"""
+    x3 = x3.contiguous()
+    B, _, H, W = x3.shape
+    K = w3k.shape[1]
+    out = torch.empty(B, K, H, W, device=x3.device, dtype=x3.dtype)
+    _check(lib().te_rgb_expand_f32(_ptr(out), _ptr(x3), _ptr(w3k.contiguous()), _ptr(bias), act, wscale, B, K, H * W, _stream()),
+           'te_rgb_expand_f32')
+    return out
 
 
 def rgb_wgrad_slabs(g, x):

@@ -47,9 +47,12 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(float* __restrict__ out, c
     }
 }
 
+// (also the forward of the discriminator's from-RGB stem, a 1x1 convolution FROM 3 channels: `bias` [K] and the scaled
+// leaky-ReLU `act` (0 none, 3 gain sqrt(2), 4 gain 1) ride in the epilogue there)
 __global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, const float* __restrict__ g,
                                                         const float* __restrict__ w, const float* __restrict__ isc,
-                                                        float wscale, int K, int HW) {
+                                                        float wscale, int K, int HW, const float* __restrict__ bias = nullptr,
+                                                        int act = 0) {
     __shared__ float ws[NOUT][KMAX];
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int k = tid; k < K; k += 256) {
@@ -65,14 +68,20 @@ __global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, 
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) gv[o] = reinterpret_cast<const float4*>(g + ((size_t)b * NOUT + o) * HW)[p4];
     float4* op = reinterpret_cast<float4*>(gx + (size_t)b * K * HW) + p4;
+    const float gain = act == 3 ? 1.4142135623730951f : 1.f;
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
         const float c0 = ws[0][k], c1 = ws[1][k], c2 = ws[2][k];
+        const float bb = bias ? bias[k] : 0.f;
         float4 r;
-        r.x = c0 * gv[0].x + c1 * gv[1].x + c2 * gv[2].x;
-        r.y = c0 * gv[0].y + c1 * gv[1].y + c2 * gv[2].y;
-        r.z = c0 * gv[0].z + c1 * gv[1].z + c2 * gv[2].z;
-        r.w = c0 * gv[0].w + c1 * gv[1].w + c2 * gv[2].w;
+        r.x = c0 * gv[0].x + c1 * gv[1].x + c2 * gv[2].x + bb;
+        r.y = c0 * gv[0].y + c1 * gv[1].y + c2 * gv[2].y + bb;
+        r.z = c0 * gv[0].z + c1 * gv[1].z + c2 * gv[2].z + bb;
+        r.w = c0 * gv[0].w + c1 * gv[1].w + c2 * gv[2].w + bb;
+        if (act >= 3) {          // block-uniform
+            r.x = (r.x > 0.f ? r.x : 0.2f * r.x) * gain; r.y = (r.y > 0.f ? r.y : 0.2f * r.y) * gain;
+            r.z = (r.z > 0.f ? r.z : 0.2f * r.z) * gain; r.w = (r.w > 0.f ? r.w : 0.2f * r.w) * gain;
+        }
         op[(size_t)k * HW4] = r;
     }
 }
@@ -160,6 +169,16 @@ extern "C" int te_rgb_dgrad_f32(float* gx, const float* g, const float* w, const
     dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
     rgb_dgrad_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, w, isc, wscale, K, HW);
     return te::launch_status("te_rgb_dgrad_f32");
+}
+
+extern "C" int te_rgb_expand_f32(float* out, const float* x3, const float* w, const float* bias, int act, float wscale, int B,
+                                 int K, int HW, te_stream_t stream_) {
+    TE_REQUIRE(out && x3 && w, TE_ERR_NULL, "te_rgb_expand_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && ok_shape(K, HW), TE_ERR_UNSUPPORTED, "te_rgb_expand_f32: need K <= 512 and H*W %% 4 == 0");
+    TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_rgb_expand_f32: act must be 0, 3 or 4");
+    dim3 grid((unsigned)te::cdiv(HW / 4, 256), (unsigned)B);
+    rgb_dgrad_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(out, x3, w, nullptr, wscale, K, HW, bias, act);
+    return te::launch_status("te_rgb_expand_f32");
 }
 
 extern "C" int te_rgb_wgrad_slab_count(int B, int K, int HW) {

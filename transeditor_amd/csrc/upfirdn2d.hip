@@ -27,7 +27,35 @@ struct FirParams {
     int size_b, act;
     float alpha, scale;
     int ext_x, ext_y;        // blur44: the last tile column / row also covers one extra output column / row
+    int tiles_x, tiles_y, zgroups;   // blur44 / fir_tile: 1-D grid, see xcd_tile()
 };
+
+// XCD-aware block -> (tile, plane group) mapping of the FIR kernels.  Consecutive workgroup ids go round-robin over the 8
+// XCDs (each with its own L2), so with a plain 3-D grid the x / y neighbours of a tile - which share its halo rows and, for
+// rows of 2H+1 floats, the partially written cache lines at its left and right edge - always sit behind a different L2 and
+// every shared line crosses the fabric twice (measured round 2: 1.38x - 1.66x the algorithmic traffic).  Here the j-th
+// block of XCD x takes tile j % T of plane group x + 8 * (j / T): all tiles of a plane run on ONE XCD at about the same
+// time and share those lines through its L2; a block then walks the planes pg, pg + zgroups, ... as before.
+#ifndef TE_FIR_XCD          // build knob for A/B measurements (tools/exp_build.py): 0 = tile-major ids, as the 3-D grid had them
+#define TE_FIR_XCD 1
+#endif
+struct TileId { int bx, by, pg; };
+__device__ __forceinline__ TileId xcd_tile(const FirParams& p) {
+    const int T = p.tiles_x * p.tiles_y;
+#if TE_FIR_XCD
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int t = j % T;
+    return TileId{t % p.tiles_x, t / p.tiles_x, xcd + 8 * (j / T)};
+#else
+    const int t = blockIdx.x % T;
+    return TileId{t % p.tiles_x, t / p.tiles_x, (int)(blockIdx.x / T)};
+#endif
+}
+inline unsigned xcd_grid(FirParams& p, int tiles_x, int tiles_y, int64_t z) {
+    p.tiles_x = tiles_x; p.tiles_y = tiles_y;
+    p.zgroups = (int)(te::cdiv(z, 8) * 8);
+    return (unsigned)((int64_t)p.zgroups * tiles_x * tiles_y);
+}
 
 template <bool AG = false>
 __device__ __forceinline__ float epilogue(float v, const float* b, int ch, const FirParams& p) {
@@ -65,12 +93,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
         for (int c = 0; c < KW; ++c) kf[a][c] = k[(KH - 1 - a) * KW + (KW - 1 - c)];
     if (threadIdx.x < KH * KW) sk[threadIdx.x] = k[KH * KW - 1 - threadIdx.x];
 
-    const int ox0 = blockIdx.x * TOW, oy0 = blockIdx.y * TOH;
+    const TileId tid3 = xcd_tile(p);
+    const int ox0 = tid3.bx * TOW, oy0 = tid3.by * TOH;
     const int mid_x0 = ox0 * DOWN + UP - 1 - p.pad_x0, mid_y0 = oy0 * DOWN + UP - 1 - p.pad_y0;
     const int ix0 = fdiv(mid_x0, UP), iy0 = fdiv(mid_y0, UP);
     const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
 
-    // A block walks several planes (blockIdx.z stride) with a register prefetch: the tile of the next plane is loaded
+    // A block walks several planes (plane-group stride) with a register prefetch: the tile of the next plane is loaded
     // while the current one is filtered out of LDS, so the global-load latency is paid once per block, not per plane.
     constexpr int NLD = (TIH * TIW + 255) / 256;
     float stage[NLD];
@@ -100,13 +129,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             }
         }
     };
-    if ((int64_t)blockIdx.z < p.major) fetch(blockIdx.z);
+    if ((int64_t)tid3.pg < p.major) fetch(tid3.pg);
 
-    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+    for (int64_t mj = tid3.pg; mj < p.major; mj += p.zgroups) {
         __syncthreads();                 // the previous plane's filter pass is done with sx / sred
         if constexpr (AG) {
             float own = 0.f;
-            const bool last_y = blockIdx.y == gridDim.y - 1, last_x = blockIdx.x == gridDim.x - 1;
+            const bool last_y = tid3.by == p.tiles_y - 1, last_x = tid3.bx == p.tiles_x - 1;
 #pragma unroll
             for (int r = 0; r < NLD; ++r) {
                 const int e = threadIdx.x + 256 * r;
@@ -125,10 +154,10 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
             if (e < TIH * TIW) sx[ry * TIWP + rx] = stage[r];
         }
         __syncthreads();
-        if (mj + gridDim.z < p.major) fetch(mj + gridDim.z);       // in flight during the filter pass below
+        if (mj + p.zgroups < p.major) fetch(mj + p.zgroups);       // in flight during the filter pass below
         if constexpr (AG) {
             if (threadIdx.x == 0)
-                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                partial[(size_t)mj * (p.tiles_x * p.tiles_y) + tid3.by * p.tiles_x + tid3.bx] =
                     (sred[0] + sred[1]) + (sred[2] + sred[3]);
         }
         const int oy = oy0 + ty;
@@ -228,8 +257,9 @@ inline int64_t fir_planes_z(int64_t major, int64_t tiles) {
 template <int UP, int DOWN, int KH, int KW>
 void launch_tile(float* out, const float* x, const float* k, const float* b, const FirParams& p, hipStream_t s) {
     const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
-    dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(p.major, tiles));
-    fir_tile_kernel<UP, DOWN, KH, KW><<<grid, 256, 0, s>>>(out, x, k, b, p);
+    FirParams q = p;
+    dim3 grid(xcd_grid(q, (int)te::cdiv(p.out_w, TOW), (int)te::cdiv(p.out_h, TOH), fir_planes_z(p.major, tiles)), 1u, 1u);
+    fir_tile_kernel<UP, DOWN, KH, KW><<<grid, 256, 0, s>>>(out, x, k, b, q);
 }
 
 
@@ -272,7 +302,8 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
 #pragma unroll
         for (int c = 0; c < 4; ++c) kf[a][c] = k[(3 - a) * 4 + (3 - c)];
 
-    const int ox0 = blockIdx.x * BOW, oy0 = blockIdx.y * BOH;
+    const TileId tid3 = xcd_tile(p);
+    const int ox0 = tid3.bx * BOW, oy0 = tid3.by * BOH;
     const int ix0 = ox0 - p.pad_x0, iy0 = oy0 - p.pad_y0;      // up = down = 1: mid = o - pad, i0 = mid, taps 0..3
     const int ax0 = ix0 - D;                                    // multiple of 4 (D = ix0 & 3, the same for every tile)
     const int ty = threadIdx.x >> 4, tx = (threadIdx.x & 15) * 4;
@@ -321,13 +352,13 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         load_tile(x, mj, stage);
         if constexpr (AG) load_tile(ref, mj, rv);
     };
-    if ((int64_t)blockIdx.z < p.major) fetch(blockIdx.z);
+    if ((int64_t)tid3.pg < p.major) fetch(tid3.pg);
 
-    for (int64_t mj = blockIdx.z; mj < p.major; mj += gridDim.z) {
+    for (int64_t mj = tid3.pg; mj < p.major; mj += p.zgroups) {
         __syncthreads();                 // the previous plane's filter pass is done with sx / sred
         if constexpr (AG) {
             float own = 0.f;
-            const bool last_y = blockIdx.y == gridDim.y - 1, last_x = blockIdx.x == gridDim.x - 1;
+            const bool last_y = tid3.by == p.tiles_y - 1, last_x = tid3.bx == p.tiles_x - 1;
 #pragma unroll
             for (int r = 0; r < NLD; ++r) {
                 const int e = threadIdx.x + 256 * r;
@@ -349,10 +380,10 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         for (int r = 0; r < NLD; ++r)
             if (sh[r] >= 0) *reinterpret_cast<f32x4v*>(&sx[lds_off[r]]) = AG ? stage[r] : place(stage[r], sh[r]);
         __syncthreads();
-        if (mj + gridDim.z < p.major) fetch(mj + gridDim.z);       // in flight during the filter pass below
+        if (mj + p.zgroups < p.major) fetch(mj + p.zgroups);       // in flight during the filter pass below
         if constexpr (AG) {
             if (threadIdx.x == 0)
-                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                partial[(size_t)mj * (p.tiles_x * p.tiles_y) + tid3.by * p.tiles_x + tid3.bx] =
                     (sred[0] + sred[1]) + (sred[2] + sred[3]);
         }
         // lane (ty, tx) filters output rows oy0 + 2 ty, oy0 + 2 ty + 1 (they share 3 of their 4 input rows), columns tx..tx+3.
@@ -361,8 +392,8 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         // (EXT: compiled in only for launches that need it, the extra multiply-adds cost every lane: the kernel is bound by
         // instruction issue, not by HBM)
         constexpr int NH = EXT ? 3 : 2, NQ = EXT ? 5 : 4;
-        const bool xcol = EXT && p.ext_x && blockIdx.x == gridDim.x - 1 && tx == BOW - 4;
-        const bool xrow = EXT && p.ext_y && blockIdx.y == gridDim.y - 1 && ty == 15;
+        const bool xcol = EXT && p.ext_x && tid3.bx == p.tiles_x - 1 && tx == BOW - 4;
+        const bool xrow = EXT && p.ext_y && tid3.by == p.tiles_y - 1 && ty == 15;
         // MODE 2: the saved forward output at this lane's output positions, requested before the filter pass
         float rf[MODE == 2 ? NH : 1][MODE == 2 ? NQ : 1];
         if constexpr (MODE == 2) {
@@ -447,7 +478,7 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
             if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = own2;
             __syncthreads();             // (the barrier at the top of the loop keeps sred intact until thread 0 has read it)
             if (threadIdx.x == 0)
-                partial[(size_t)mj * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                partial[(size_t)mj * (p.tiles_x * p.tiles_y) + tid3.by * p.tiles_x + tid3.bx] =
                     (sred[0] + sred[1]) + (sred[2] + sred[3]);
         }
     }
@@ -463,7 +494,7 @@ void launch_blur44(float* out, const float* x, const float* k, const float* b, c
     q.ext_x = tx_n * BOW < p.out_w;
     q.ext_y = ty_n * BOH < p.out_h;
     const int64_t tiles = (int64_t)tx_n * ty_n;
-    dim3 grid((unsigned)tx_n, (unsigned)ty_n, (unsigned)fir_planes_z(p.major, 2 * tiles));
+    dim3 grid(xcd_grid(q, tx_n, ty_n, fir_planes_z(p.major, 2 * tiles)), 1u, 1u);
     const int d = (-p.pad_x0) & 3;
     if (q.ext_x || q.ext_y) {
         switch (d) {
@@ -514,7 +545,7 @@ extern "C" int te_blur_actgrad_f32(float* gx, float* partial, const float* g, co
         launch_blur44<1>(gx, g, k, nullptr, p, (hipStream_t)stream_, ref, partial);
     } else {
         const int64_t tiles = te::cdiv(p.out_w, TOW) * te::cdiv(p.out_h, TOH);
-        dim3 grid((unsigned)te::cdiv(p.out_w, TOW), (unsigned)te::cdiv(p.out_h, TOH), (unsigned)fir_planes_z(major, tiles));
+        dim3 grid(xcd_grid(p, (int)te::cdiv(p.out_w, TOW), (int)te::cdiv(p.out_h, TOH), fir_planes_z(major, tiles)), 1u, 1u);
         fir_tile_kernel<1, 1, 4, 4, true><<<grid, 256, 0, (hipStream_t)stream_>>>(gx, g, k, nullptr, p, ref, partial);
     }
     return te::launch_status("te_blur_actgrad_f32");

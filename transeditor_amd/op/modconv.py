@@ -330,6 +330,15 @@ class _ModConvFused(Function):
             ctx.save_for_backward(x, w, isc, osc, bias, None)
             ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
             return out
+        # from-RGB stem (1x1 FROM 3 channels, unmodulated: the discriminator's first layer, :815): write-bound, the same
+        # streaming kernels with the operands' roles exchanged instead of a 3-of-16-channels MFMA stage
+        ctx.stem = (kind == '1x1' and w.shape[1] == 3 and isc is None and osc is None
+                    and _lib.rgb_supported(3, w.shape[0], x.shape[2] * x.shape[3]))
+        if ctx.stem:
+            out = _lib.rgb_expand(x, w.reshape(w.shape[0], 3).t(), bias, _act_code(act), wscale)
+            ctx.save_for_backward(x, w, isc, osc, bias, out if act else None)
+            ctx.act, ctx.kind, ctx.wscale = act, kind, wscale
+            return out
         ctx.wp_bwd = None
         if ctx.needs_input_grad[0]:         # a backward will want dx: pack the data-gradient layout in the same launch
             out, ctx.wp_bwd = _fwd_raw(x, w, kind, isc, osc, bias, _act_code(act), wscale, with_bwd_pack=True)
@@ -368,6 +377,13 @@ class _ModConvFused(Function):
             g, g_bias = _lib.bias_act_bwd(g, out, 0.2, _act_gain(act), want_bias=bias is not None)
         elif bias is not None and need[4]:
             g_bias = g.sum(dim=(0, 2, 3))
+        if getattr(ctx, 'stem', False):
+            gx = _lib.rgb_fwd(g, w.reshape(w.shape[0], 3).t().contiguous(), None, None, wscale) if need[0] else None
+            gw = None
+            if need[1]:
+                gw = _lib.rgb_wgrad_slabs(x, g).sum(dim=(0, 1)).reshape(3, w.shape[0]).t().reshape(w.shape)
+                gw = gw * wscale if wscale != 1.0 else gw
+            return gx, gw, None, None, g_bias, None, None, None, None
         if ctx.rgb:
             gx = _lib.rgb_dgrad(g, w.reshape(w.shape[0], w.shape[1]), isc, x.shape[1], wscale) if need[0] else None
         else:
