@@ -63,6 +63,7 @@ class _Local(threading.local):
         self.graph = _DEFAULT_GRAPH          # token of the current / most recent second_order() context of this thread
         self.frozen_on = False
         self.frozen_cache = None
+        self.pack_cache = None               # dict while a packed_weights_cache() context is open on this thread
 
     def __getitem__(self, k):
         if k == 'skip_w':
@@ -131,6 +132,66 @@ def frozen_weights(cache):
         _STATE.frozen_on, _STATE.frozen_cache = old
 
 
+# Packed-weight cache for a TRAINING loop that owns every write to the weights (train_step.TrainStep): inside
+# `packed_weights_cache(d)` the packed layouts of a weight tensor are kept in `d` and reused as long as the tensor's version
+# counter and storage address are unchanged.  One iteration runs the discriminator three times and the generator twice
+# between optimiser steps (train_spatial_query.py:173-224), the regulariser steps pack the same weight once per autograd
+# node: ~45 of ~110 packing launches per iteration disappear.  Opt-in and thread-local for the same reason as the
+# frozen-weight cache: a write through `.data` does not move the version counter (FusedAdam / MultiTensorEMA do bump it).
+@contextlib.contextmanager
+def packed_weights_cache(cache):
+    old = _STATE.pack_cache
+    _STATE.pack_cache = cache
+    try:
+        yield
+    finally:
+        _STATE.pack_cache = old
+
+
+def _pack_key(w, pack_kind, wscale):
+    return (w.data_ptr(), tuple(w.shape), pack_kind, float(wscale))
+
+
+def _cacheable(w):
+    """only model parameters (or views of them) are cached: an intermediate tensor (the `ggw` of a double backward) may share
+    address, shape and version 0 with an earlier one"""
+    if _STATE.pack_cache is None:
+        return None
+    base = w._base if w._base is not None else w
+    return base if isinstance(base, torch.nn.Parameter) else None
+
+
+def packed(w, pack_kind, wscale=1.0):
+    """packed layout `pack_kind` of w (through the cache when one is open)"""
+    base = _cacheable(w)
+    if base is None:
+        return _lib.conv_pack(w, pack_kind, wscale)
+    cache, key = _STATE.pack_cache, _pack_key(w, pack_kind, wscale)
+    ent = cache.get(key)
+    if ent is None or ent[0] != w._version or ent[2] is not base:
+        ent = cache[key] = (w._version, _lib.conv_pack(w, pack_kind, wscale), base)      # (keeps the storage alive: the key stays valid)
+    return ent[1]
+
+
+def packed2(w, kind_a, kind_b, wscale=1.0):
+    """two layouts of w; one launch when both have to be produced"""
+    base = _cacheable(w)
+    if base is None:
+        return _lib.conv_pack2(w, kind_a, kind_b, wscale)
+    cache = _STATE.pack_cache
+    ka, kb = _pack_key(w, kind_a, wscale), _pack_key(w, kind_b, wscale)
+    ea, eb = cache.get(ka), cache.get(kb)
+    va = ea is not None and ea[0] == w._version and ea[2] is base
+    vb = eb is not None and eb[0] == w._version and eb[2] is base
+    if va and vb:
+        return ea[1], eb[1]
+    if not va and not vb:
+        wa, wb = _lib.conv_pack2(w, kind_a, kind_b, wscale)
+        cache[ka], cache[kb] = (w._version, wa, base), (w._version, wb, base)
+        return wa, wb
+    return packed(w, kind_a, wscale), packed(w, kind_b, wscale)
+
+
 def _frozen_entry(w, kind, wscale, want_wsq):
     base = w._base if w._base is not None else w
     key = (id(base), w.data_ptr(), tuple(w.shape), kind, float(wscale))
@@ -196,9 +257,14 @@ def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0, with_
     """with_bwd_pack: also return the data-gradient packing of w (one launch packs both layouts)."""
     H, W = _lowres_hw(kind, False, x)
     if with_bwd_pack:
-        wp, wpb = _lib.conv_pack2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
+        wp, wpb = packed2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
         return _lib.conv(x, wp, _KIND[kind], w.shape[0], H, W, isc, osc, bias, act), wpb
-    return _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, wscale), _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
+    if _STATE.pack_cache is not None and torch.is_grad_enabled() is False:
+        # (a no-grad forward inside a training loop: the same weights meet a backward later in the iteration)
+        wp, _ = packed2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
+    else:
+        wp = packed(w, _lib.PACK_FWD, wscale)
+    return _lib.conv(x, wp, _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
 
 
 def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
@@ -206,7 +272,7 @@ def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
     isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci]).  wp: w already packed for it."""
     H, W = _lowres_hw(kind, True, g)
     if wp is None:
-        wp = _lib.conv_pack(w, _bwd_pack_kind(kind), wscale)
+        wp = packed(w, _bwd_pack_kind(kind), wscale)
     if kind == 'up':       # adjoint of the transposed conv = strided conv
         return _lib.conv(g, wp, _lib.CONV_S2, w.shape[1], H, W, isc, osc)
     if kind == 'down':     # adjoint of the strided conv = transposed conv

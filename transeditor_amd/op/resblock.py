@@ -25,7 +25,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain
+from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, packed, packed2
 from .upfirdn2d import _geometry, flipped_taps, upfirdn2d
 
 _SQRT2 = math.sqrt(2.0)
@@ -49,9 +49,9 @@ class _ResBlock(Function):
         H, W = x.shape[2], x.shape[3]
         # conv1 (+ its data-gradient packing when dx will be asked for)
         if need[0]:
-            wp1, wp1b = _lib.conv_pack2(w1, _lib.PACK_FWD, _bwd_pack_kind('3x3'), s1)
+            wp1, wp1b = packed2(w1, _lib.PACK_FWD, _bwd_pack_kind('3x3'), s1)
         else:
-            wp1, wp1b = _lib.conv_pack(w1, _lib.PACK_FWD, s1), None
+            wp1, wp1b = packed(w1, _lib.PACK_FWD, s1), None
         y1 = _lib.conv(x, wp1, _lib.CONV_3X3, w1.shape[0], H, W, None, None, b1, 3)
         pm = (pad_main[0], pad_main[1], pad_main[0], pad_main[1])
         yb = _lib.upfirdn2d_raw(y1, k_main, (1, 1), (1, 1), pm)
@@ -59,9 +59,9 @@ class _ResBlock(Function):
             raise RuntimeError(f'resblock: blurred size {tuple(yb.shape[2:])} is not (2h+1)x(2w+1)')
         h, w_ = (yb.shape[2] - 1) // 2, (yb.shape[3] - 1) // 2
         if front:
-            wp2, wp2b = _lib.conv_pack2(w2, _lib.PACK_FWD, _bwd_pack_kind('down'), s2)
+            wp2, wp2b = packed2(w2, _lib.PACK_FWD, _bwd_pack_kind('down'), s2)
         else:
-            wp2, wp2b = _lib.conv_pack(w2, _lib.PACK_FWD, s2), None
+            wp2, wp2b = packed(w2, _lib.PACK_FWD, s2), None
         act2 = 3 if abs(_SQRT2 * gain - _SQRT2) < 1e-6 else 4
         if act2 == 4 and abs(_SQRT2 * gain - 1.0) > 1e-6:
             raise RuntimeError(f'resblock: leaky-ReLU gain {_SQRT2 * gain} is not one the kernels fuse (sqrt(2) or 1)')
@@ -71,9 +71,9 @@ class _ResBlock(Function):
         if xs.shape[2:] != y2.shape[2:]:
             raise RuntimeError(f'resblock: branch sizes differ {tuple(xs.shape[2:])} vs {tuple(y2.shape[2:])}')
         if need[0]:
-            wps, wpsb = _lib.conv_pack2(ws, _lib.PACK_FWD, _bwd_pack_kind('1x1'), ss * gain)
+            wps, wpsb = packed2(ws, _lib.PACK_FWD, _bwd_pack_kind('1x1'), ss * gain)
         else:
-            wps, wpsb = _lib.conv_pack(ws, _lib.PACK_FWD, ss * gain), None
+            wps, wpsb = packed(ws, _lib.PACK_FWD, ss * gain), None
         out = _lib.conv(xs, wps, _lib.CONV_1X1, ws.shape[0], xs.shape[2], xs.shape[3], None, None, None, 0, res=y2)
         ctx.save_for_backward(x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs)
         ctx.packs = (wp1b, wp2b, wpsb)

@@ -22,7 +22,7 @@ from torch import autograd
 from torch.nn import functional as F
 
 from .model_spatial_query import Discriminator, Generator
-from .op.modconv import no_weight_grads, second_order
+from .op.modconv import no_weight_grads, packed_weights_cache, second_order
 from .optim import FusedAdam, MultiTensorEMA
 from .utils import distributed as D
 from .utils.sample import prepare_noise_new, prepare_param
@@ -108,6 +108,7 @@ class TrainStep:
                                  betas=(0 ** d_ratio, 0.99 ** d_ratio))
         self._ema = MultiTensorEMA(self.g_ema, self.generator)
         self.sampler = sampler if sampler is not None else RandomSampler(args, device)
+        self._packs = {}
         self.mean_path_length = 0
         self.mean_path_length_avg = 0
         self.mean_spatial_path_length = 0
@@ -239,13 +240,16 @@ class TrainStep:
     def iteration(self, i, real_img):
         """One iteration `i` of the reference loop on a batch of real images already on the device."""
         a = self.args
-        self.d_step(real_img)
-        if i % a.d_reg_every == 0:
-            self.r1_step(real_img)
-        self.g_step()
-        if i % a.g_reg_every == 0:
-            self.path_step()
-        if a.spatial_regu and i % a.g_reg_every == 0:
-            self.spatial_step()
+        # every write to the weights inside this loop goes through FusedAdam / MultiTensorEMA (which move the version
+        # counters), so packed weight layouts can be reused between the optimiser steps
+        with packed_weights_cache(self._packs):
+            self.d_step(real_img)
+            if i % a.d_reg_every == 0:
+                self.r1_step(real_img)
+            self.g_step()
+            if i % a.g_reg_every == 0:
+                self.path_step()
+            if a.spatial_regu and i % a.g_reg_every == 0:
+                self.spatial_step()
         self._ema.update(self.accum)                                         # :294
         return D.reduce_loss_dict(self.loss)
