@@ -261,6 +261,10 @@ def cpu_baseline_train(size):
             v.grad = g
         g_opt.step()
 
+    # one untimed warm-up pass of the two steps that carry the iteration (first-touch cost: oneDNN primitive creation,
+    # page faults of the 0.6 GB of activations), then every sub-step timed once
+    d_step()
+    g_step()
     timed('d', d_step)
     timed('r1', r1_step)
     timed('g', g_step)
@@ -275,13 +279,22 @@ def cpu_baseline_train(size):
         t0 = time.perf_counter()
         O.generator_forward(Pg, z, p, size)
         f16 = (time.perf_counter() - t0) / 16
+    # BASELINE configs[1] on the host at the CONFIG batch: generator forward + backward, batch 16, once
+    z, p = synth.latents(16, 904)
+    t0 = time.perf_counter()
+    img = O.generator_forward(Pg, z, p, size)[0]
+    torch.autograd.grad(img.sum(), g_leaves, allow_unused=True)
+    fb16 = time.perf_counter() - t0
+    del img
     return {'value': B / it, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': f'CPU oracle (PyTorch fp32 restatement of the reference) running ONE FFHQ-{size} G+D training iteration at '
                       f'batch {B} (config batch is 16): D step {t["d"]:.2f} s, R1 step {t["r1"]:.2f} s, G step {t["g"]:.2f} s, '
                       f'path-length step (batch 1) {t["path"]:.2f} s, Adam included; iteration = D + G + R1/16 + path/4 = '
-                      f'{it:.2f} s; no warm-up pass (first-touch cost included)',
+                      f'{it:.2f} s; after one untimed warm-up pass of the D and G steps',
             'batch_scaling': {'generator_fwd_s_per_image_batch2': f2, 'generator_fwd_s_per_image_batch16': f16,
                               'note': 'per-image cost at the config batch relative to the sampled batch'},
+            'generator_fwd_bwd_batch16': {'seconds': fb16, 'images_per_sec': 16 / fb16,
+                                          'note': 'BASELINE configs[1] (generator fwd+bwd at the config batch 16) on the same cores, one pass'},
             'thread_sweep_s_generator_fwd_batch2': sweep, 'usable_threads': ncpu,
             'cpu_model': _cpu_model(), 'host_threads': os.cpu_count()}
 

@@ -20,6 +20,17 @@
  * the two ops that ARE the reference's native boundary — also exist as te_bias_act_f16 / _f64 and te_upfirdn2d_f16 / _f64
  * (plain kernels, same semantics).  Every other entry point is fp32 only: the Python wrappers raise on any other dtype
  * instead of silently casting (tests/test_gpu_generator.py::test_non_contiguous_and_wrong_dtype_inputs).
+ *
+ * Run-to-run reproducibility.  Forward results are bit-reproducible.  Fixed-order (bit-reproducible) reductions: the split-K
+ * convolution WITH a workspace (te_conv_ws_f32 / te_conv_res_f32), te_small_gemm_splitk_f32, the per-(sample, chunk)
+ * correlation slabs of te_wgrad_f32 / te_rgb_wgrad_f32, the per-tile bias-gradient partials of te_blur_actgrad_f32 /
+ * te_blur_gradact_f32, te_chan_dot_f32, the layer / pixel norm and minibatch-stddev kernels.  NOT fixed-order (hardware fp32
+ * atomic adds, library built with -munsafe-fp-atomics; same values up to summation order, i.e. relative differences of
+ * ~1e-7 per element between runs): te_conv_f32 on a split problem WITHOUT a workspace (hipMemsetAsync + atomics),
+ * te_bias_act_bwd_f32's bias gradient (one atomic per block and channel), te_wgrad_reduce_f32's style / demodulation
+ * gradients (one atomic per tile and (sample, channel)) and its weight gradient when the slab chunks of narrow layers are
+ * split over blockIdx.z, te_demod_bwd_f32 in accumulate mode.  Training gradients are therefore reproducible to ~1e-6
+ * relative, not bit-wise; tests compare those paths with tolerances, never for bit equality.
  */
 #ifndef TE_HIP_H
 #define TE_HIP_H

@@ -223,3 +223,40 @@ def test_tools_and_entry_points_compile():
     assert len(files) > 10
     for f in files:
         compile(open(f).read(), f, 'exec')
+
+
+def test_roctx_ranges_behind_env_switch():
+    """TE_ROCTX=1 wraps every tensor-level entry of _lib in a roctx range (operator names in rocprofv3 marker traces)"""
+    import subprocess
+    import sys
+    code = ("from transeditor_amd import _lib; assert _lib.ROCTX and _lib.conv.__wrapped__.__name__ == 'conv' "
+            "and _lib.upfirdn2d_raw.__wrapped__.__name__ == 'upfirdn2d_raw'; print('ok')")
+    env = dict(os.environ, TE_ROCTX='1', PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
+    from transeditor_amd import _lib
+    assert not _lib.ROCTX and not hasattr(_lib.conv, '__wrapped__')
+
+
+def test_fused_adam_loads_reference_style_optimizer_state():
+    """the reference's torch 1.7 Adam stores `step` as a python int, and torch.load(map_location=device) moves a
+    tensor `step` to the GPU; FusedAdam normalises both to a host fp32 scalar at load time (the kernel step itself is GPU-only:
+    tests/test_gpu_optim.py)."""
+    from transeditor_amd.optim import FusedAdam
+    p = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = FusedAdam(p, lr=0.002, betas=(0.0, 0.99))
+    ref = torch.optim.Adam(p, lr=0.002, betas=(0.0, 0.99))
+    for q in p:
+        q.grad = torch.randn_like(q)
+    ref.step()
+    sd = ref.state_dict()
+    for st in sd['state'].values():
+        st['step'] = 7                                   # torch 1.7 layout: python int
+    opt.load_state_dict(sd)
+    for q in p:
+        s = opt.state[q]['step']
+        assert torch.is_tensor(s) and s.device.type == 'cpu' and s.dtype == torch.float32 and float(s) == 7.0
+        assert torch.equal(opt.state[q]['exp_avg_sq'], ref.state[q]['exp_avg_sq'])
+    opt.state[p[0]]['step'] = 9                          # assigned behind the optimiser's back: normalised at the next step
+    FusedAdam._host_step(opt.state[p[0]])
+    assert float(opt.state[p[0]]['step']) == 9.0 and torch.is_tensor(opt.state[p[0]]['step'])

@@ -67,6 +67,36 @@ def test_fused_adam_matches_torch_adam(betas):
         assert float((a.detach() - b.detach()).abs().max() / a.detach().abs().max()) < 1e-6
 
 
+def test_fused_adam_steps_after_loading_reference_style_state():
+    """a `g_optim` written by the reference (torch 1.7: python-int `step`) or loaded with
+    torch.load(map_location='cuda') (tensor `step` on the GPU) must load and continue exactly like torch.optim.Adam."""
+    from transeditor_amd.optim import FusedAdam
+    shapes = [(64, 32, 3, 3), (64,), (7, 5)]
+    base, ref = _params(3, shapes), _params(3, shapes)
+    o_ref = torch.optim.Adam(ref, lr=0.0016, betas=(0.0, 0.99 ** 0.8))
+    for i, b in enumerate(ref):
+        b.grad = synth.normal(tuple(b.shape), f'optl.g{i}', 1).to(DEV)
+    o_ref.step()
+    for layout in ('int', 'cuda'):
+        sd = copy.deepcopy(o_ref.state_dict())
+        for st in sd['state'].values():
+            st['step'] = int(st['step']) if layout == 'int' else torch.tensor(float(st['step']), device=DEV)
+        ours = [torch.nn.Parameter(b.detach().clone()) for b in ref]
+        o = FusedAdam(ours, lr=0.0016, betas=(0.0, 0.99 ** 0.8))
+        o.load_state_dict(sd)
+        twin = [torch.nn.Parameter(b.detach().clone()) for b in ref]
+        o_t = torch.optim.Adam(twin, lr=0.0016, betas=(0.0, 0.99 ** 0.8))
+        o_t.load_state_dict(copy.deepcopy(o_ref.state_dict()))
+        for i, (a, b) in enumerate(zip(ours, twin)):
+            a.grad = synth.normal(tuple(a.shape), f'optl.g{i}', 2).to(DEV)
+            b.grad = a.grad.clone()
+        o.step()
+        o_t.step()
+        for a, b in zip(ours, twin):
+            assert float((a.detach() - b.detach()).abs().max() / b.detach().abs().max()) < 1e-6, layout
+        assert all(st['step'].device.type == 'cpu' and float(st['step']) == 2.0 for st in o.state.values())
+
+
 def test_multi_tensor_ema_matches_reference_formula():
     from transeditor_amd.optim import MultiTensorEMA
     from transeditor_amd.train_step import accumulate

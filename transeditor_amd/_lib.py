@@ -617,3 +617,37 @@ def chan_dot(a, b):
     out = torch.empty(a.shape[0], a.shape[1], device=a.device, dtype=a.dtype)
     _check(lib().te_chan_dot_f32(_ptr(out), _ptr(a), _ptr(b), rows, a.numel() // max(rows, 1), _stream()), 'te_chan_dot_f32')
     return out
+
+
+# --------------------------------------------------------------------------------------------- roctx ranges (SURVEY §5 tracing)
+# TE_ROCTX=1: every tensor-level wrapper above runs inside a roctx range "te:<op> <shape of its first tensor>", so a
+# `rocprofv3 --kernel-trace --marker-trace` timeline attributes kernels to operators instead of showing template names only
+# (torch.cuda.nvtx is backed by roctx on ROCm builds).  Off by default: two extra calls per launch.
+def _install_roctx():
+    import functools
+    import torch.cuda.nvtx as nvtx
+    names = ['bias_act', 'bias_act_bwd', 'upfirdn2d_raw', 'blur_actgrad', 'blur_gradact', 'conv_pack', 'conv_pack2', 'conv',
+             'wgrad_slabs', 'wgrad_reduce', 'rgb_fwd', 'rgb_dgrad', 'rgb_expand', 'rgb_wgrad_slabs', 'small_gemm',
+             'small_gemm_splitk', 'small_gemm_batched', 'small_gemm_batched_rs', 'minibatch_stddev_fwd', 'minibatch_stddev_bwd',
+             'layer_norm_fwd', 'layer_norm_bwd', 'pixel_norm_fwd', 'pixel_norm_bwd', 'demod_fwd', 'demod_from_wsq', 'demod_bwd',
+             'attn_fwd', 'attn_bwd', 'attn_stack_fwd', 'attn_stack_bwd', 'mt_adam', 'mt_ema', 'chan_scale', 'chan_dot']
+    g = globals()
+
+    def wrap(fn, name):
+        @functools.wraps(fn)
+        def run(*a, **k):
+            t = next((x for x in a if torch.is_tensor(x)), None)
+            nvtx.range_push(f'te:{name} {tuple(t.shape)}' if t is not None else f'te:{name}')
+            try:
+                return fn(*a, **k)
+            finally:
+                nvtx.range_pop()
+        return run
+    for n in names:
+        if n in g:
+            g[n] = wrap(g[n], n)
+
+
+ROCTX = os.environ.get('TE_ROCTX') == '1'
+if ROCTX:
+    _install_roctx()
