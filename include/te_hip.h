@@ -150,13 +150,15 @@ int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, 
 int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
-/* te_conv_ws_f32 with a residual epilogue: out = act(osc * conv + bias) + res, res shaped like out (may be NULL; not for
- * TE_CONV_T2).  It carries the sum of a ResBlock's two branches (model_spatial_query.py:796, forward) and the sum of the two
- * gradient branches that meet at the block's input (backward) without an extra elementwise pass.  A split launch (S > 1)
- * needs the workspace. */
+/* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):
+ *     out = ( act(osc * conv + bias) + res ) * (mask_ref > 0 ? mask_gain : 0.2 * mask_gain)
+ * res (shaped like out, may be NULL) carries the sum of a ResBlock's two branches (model_spatial_query.py:796, forward) and
+ * the sum of the two gradient branches that meet at the block's input (backward) without an extra elementwise pass;
+ * mask_ref (shaped like out, may be NULL) is the saved output of a fused bias + leaky-ReLU(0.2) * mask_gain layer whose
+ * OUTPUT this data gradient lands on: its activation gradient (fused_bias_act_kernel.cu:26-47, grad pass) in this epilogue. */
 int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
-                    const float* bias, const float* res, int act, int kind, int B, int K, int M, int H, int W,
-                    te_stream_t stream);
+                    const float* bias, const float* res, const float* mask_ref, float mask_gain, int act, int kind, int B,
+                    int K, int M, int H, int W, te_stream_t stream);
 
 /* Weight-gradient correlation, per sample and per pixel chunk ("slabs"), NO modulation applied:
  *   slab[b][s][co][ci][tap] = sum_{pixels of chunk s} g[b,co,p (+) tap] * x[b,ci,p]
@@ -198,6 +200,10 @@ int te_rgb_expand_f32(float* out, const float* x3, const float* w, const float* 
                       int HW, te_stream_t stream);
 int te_rgb_wgrad_slab_count(int B, int K, int HW);
 int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream);
+/* te_rgb_wgrad_f32 with a 4th slab row: slabs[b][c][3][k] = sum_{p in chunk c} x[b,k,p]  (slabs [B][S][4][K]).  With the
+ * operands exchanged (g = the 3-channel image, x = the gradient of the from-RGB stem's pre-activation) rows 0-2 are the stem's
+ * weight gradient and row 3 its bias gradient: one pass over the 128-channel gradient instead of two. */
+int te_rgb_wgrad_sum_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F2  attention core of the dual-space cross-attention block (reference: Attention.forward,

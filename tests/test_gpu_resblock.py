@@ -158,3 +158,40 @@ def test_from_rgb_stem_streaming_path(C, H, B):
     got = torch.autograd.grad((out * gy.to(DEV)).sum(), [xd, params['0.weight'], params['1.bias']])
     for n, a, b in zip(('dx', 'dW', 'db'), got, gref):
         assert rel_l2(a, b) < 2e-5 and rel_err(a, b) < 2e-4, n
+
+
+@pytest.mark.parametrize('frozen', [False, True])
+def test_discriminator_stem_plus_first_block_node(frozen):
+    """Discriminator(64): from-RGB layer + first ResBlock run as ONE node (stem's activation gradient in the mask stage of the
+    block's data-gradient epilogue, dW0 / db0 from one te_rgb_wgrad_sum_f32 pass).  Prediction, d/d image and every parameter
+    gradient against the CPU oracle; `frozen` = the G step (only the image gradient flows)."""
+    from transeditor_amd.model_spatial_query import Discriminator
+    Dn = Discriminator(64)
+    sd = Dn.state_dict()
+    synth.fill_state_dict(sd, 5)
+    for k in sd:
+        if k.endswith('bias'):
+            sd[k].copy_(0.2 * synth.normal(tuple(sd[k].shape), f'dst.b.{k}'))
+    Dn.load_state_dict(sd)
+    img = synth.normal((4, 3, 64, 64), 'dst.img').clamp(-1, 1)
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'kernel' not in k else v) for k, v in sd.items()}
+    names = [k for k, v in P.items() if v.requires_grad]
+    ic = img.clone().requires_grad_(True)
+    ref = O.discriminator_forward(P, ic, 64)
+    w = synth.normal((4, 1), 'dst.w')
+    gref = torch.autograd.grad((ref * w).sum(), [ic] + [P[k] for k in names])
+    Dn = Dn.to(DEV)
+    if frozen:
+        for p in Dn.parameters():
+            p.requires_grad_(False)
+    idv = img.to(DEV).requires_grad_(True)
+    assert Dn._stem_fusable(idv)
+    pred = Dn(idv)
+    assert rel_err(pred, ref) < 1e-4
+    params = dict(Dn.named_parameters())
+    ins = [idv] + ([] if frozen else [params[k] for k in names])
+    got = torch.autograd.grad((pred * w.to(DEV)).sum(), ins)
+    for n, a, b in zip(['dimg'] + names, got, gref):
+        # whole-network first-order gradients (12 activation layers deep): the north-star 1e-3 on the norm, 2e-3 in L2
+        assert abs(float(a.double().norm()) - float(b.double().norm())) <= 1e-3 * float(b.double().norm()), n
+        assert rel_l2(a, b) < 2e-3, n

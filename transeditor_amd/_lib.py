@@ -35,13 +35,14 @@ _SIGNATURES = {
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     'te_rgb_supported': (C.c_int, [_I, _I, _I]),
     'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    'te_rgb_wgrad_sum_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'te_rgb_expand_f32': (C.c_int, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
     'te_rgb_wgrad_slab_count': (C.c_int, [_I, _I, _I]),
     'te_rgb_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -302,20 +303,25 @@ def conv_out_shape(kind, B, M, H, W):
     return (B, M, H, W)
 
 
-def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0, res=None):
-    """H, W = LOW-resolution size (see te_hip.h).  x [B,K,Hin,Win].  res: residual added after the activation."""
+def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0, res=None, mask_ref=None, mask_gain=1.0):
+    """H, W = LOW-resolution size (see te_hip.h).  x [B,K,Hin,Win].  res: residual added after the activation; mask_ref:
+    leaky-ReLU gradient mask (saved output of the layer this data gradient lands on) applied last."""
     x = x.contiguous()
     B, K = x.shape[0], x.shape[1]
     out = torch.empty(conv_out_shape(kind, B, M, H, W), device=x.device, dtype=x.dtype)
     if res is not None and tuple(res.shape) != tuple(out.shape):
         raise RuntimeError(f'te_hip: residual {tuple(res.shape)} does not match the convolution output {tuple(out.shape)}')
+    if mask_ref is not None and tuple(mask_ref.shape) != tuple(out.shape):
+        raise RuntimeError(f'te_hip: mask reference {tuple(mask_ref.shape)} does not match the convolution output {tuple(out.shape)}')
     S = lib().te_conv_splitk_count(kind, B, K, M, H, W)
     if S < 1:
         raise RuntimeError(f'te_conv_splitk_count failed ({S})')
     # small images split the channel loop over the grid: per-split slabs + fixed-order sum (deterministic, graph-capturable)
     ws = torch.empty((S,) + tuple(out.shape), device=x.device, dtype=x.dtype) if S > 1 else None
     _check(lib().te_conv_res_f32(_ptr(out), _ptr(ws), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias),
-                                 _ptr(res.contiguous()) if res is not None else None, act, kind, B, K, M, H, W, _stream()),
+                                 _ptr(res.contiguous()) if res is not None else None,
+                                 _ptr(mask_ref.contiguous()) if mask_ref is not None else None, mask_gain, act, kind, B, K, M, H, W,
+                                 _stream()),
            'te_conv_res_f32')
     return out
 
@@ -370,6 +376,16 @@ def rgb_dgrad(g, w, isc, K, wscale=1.0):
     _check(lib().te_rgb_dgrad_f32(_ptr(gx), _ptr(g), _ptr(w.contiguous()), _ptr(isc), wscale, B, K, H * W, _stream()),
            'te_rgb_dgrad_f32')
     return gx
+
+
+def rgb_wgrad_sum_slabs(g3, x):
+    """slabs [B,S,4,K]: rows 0-2 = sum_p g3[b,o,p] x[b,k,p], row 3 = sum_p x[b,k,p]"""
+    g3, x = g3.contiguous(), x.contiguous()
+    B, K, H, W = x.shape
+    S = lib().te_rgb_wgrad_slab_count(B, K, H * W)
+    slabs = torch.empty(B, S, 4, K, device=x.device, dtype=x.dtype)
+    _check(lib().te_rgb_wgrad_sum_f32(_ptr(slabs), _ptr(g3), _ptr(x), B, K, H * W, S, _stream()), 'te_rgb_wgrad_sum_f32')
+    return slabs
 
 
 def rgb_expand(x3, w3k, bias, act, wscale=1.0):

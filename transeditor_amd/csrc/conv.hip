@@ -90,6 +90,8 @@ struct ConvArgs {
     const float* osc;
     const float* bias;
     const float* res;        // residual [B][M][Ho][Wo] added AFTER the activation (the sum of a ResBlock / of two gradient branches), or NULL
+    const float* mref;       // leaky-ReLU gradient mask applied LAST: out *= (mref > 0 ? mgain : 0.2 * mgain), mref shaped like out
+    float mgain;             // (a data gradient that lands on the output of a fused bias + leaky-ReLU: its backward in this epilogue)
     int B, K, M, Kp, Mp;
     int Hi, Wi, Ho, Wo;      // input / output spatial size
     int H, W;                // low-resolution size (cells of T2 live on (H+1)x(W+1))
@@ -125,7 +127,10 @@ template <> struct Kind<TE_CONV_1X1> { static constexpr int NT = 1; };
 // FAST: every stage is a full one (K % KC == 0, host-checked): stage loads take scalar channel offsets and are spread over
 // the MFMA steps, the LDS operands are read one step ahead, input tiles are staged as 16-byte row segments, and the four
 // shifted B fragments of T2 are shared by its taps.
-template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
+// EPI: the residual / activation-gradient-mask epilogue stages are compiled in (unmodulated 3x3 / 1x1 launches that ask for
+// them: the discriminator's ResBlock node).  A template flag, not a run-time branch: the 16 + 16 extra loads per accumulator
+// tile push the 168-register (3 waves / SIMD) kernels into scratch spills when they are part of every instantiation.
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST, bool EPI = false>
 __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs p) {
     using C = Cfg<KIND, TC>;
     constexpr int NBW = C::NBW, MBW = C::MBW, KC = C::KC, WM = C::WM, WN = 4 / C::WM, NSP = C::NSP;
@@ -593,7 +598,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                     if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
                     if (ok) {
                         const size_t oi = (size_t)ci * p.Wo + cj;
-                        if (p.res) v += p.res[(size_t)(obase - p.out) + oi];
+                        if (EPI) {
+                            if (p.res) v += p.res[(size_t)(obase - p.out) + oi];
+                            if (p.mref) v *= p.mref[(size_t)(obase - p.out) + oi] > 0.f ? p.mgain : 0.2f * p.mgain;
+                        }
                         obase[oi] = v;
                     }
                 } else {
@@ -628,7 +636,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 // epilogue of the split-K path: out = act((sum_z ws[z] | out) * osc[b,m] + bias[m]); the slabs are summed in fixed order
 __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ out, const float* __restrict__ ws, int ksplit,
                                                             const float* __restrict__ osc,
-                                                            const float* __restrict__ bias, const float* __restrict__ res, int act,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            const float* __restrict__ mref, float mgain, int act,
                                                             int M, int plane, int64_t total) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t bm = e / plane;
@@ -643,6 +652,7 @@ __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ 
         if (bias) v += bias[bm % M];
         if (act >= 3) v = (v > 0.f ? v : v * 0.2f) * (act == 3 ? 1.4142135623730951f : 1.f);
         if (res) v += res[e];
+        if (mref) v *= mref[e] > 0.f ? mgain : 0.2f * mgain;
         out[e] = v;
     }
 }
@@ -768,11 +778,11 @@ int add_region(ConvArgs& a, int ri0, int rj0, int rh, int rw, int& nblocks, size
 #endif
 constexpr int conv_occ() { return TE_CONV_OCC; }      // waves per SIMD the plain 3x3 128-row tile is compiled for (2: 135.7 vs 140.1 TFLOP/s with the FAST kernel)
 
-template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST>
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool FAST, bool EPI>
 void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) {
     constexpr int BM = tile_bm<KIND, TC>();
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST>, 128 * 1024);
+    te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST, EPI>, 128 * 1024);
     ConvArgs b = a;
     b.ntiles = nblocks; b.mblocks = (int)te::cdiv(a.M, BM);
 #if TE_CONV_XCD
@@ -780,24 +790,25 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
 #else
     dim3 grid((unsigned)(nblocks * b.mblocks), 1u, (unsigned)a.ksplit);
 #endif
-    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(b);
+    conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST, EPI><<<grid, NTHREADS, lds_floats * sizeof(float), s>>>(b);
 }
 
 template <int KIND, int TC> constexpr bool have_fast() { return TE_CONV_FAST && (TC == 3 || ((TC == 0 || TE_CONV_FAST_NARROW) && KIND != TE_CONV_1X1)); }
 
-template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC>
+template <int KIND, int TC, bool HAS_ISC, bool MS, int OCC, bool EPI>
 void launch_o(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
     constexpr bool HAVE_FAST = have_fast<KIND, TC>() && !MS;
-    if (HAVE_FAST && fast) launch_f<KIND, TC, HAS_ISC, MS, OCC, HAVE_FAST>(a, nblocks, lds_floats, s);
-    else launch_f<KIND, TC, HAS_ISC, MS, OCC, false>(a, nblocks, lds_floats, s);
+    if (HAVE_FAST && fast) launch_f<KIND, TC, HAS_ISC, MS, OCC, HAVE_FAST, EPI>(a, nblocks, lds_floats, s);
+    else launch_f<KIND, TC, HAS_ISC, MS, OCC, false, EPI>(a, nblocks, lds_floats, s);
 }
 
-template <int KIND, int TC, bool HAS_ISC, bool MS>
+template <int KIND, int TC, bool HAS_ISC, bool MS, bool EPI = false>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
-    // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168)
-    constexpr bool CAN3 = (KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS);
-    if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2>(a, nblocks, lds_floats, s, fast);
-    else launch_o<KIND, TC, HAS_ISC, MS, 2>(a, nblocks, lds_floats, s, fast);
+    // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168); the
+    // epilogue-stage variants take the 2-wave budget (their extra loads do not fit 168 registers)
+    constexpr bool CAN3 = !EPI && ((KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS));
+    if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2, EPI>(a, nblocks, lds_floats, s, fast);
+    else launch_o<KIND, TC, HAS_ISC, MS, 2, EPI>(a, nblocks, lds_floats, s, fast);
 }
 
 // regions: list of {ri0, rj0, rh, rw}
@@ -825,6 +836,16 @@ int launch_regions_tc(ConvArgs a, const int (*regions)[4], int n, hipStream_t s)
     }
     if (nblocks == 0) return 0;
     if (TC == 3 && !fast) return launch_regions_tc<KIND, 0>(a, regions, n, s);      // the deep-stage class exists as a FAST kernel only
+    if (a.res || a.mref) {
+        if constexpr (KIND == TE_CONV_3X3 || KIND == TE_CONV_1X1) {
+            if (a.isc) return te::fail(TE_ERR_UNSUPPORTED, "te_conv_res_f32: residual / mask epilogue exists for unmodulated launches only");
+            if (ms) launch_t<KIND, TC, false, true, true>(a, nblocks, lds_floats, s, fast);
+            else launch_t<KIND, TC, false, false, true>(a, nblocks, lds_floats, s, fast);
+            return 0;
+        } else {
+            return te::fail(TE_ERR_UNSUPPORTED, "te_conv_res_f32: residual / mask epilogue exists for the 3x3 and 1x1 kinds only");
+        }
+    }
     if (!a.isc) launch_t<KIND, TC, false, false>(a, nblocks, lds_floats, s, fast);
     else if (ms) launch_t<KIND, TC, true, true>(a, nblocks, lds_floats, s, fast);
     else launch_t<KIND, TC, true, false>(a, nblocks, lds_floats, s, fast);
@@ -923,22 +944,24 @@ extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W)
 }
 
 extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
-                               const float* bias, const float* res, int act, int kind, int B, int K, int M, int H, int W,
-                               te_stream_t stream_) {
+                               const float* bias, const float* res, const float* mask_ref, float mask_gain, int act, int kind,
+                               int B, int K, int M, int H, int W, te_stream_t stream_) {
     TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
-    TE_REQUIRE(!res || kind != TE_CONV_T2, TE_ERR_UNSUPPORTED, "te_conv_res_f32: no residual epilogue for the transposed kind");
+    TE_REQUIRE(!(res || mask_ref) || kind != TE_CONV_T2, TE_ERR_UNSUPPORTED,
+               "te_conv_res_f32: no residual / mask epilogue for the transposed kind");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
     TE_REQUIRE(kind >= 0 && kind <= 3, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     hipStream_t s = (hipStream_t)stream_;
     ConvArgs a{};
-    a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.act = act;
+    a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
     const int tc = pl.tc;
     a.ksplit = pl.ksplit; a.kchunk = pl.kchunk;
     if (a.ksplit == 1) a.ws = nullptr;
-    TE_REQUIRE(!(res && a.ksplit > 1 && !a.ws), TE_ERR_NULL, "te_conv_res_f32: a split launch with a residual needs the workspace");
+    TE_REQUIRE(!((res || mask_ref) && a.ksplit > 1 && !a.ws), TE_ERR_NULL,
+               "te_conv_res_f32: a split launch with a residual / mask epilogue needs the workspace");
     if (a.ksplit > 1 && !a.ws) {       // no workspace: the splits accumulate into `out` with atomics (order not fixed)
         const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
         hipError_t e = hipMemsetAsync(out, 0, bytes, s);
@@ -978,14 +1001,14 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
         const int plane = a.Ho * a.Wo;
         const int64_t total = (int64_t)B * M * plane;
         conv_finalize_kernel<<<(int)std::min<int64_t>(te::cdiv(total, 256), te::kNumCU * 8), 256, 0, s>>>(out, a.ws, a.ksplit, osc, bias, res,
-                                                                                                     act, M, plane, total);
+                                                                                                     mask_ref, mask_gain, act, M, plane, total);
     }
     return te::launch_status("te_conv_f32");
 }
 
 extern "C" int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                               const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream_) {
-    return te_conv_res_f32(out, ws, in, wp, isc, osc, bias, nullptr, act, kind, B, K, M, H, W, stream_);
+    return te_conv_res_f32(out, ws, in, wp, isc, osc, bias, nullptr, nullptr, 1.f, act, kind, B, K, M, H, W, stream_);
 }
 
 extern "C" int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, const float* osc,

@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, 
 
 // one block per (sample, pixel chunk); x tile [K][TP] staged in LDS (row stride TP+1: conflict-free column reads),
 // thread k accumulates its 3 dot products over the chunk's pixels
+// SUM: a 4th slab row holds sum_p x[b,k,p] (the bias gradient of the from-RGB stem comes out of the same pass over x)
 constexpr int TP = 32;
+template <bool SUM>
 __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slabs, const float* __restrict__ g,
                                                         const float* __restrict__ x, int K, int HW, int S) {
+    constexpr int NROW = SUM ? NOUT + 1 : NOUT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xl = smem;                      // [K][TP + 1]
     float* gl = smem + K * (TP + 1);       // [NOUT][TP]
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slab
     const int t0 = (int)((int64_t)ntile * c / S), t1 = (int)((int64_t)ntile * (c + 1) / S);
     const float* xb = x + (size_t)b * K * HW;
     const float* gb = g + (size_t)b * NOUT * HW;
-    float acc[2][NOUT] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float acc[2][NOUT + 1] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int tl = t0; tl < t1; ++tl) {
         const int p0 = tl * TP;
         __syncthreads();
@@ -132,17 +135,18 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slab
                     const float xv = xl[k * (TP + 1) + pp];
 #pragma unroll
                     for (int o = 0; o < NOUT; ++o) acc[h][o] += gl[o * TP + pp] * xv;
+                    if (SUM) acc[h][NOUT] += xv;
                 }
             }
         }
     }
-    float* sl = slabs + ((size_t)b * S + c) * NOUT * K;
+    float* sl = slabs + ((size_t)b * S + c) * NROW * K;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int k = tid + 256 * h;
         if (k < K) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) sl[o * K + k] = acc[h][o];
+            for (int o = 0; o < NROW; ++o) sl[o * K + k] = acc[h][o];
         }
     }
 }
@@ -193,8 +197,19 @@ extern "C" int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, in
     TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_f32: need 0 < K <= 512");
     const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel, 96 * 1024);
+    te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel<false>, 96 * 1024);
     dim3 grid((unsigned)S, (unsigned)B);
-    rgb_wgrad_kernel<<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
+    rgb_wgrad_kernel<false><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
     return te::launch_status("te_rgb_wgrad_f32");
+}
+
+extern "C" int te_rgb_wgrad_sum_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream_) {
+    TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_rgb_wgrad_sum_f32: NULL pointer");
+    TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_sum_f32: need 0 < K <= 512");
+    const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel<true>, 96 * 1024);
+    dim3 grid((unsigned)S, (unsigned)B);
+    rgb_wgrad_kernel<true><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
+    return te::launch_status("te_rgb_wgrad_sum_f32");
 }

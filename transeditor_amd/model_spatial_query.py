@@ -530,16 +530,24 @@ class ResBlock(nn.Module):                                                      
                 and (sk[1].weight.shape[2], sk[1].stride, sk[1].padding) == (1, 2, 0)
                 and tuple(c2[0].kernel.shape) == (4, 4) and tuple(sk[0].kernel.shape) == (4, 4))
 
-    def forward(self, input):
+    def fusable(self, input):
+        return (input.is_cuda and input.dtype == torch.float32 and not _modconv_state['second_order'] and input.shape[2] >= 8
+                and input.shape[3] >= 8 and input.shape[2] % 2 == 0 and input.shape[3] % 2 == 0 and self._standard())
+
+    def forward(self, input, stem=None):
+        """`stem` (extension used by Discriminator): the from-RGB ConvLayer(3, C, 1) in front of this block, run inside the
+        block's autograd node; `input` is the image then."""
         # (conv2 + skip) / sqrt(2) (:796) with the constant folded into the two branches' last convolutions
         g = 1 / math.sqrt(2)
-        if (input.is_cuda and input.dtype == torch.float32 and not _modconv_state['second_order'] and input.shape[2] >= 8
-                and input.shape[3] >= 8 and input.shape[2] % 2 == 0 and input.shape[3] % 2 == 0 and self._standard()):
+        if self.fusable(input):
             # the whole block as one autograd node (op/resblock.py): sums in convolution epilogues, conv1's activation
             # gradient in the adjoint blur
             c1, c2, sk = self.conv1, self.conv2, self.skip
+            st = None if stem is None else (stem[0].weight, stem[1].bias, stem[0].scale)
             return resblock(input, c1[0].weight, c1[1].bias, c2[1].weight, c2[2].bias, sk[1].weight, c2[0].kernel, sk[0].kernel,
-                            c1[0].scale, c2[1].scale, sk[1].scale, c2[0].pad, sk[0].pad, g)
+                            c1[0].scale, c2[1].scale, sk[1].scale, c2[0].pad, sk[0].pad, g, stem=st)
+        if stem is not None:
+            input = stem(input)
         return self.conv2(self.conv1(input), gain=g) + self.skip(input, gain=g)
 
 
@@ -559,8 +567,24 @@ class Discriminator(nn.Module):                                                 
         self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation='fused_lrelu'),
                                           EqualLinear(channels[4], 1))
 
+    def _stem_fusable(self, input):
+        """from-RGB layer + first ResBlock as one node (op/resblock.py): the standard ConvLayer(3, C, 1) followed by a standard block"""
+        if len(self.convs) < 2 or not isinstance(self.convs[1], ResBlock) or not isinstance(self.convs[0], ConvLayer):
+            return False
+        st = list(self.convs[0])
+        return (len(st) == 2 and isinstance(st[0], EqualConv2d) and st[0].bias is None
+                and (st[0].weight.shape[1], st[0].weight.shape[2], st[0].stride, st[0].padding) == (3, 1, 1, 0)
+                and isinstance(st[1], FusedLeakyReLU) and st[1].bias is not None and st[1].negative_slope == 0.2
+                and abs(st[1].scale - 2 ** 0.5) < 1e-12 and input.shape[1] == 3 and st[0].weight.shape[0] <= 512
+                and (input.shape[2] * input.shape[3]) % 4 == 0 and self.convs[1].fusable(input))
+
     def forward(self, input):
-        out = self.convs(input)
+        if self._stem_fusable(input):
+            out = self.convs[1](input, stem=self.convs[0])
+            for m in list(self.convs)[2:]:
+                out = m(out)
+        else:
+            out = self.convs(input)
         batch = out.shape[0]
         # :844-852 minibatch stddev + concat: one launch (op/stddev.py)
         out = minibatch_stddev(out, self.stddev_group, self.stddev_feat, second_order=_modconv_state['second_order'])

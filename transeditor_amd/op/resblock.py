@@ -31,8 +31,10 @@ from .upfirdn2d import _geometry, flipped_taps, upfirdn2d
 _SQRT2 = math.sqrt(2.0)
 
 
-def resblock_composite(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain):
-    """the same function from any-order differentiable pieces"""
+def resblock_composite(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, w0=None, b0=None, s0=1.0):
+    """the same function from any-order differentiable pieces (w0 / b0: the from-RGB stem in front, x is the image then)"""
+    if w0 is not None:
+        x = _composite(x, w0, None, None, b0, True, '1x1', s0)
     y1 = _composite(x, w1, None, None, b1, True, '3x3', s1)
     yb = upfirdn2d(y1, k_main, pad=pad_main)
     y2 = _composite(yb, w2, None, None, b2, _SQRT2 * gain, 'down', s2)
@@ -42,13 +44,23 @@ def resblock_composite(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_ma
 
 class _ResBlock(Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain):
+    def forward(ctx, x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, w0, b0, s0):
         x = x.contiguous()
         need = ctx.needs_input_grad
-        front = need[0] or need[1] or need[2]                 # anything upstream of the blur wants a gradient
+        # Optional from-RGB stem in front (the discriminator's ConvLayer(3, C, 1), :815, + its first ResBlock as one node):
+        # x is the image, the block's input is lrelu(conv1x1(x, w0) + b0) * sqrt(2).  The stem's activation gradient then
+        # rides in the epilogue of conv1's data gradient (te_conv_res_f32's mask stage) instead of a pass of its own.
+        ctx.stem = w0 is not None
+        img = None
+        need_x = need[0]
+        if ctx.stem:
+            img = x
+            x = _lib.rgb_expand(img, w0.reshape(w0.shape[0], 3).t(), b0, 3, s0)
+            need_x = need[0] or need[14] or need[15]          # the block's input gradient feeds dimg, dw0, db0
+        front = need_x or need[1] or need[2]                  # anything upstream of the blur wants a gradient
         H, W = x.shape[2], x.shape[3]
         # conv1 (+ its data-gradient packing when dx will be asked for)
-        if need[0]:
+        if need_x:
             wp1, wp1b = packed2(w1, _lib.PACK_FWD, _bwd_pack_kind('3x3'), s1)
         else:
             wp1, wp1b = packed(w1, _lib.PACK_FWD, s1), None
@@ -70,31 +82,36 @@ class _ResBlock(Function):
         xs = _lib.upfirdn2d_raw(x, k_skip, (1, 1), (2, 2), ps)
         if xs.shape[2:] != y2.shape[2:]:
             raise RuntimeError(f'resblock: branch sizes differ {tuple(xs.shape[2:])} vs {tuple(y2.shape[2:])}')
-        if need[0]:
+        if need_x:
             wps, wpsb = packed2(ws, _lib.PACK_FWD, _bwd_pack_kind('1x1'), ss * gain)
         else:
             wps, wpsb = packed(ws, _lib.PACK_FWD, ss * gain), None
         out = _lib.conv(xs, wps, _lib.CONV_1X1, ws.shape[0], xs.shape[2], xs.shape[3], None, None, None, 0, res=y2)
-        ctx.save_for_backward(x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs)
+        ctx.save_for_backward(x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs, img, w0, b0)
         ctx.packs = (wp1b, wp2b, wpsb)
-        ctx.cfg = (s1, s2, ss, tuple(pad_main), tuple(pad_skip), gain, pm, ps)
+        ctx.cfg = (s1, s2, ss, tuple(pad_main), tuple(pad_skip), gain, pm, ps, s0, need_x)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs = ctx.saved_tensors
-        s1, s2, ss, pad_main, pad_skip, gain, pm, ps = ctx.cfg
+        x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs, img, w0, b0 = ctx.saved_tensors
+        s1, s2, ss, pad_main, pad_skip, gain, pm, ps, s0, need_x = ctx.cfg
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():          # double backward requested: differentiate the composite (partial derivatives
             with torch.enable_grad():        # w.r.t. fresh aliases, everything stays connected for the next order)
-                al = [t.view_as(t) for t in (x, w1, b1, w2, b2, ws)]
-                y = resblock_composite(*al, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain)
-                ins = [t for t, n in zip(al, need[:6]) if n]
+                src = (img if ctx.stem else x, w1, b1, w2, b2, ws)
+                al = [t.view_as(t) for t in src]
+                st = [w0.view_as(w0), b0.view_as(b0)] if ctx.stem else [None, None]
+                y = resblock_composite(*al, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, st[0], st[1], s0)
+                flags = list(need[:6]) + ([need[14], need[15]] if ctx.stem else [])
+                ins = [t for t, n in zip(al + (st if ctx.stem else []), flags) if n]
                 gs = iter(torch.autograd.grad(y, ins, g, create_graph=True, allow_unused=True))
-            return tuple(next(gs) if n else None for n in need[:6]) + (None,) * 8
+            first = tuple(next(gs) if n else None for n in need[:6])
+            tail = (next(gs) if need[14] else None, next(gs) if need[15] else None) if ctx.stem else (None, None)
+            return first + (None,) * 8 + tail + (None,)
         wp1b, wp2b, wpsb = ctx.packs
         g = g.contiguous()
-        front = need[0] or need[1] or need[2]
+        front = need_x or need[1] or need[2]
         gx = gw1 = gb1 = gw2 = gb2 = gws = None
         # ---- main branch, from the tail: activation gradient of conv2 (quarter resolution), its data / weight gradient
         g2, gb2 = _lib.bias_act_bwd(g, y2, 0.2, _SQRT2 * gain, want_bias=need[4])
@@ -117,15 +134,31 @@ class _ResBlock(Function):
         # ---- skip branch
         if need[5]:
             gws = _wgrad_plain(g, xs, '1x1', 1, ss * gain)
-        if need[0]:
+        gw0 = gb0 = None
+        if need_x:
             g_xs = _dgrad_raw(g, ws, '1x1', wscale=ss * gain, wp=wpsb)
             _, gp_s = _geometry(x.shape[2:], k_skip.shape, (1, 1), (2, 2), ps)
             gx_b = _lib.upfirdn2d_raw(g_xs, flipped_taps(k_skip), (2, 2), (1, 1), gp_s)
-            # data gradient of conv1 + the skip branch's gradient in its epilogue
-            gx = _lib.conv(g1, wp1b, _lib.CONV_3X3, w1.shape[1], x.shape[2], x.shape[3], None, None, None, 0, res=gx_b)
-        return (gx, gw1, gb1, gw2, gb2, gws) + (None,) * 8
+            # data gradient of conv1 + the skip branch's gradient in its epilogue (+ the stem's activation gradient)
+            gx = _lib.conv(g1, wp1b, _lib.CONV_3X3, w1.shape[1], x.shape[2], x.shape[3], None, None, None, 0, res=gx_b,
+                           mask_ref=x if ctx.stem else None, mask_gain=_SQRT2)
+        if ctx.stem:
+            gpre, gx = gx, None                               # gradient w.r.t. the stem's pre-activation
+            M = w0.shape[0]
+            if need[14] or need[15]:                          # dW0 [M,3] and db0 [M] from one pass over gpre
+                sl = _lib.rgb_wgrad_sum_slabs(img, gpre).sum(dim=(0, 1))          # [4, M]
+                if need[14]:
+                    gw0 = sl[:3].t().reshape(w0.shape)
+                    gw0 = gw0 * s0 if s0 != 1.0 else gw0
+                if need[15]:
+                    gb0 = sl[3].contiguous()
+            if need[0]:
+                gx = _lib.rgb_fwd(gpre, w0.reshape(M, 3).t().contiguous(), None, None, s0)
+        return (gx, gw1, gb1, gw2, gb2, gws) + (None,) * 8 + (gw0, gb0, None)
 
 
-def resblock(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain):
+def resblock(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, stem=None):
+    """stem = (w0 [C,3,1,1], b0 [C], s0): x is the 3-channel image and the from-RGB layer runs inside the node"""
+    w0, b0, s0 = stem if stem is not None else (None, None, 1.0)
     return _ResBlock.apply(x, w1, b1, w2, b2, ws, k_main, k_skip, float(s1), float(s2), float(ss), tuple(pad_main),
-                           tuple(pad_skip), float(gain))
+                           tuple(pad_skip), float(gain), w0, b0, float(s0))
