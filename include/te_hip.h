@@ -82,6 +82,16 @@ int te_bias_act_f64(double* out, const double* x, const double* b, const double*
  * are combined with atomics).  */
 int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const float* ref, float alpha, float scale,
                         int64_t outer, int64_t C, int64_t inner, te_stream_t stream);
+/* te_bias_act_bwd_f32 with the data gradient of a ToRGB layer (1x1 modulated convolution to 3 channels, ToRGB.forward,
+ * model_spatial_query.py:416-425) folded in — te_rgb_dgrad_f32, the gradient-accumulation add and the activation gradient
+ * in one pass over the activation-sized tensors:
+ *     gi = ( g + wscale * srgb[n,c] * sum_o wrgb[o,c] * grgb[n,o,:] ) * (ref > 0 ? 1 : alpha) * scale ,   gb[c] += sum gi
+ * g [outer,C,inner] may be NULL (nothing but ToRGB consumes the activation), grgb [outer,3,inner], wrgb [3,C], srgb [outer,C] or
+ * NULL; gb zero-filled by the caller or NULL.  te_bias_act_bwd_rgb_supported: inner % 4 == 0 and inner >= 1024. */
+int te_bias_act_bwd_rgb_supported(int64_t outer, int64_t C, int64_t inner);
+int te_bias_act_bwd_rgb_f32(float* gi, float* gb, const float* g, const float* ref, const float* grgb, const float* wrgb,
+                            const float* srgb, float wscale, float alpha, float scale, int64_t outer, int64_t C, int64_t inner,
+                            te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K2  upfirdn2d.  Replaces pybind `upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel, up_x,

@@ -25,6 +25,8 @@ _SIGNATURES = {
     'te_bias_act_f16': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_f64': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_bwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_bwd_rgb_supported': (C.c_int, [_L, _L, _L]),
+    'te_bias_act_bwd_rgb_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _P]),
     'te_upfirdn2d_f32': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                    _P, _L, _I, _F, _F, _P]),
     'te_upfirdn2d_f16': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -209,6 +211,29 @@ def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
     gb = zeros(Cn, g.device) if want_bias else None
     _check(lib().te_bias_act_bwd_f32(_ptr(gi), _ptr(gb), _ptr(g), _ptr(ref), alpha, scale, g.shape[0], Cn, inner,
                                      _stream()), 'te_bias_act_bwd_f32')
+    return gi, gb
+
+
+def bias_act_bwd_rgb_supported(shape):
+    inner = 1
+    for d in shape[2:]:
+        inner *= d
+    return bool(lib().te_bias_act_bwd_rgb_supported(shape[0], shape[1], inner))
+
+
+def bias_act_bwd_rgb(g, ref, grgb, wrgb, srgb, wscale, alpha, scale, want_bias=True):
+    """activation gradient with a ToRGB data gradient folded in (see te_hip.h); g may be None.  -> (gi, gb | None)"""
+    ref, grgb = ref.contiguous(), grgb.contiguous()
+    g = g.contiguous() if g is not None else None
+    gi = torch.empty_like(ref)
+    Cn = ref.shape[1]
+    inner = 1
+    for d in ref.shape[2:]:
+        inner *= d
+    gb = zeros(Cn, ref.device) if want_bias else None
+    _check(lib().te_bias_act_bwd_rgb_f32(_ptr(gi), _ptr(gb), _ptr(g), _ptr(ref), _ptr(grgb), _ptr(wrgb.contiguous()),
+                                         _ptr(srgb.contiguous()) if srgb is not None else None, wscale, alpha, scale,
+                                         ref.shape[0], Cn, inner, _stream()), 'te_bias_act_bwd_rgb_f32')
     return gi, gb
 
 

@@ -100,6 +100,51 @@ __global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restri
     }
 }
 
+// The same pass with the data gradient of a ToRGB layer folded in (generator, model_spatial_query.py:416-425: the activation
+// a2 feeds the next layer AND a 1x1 modulated convolution to 3 channels):
+//     gi = (g + coef[0] * grgb[n,0] + coef[1] * grgb[n,1] + coef[2] * grgb[n,2]) * slope(ref),   coef[o] = wscale * srgb[n,c] * wrgb[o,c]
+// i.e. te_rgb_dgrad_f32 + the framework's gradient-accumulation add + te_bias_act_bwd_f32 in one read of g / ref and one
+// write of gi (12 instead of 28 bytes per element; the 3-channel grgb rows are re-read by every channel from L2).  g may be
+// NULL (the last layer's activation feeds ToRGB only).
+__global__ __launch_bounds__(256) void bias_act_bwd_rgb_rows_kernel(float4* __restrict__ gi, float* __restrict__ gb,
+                                                                    const float4* __restrict__ g, const float4* __restrict__ ref,
+                                                                    const float4* __restrict__ grgb, const float* __restrict__ wrgb,
+                                                                    const float* __restrict__ srgb, float wscale, float alpha,
+                                                                    float scale, uint32_t C, uint32_t inner4) {
+    __shared__ float lds4[4];
+    const uint32_t c = blockIdx.y, n = blockIdx.z;
+    const size_t row = ((size_t)n * C + c) * inner4;
+    const size_t rrow = (size_t)n * 3 * inner4;
+    const float sc = (srgb ? srgb[(size_t)n * C + c] : 1.f) * wscale;
+    const float c0 = sc * wrgb[c], c1 = sc * wrgb[C + c], c2 = sc * wrgb[2 * C + c];
+    const uint32_t base = blockIdx.x * (256 * kBwdVecPerThread);
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < kBwdVecPerThread; ++it) {
+        const uint32_t i = base + it * 256 + threadIdx.x;
+        if (i < inner4) {
+            const float4 rv = ref[row + i];
+            const float4 r0 = grgb[rrow + i], r1 = grgb[rrow + inner4 + i], r2 = grgb[rrow + 2 * (size_t)inner4 + i];
+            float4 gv = g ? g[row + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            gv.x += c0 * r0.x + c1 * r1.x + c2 * r2.x;
+            gv.y += c0 * r0.y + c1 * r1.y + c2 * r2.y;
+            gv.z += c0 * r0.z + c1 * r1.z + c2 * r2.z;
+            gv.w += c0 * r0.w + c1 * r1.w + c2 * r2.w;
+            float4 o;
+            o.x = gv.x * (rv.x > 0.f ? 1.f : alpha) * scale;
+            o.y = gv.y * (rv.y > 0.f ? 1.f : alpha) * scale;
+            o.z = gv.z * (rv.z > 0.f ? 1.f : alpha) * scale;
+            o.w = gv.w * (rv.w > 0.f ? 1.f : alpha) * scale;
+            gi[row + i] = o;
+            acc += (o.x + o.y) + (o.z + o.w);
+        }
+    }
+    if (gb) {
+        const float tot = block_sum_256(acc, lds4);
+        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+    }
+}
+
 // generic layout: one block per channel, loops over (n, i)
 __global__ __launch_bounds__(256) void bias_act_bwd_chan_kernel(float* __restrict__ gi, float* __restrict__ gb,
                                                                 const float* __restrict__ g, const float* __restrict__ ref,
@@ -239,4 +284,24 @@ extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const f
         bias_act_bwd_chan_kernel<<<(int)C, 256, 0, stream>>>(gi, gb, g, ref, alpha, scale, outer, C, inner);
     }
     return te::launch_status("te_bias_act_bwd_f32");
+}
+
+extern "C" int te_bias_act_bwd_rgb_supported(int64_t outer, int64_t C, int64_t inner) {
+    return (outer > 0 && C > 0 && inner % 4 == 0 && inner >= 1024 && C <= 65535 && outer <= 65535) ? 1 : 0;
+}
+
+extern "C" int te_bias_act_bwd_rgb_f32(float* gi, float* gb, const float* g, const float* ref, const float* grgb, const float* wrgb,
+                                       const float* srgb, float wscale, float alpha, float scale, int64_t outer, int64_t C,
+                                       int64_t inner, te_stream_t stream_) {
+    TE_REQUIRE(gi && ref && grgb && wrgb, TE_ERR_NULL, "te_bias_act_bwd_rgb_f32: gi/ref/grgb/wrgb is NULL");
+    TE_REQUIRE(te_bias_act_bwd_rgb_supported(outer, C, inner), TE_ERR_UNSUPPORTED,
+               "te_bias_act_bwd_rgb_f32: needs inner %% 4 == 0 and inner >= 1024 (use te_rgb_dgrad_f32 + te_bias_act_bwd_f32)");
+    TE_REQUIRE(aligned16(gi) && (!g || aligned16(g)) && aligned16(ref) && aligned16(grgb), TE_ERR_UNSUPPORTED,
+               "te_bias_act_bwd_rgb_f32: 16-byte aligned tensors required");
+    const uint32_t inner4 = (uint32_t)(inner / 4);
+    dim3 grid((unsigned)te::cdiv(inner4, 256 * kBwdVecPerThread), (unsigned)C, (unsigned)outer);
+    bias_act_bwd_rgb_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((float4*)gi, gb, (const float4*)g, (const float4*)ref,
+                                                                       (const float4*)grgb, wrgb, srgb, wscale, alpha, scale,
+                                                                       (uint32_t)C, inner4);
+    return te::launch_status("te_bias_act_bwd_rgb_f32");
 }

@@ -32,6 +32,7 @@ from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused
 from .op.modconv import modconv, _STATE as _modconv_state
 from .op.resblock import resblock
+from .op import styled_rgb
 from .op.stddev import minibatch_stddev
 from .op.style import demod
 from .op.token_mlp import token_mlp
@@ -363,6 +364,23 @@ class Generator(nn.Module):                                                     
             noises += [torch.randn(1, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
         return noises
 
+    def _conv_rgb(self, conv, to_rgb, x, style_c, style_r, skip, noise):
+        """`out = conv(x, style_c); skip = to_rgb(out, style_r, skip)` (:702-714).  In a training forward the plain StyledConv
+        and the ToRGB reading it run as one autograd node (op/styled_rgb.py): the ToRGB data gradient is folded into the
+        convolution's activation-gradient pass instead of a pass + a gradient-accumulation add of its own."""
+        m, a = conv.conv, conv.activate
+        w = m.weight.view(m.weight.shape[1:])
+        wr = to_rgb.conv.weight.view(to_rgb.conv.weight.shape[1:])
+        if (torch.is_grad_enabled() and not conv.layer_noise_injection and not _modconv_state['second_order']
+                and not _modconv_state.frozen_on and m.kind == '3x3' and m.demodulate and not to_rgb.conv.demodulate
+                and to_rgb.conv.kind == '1x1' and a.bias is not None and a.negative_slope == 0.2
+                and abs(a.scale - 2 ** 0.5) < 1e-12 and styled_rgb.supported(x, w, wr)):
+            out, rgb = styled_rgb.styled_conv_rgb(x, w, m.modulation(style_c), a.bias, wr, to_rgb.conv.modulation(style_r),
+                                                  to_rgb.bias.view(3), m.scale, m.eps, to_rgb.conv.scale)
+            return out, (rgb if skip is None else rgb + to_rgb.upsample(skip))
+        out = conv(x, style_c, noise=noise)
+        return out, to_rgb(out, style_r, skip)
+
     def _map_tokens(self, net, codes, n_map):
         """:626-646 — PixelNorm, then token i through its own EqualLinear + fused lrelu: all tokens of a network in one
         batched launch (op/token_mlp.py).  codes [B, D, C] -> [B, D, C] (tokens >= n_map stay 0)."""
@@ -431,14 +449,12 @@ class Generator(nn.Module):                                                     
         # per-layer styles latent[:, i]: one contiguous copy + one unbind, so the backward is a single stack instead of
         # a zero-fill + add of the whole latent per layer
         lat = latent.contiguous().unbind(1)
-        out = self.conv1(out, lat[0], noise=noise[0])
-        skip = self.to_rgb1(out, lat[1])
+        out, skip = self._conv_rgb(self.conv1, self.to_rgb1, out, lat[0], lat[1], None, noise[0])
         i = 1
         for conv_up, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                  self.to_rgbs):
             out = conv_up(out, lat[i], noise=n1)
-            out = conv(out, lat[i + 1], noise=n2)
-            skip = to_rgb(out, lat[i + 2], skip)
+            out, skip = self._conv_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], skip, n2)
             i += 2
         image = skip
 
