@@ -229,30 +229,6 @@ int te_attn_bwd_f32(float* gq, float* gk, float* gv, const float* go, const floa
                     int G, int M, int L, int D, te_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * A1 + A2 fused  the WHOLE stack of cross-attention blocks in one launch per direction (reference: AttentionBlock.forward
- * + Attention.forward, model_spatial_query.py:883-901, 920-936, chained n_trans times by Generator.forward :670-679; ~26
- * launches per block unfused).  One 1024-thread workgroup per sample keeps the sample's activations in LDS and streams
- * the weights through v_mfma_f32_16x16x4_f32.  Shapes: 16 tokens, planes 128 (4 heads x 32), block output 512; block 0
- * may take cin / cp up to 528 (multiples of 16) and then owns a skip projection, later blocks take 512.
- *   weights: HOST array of nblocks x 14 device pointers, per block in the order
- *            atten.q_transform.{weight,bias}, atten.k_transform.*, atten.v_transform.*, atten.proj.*, mlp.0.*, mlp.2.*,
- *            proj.{weight,bias} (NULL, NULL when cin == 512);  dims: HOST array of nblocks x {cin, cp}
- *   x0 [N,16,cin0], p0 [N,16,cp0] (P seen by block 0), p [N,16,512] (P seen by the others), xout [N,16,512]
- *   save (may be NULL = inference): HOST array of 11 device buffers for the backward, each [nblocks][N][...]:
- *            xn [16][528] (row stride 528), q, k, v, o [16][128], sim [4][16][16], x1, xn1, hpre, h [16][512], stats [4]
- *   sim_out (may be NULL): [nblocks][N][4][16][16] attention matrices (return_similarity)
- * Backward: gx0 / gp0 / gp (gp = sum over the blocks after the first) and the six per-layer gradient matrices
- *   gmat = {g_x2, g_hpre, g_x1 : [nblocks][N][16][512];  g_q, g_k, g_v : [nblocks][N][16][128]}
- * from which weight / bias gradients are batched GEMMs over all samples (te_small_gemm_batched_rs_f32). */
-int te_attn_stack_lds_bytes(void);
-int te_attn_stack_fwd_f32(float* xout, const float* x0, const float* p0, const float* p, const float* const* weights, const int* dims,
-                          int nblocks, int N, float lr_mul, float attn_scale, float eps, float* const* save, float* sim_out,
-                          te_stream_t stream);
-int te_attn_stack_bwd_f32(float* gx0, float* gp0, float* gp, const float* gout, const float* const* weights, const int* dims,
-                          int nblocks, int N, float lr_mul, float attn_scale, float* const* save, float* const* gmat,
-                          te_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------
  * K2b  backward of "blur -> + bias -> leaky-ReLU * sqrt(2)" (the upsampling StyledConv tail, model_spatial_query.py:321 +
  * :401; reference backward = fused_bias_act_kernel.cu grad pass, then upfirdn2d with flipped taps) in ONE pass:
  *   gpre = g * (ref > 0 ? scale : alpha * scale)      ref = saved forward output, g / ref: [major, in_h, in_w]
@@ -284,12 +260,6 @@ int te_blur_gradact_f32(float* gx, float* partial, const float* g, const float* 
 int te_small_gemm_f32(float* c, float* pre, const float* a, const float* b, const float* bias, const float* residual,
                       float* arowsum, float rs_scale, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
                       int64_t sbj, float alpha, float beta, int act, te_stream_t stream);
-
-/* the uniform-stride batched form plus the row sums of A per z (arowsum[z * zrs + i] = rs_scale * sum_k A_z(i,k); may be
- * NULL): weight AND bias gradient of the same layer of several attention blocks in one launch (A_z = g_z^T). */
-int te_small_gemm_batched_rs_f32(float* c, const float* a, const float* b, float* arowsum, int64_t zrs, float rs_scale, int nz,
-                                 int64_t za, int64_t zc, int64_t zb, int I, int J, int K, int64_t sai, int64_t sak, int64_t sbk,
-                                 int64_t sbj, int64_t sci, int64_t scj, float alpha, te_stream_t stream);
 
 /* the same GEMM for WIDE reductions (reference: the discriminator's EqualLinear(8192, 512, 'fused_lrelu'),
  * model_spatial_query.py:831-834): K is split into S chunks (K % S == 0, (K / S) % 8 == 0) that run as S x tiles blocks,

@@ -91,3 +91,37 @@ def test_sample_data_cycles_and_prefetcher_passthrough_on_cpu():
     assert all(b.shape == (2, 3, 8, 8) for b in got) and torch.equal(got[0], got[3])
     pre = list(DevicePrefetcher([got[0], got[1]], 'cpu'))
     assert len(pre) == 2 and torch.equal(pre[1], got[1])
+
+
+class _PidTransform:
+    """image_transform + the decoding process's pid in element [0, 0, 0] (picklable: worker processes get a copy)"""
+
+    def __init__(self):
+        self.base = image_transform(0.0)
+
+    def __call__(self, img):
+        import os
+        t = self.base(img)
+        t[0, 0, 0] = float(os.getpid() % 100000)
+        return t
+
+
+def test_decode_runs_in_worker_processes():
+    """(f.4) decode off the training process: `data_loader(num_workers=2)` decodes in DataLoader workers (the reference keeps
+    num_workers=0, train_spatial_query.py:520-525), batches keep the reference's shape / drop_last semantics."""
+    import os
+    from transeditor_amd.utils.dataset import data_loader
+    store, imgs = _store(12, 8)
+    ds = MultiResolutionDataset(FakeEnv(store), _PidTransform(), 8)
+    loader = data_loader(ds, batch_size=4, sampler=torch.utils.data.SequentialSampler(ds), num_workers=2)
+    batches = list(loader)
+    assert len(batches) == 3 and all(b.shape == (4, 3, 8, 8) for b in batches)
+    pids = {int(b[i, 0, 0, 0]) for b in batches for i in range(4)}
+    assert os.getpid() % 100000 not in pids and 1 <= len(pids) <= 2
+    want = (torch.from_numpy(imgs[5].astype(np.float32)).permute(2, 0, 1) / 255.0 - 0.5) / 0.5
+    got = batches[1][1].clone()
+    got[0, 0, 0] = want[0, 0, 0]
+    assert torch.allclose(got, want, atol=1e-6)
+    same = data_loader(ds, batch_size=4, sampler=torch.utils.data.SequentialSampler(ds), num_workers=0)
+    assert {int(b[0, 0, 0, 0]) for b in same} == {os.getpid() % 100000}
+    del loader

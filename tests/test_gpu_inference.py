@@ -80,18 +80,3 @@ def test_optimizer_kernels_bump_parameter_versions():
     v1 = b.weight._version
     MultiTensorEMA(b, a).update(0.5)
     assert b.weight._version > v1
-
-
-def test_sampler_with_fused_attention_stack(golden, g64):
-    """GeneratorSampler(fused_attention=True): the n_trans attention blocks as one launch, eager and under graph replay,
-    against the reference fixture; the module-wide setting is restored afterwards."""
-    from transeditor_amd.inference import GeneratorSampler
-    from transeditor_amd.op import attn_stack
-    gold = golden('generator64_flags')
-    zz, pp = (t.to(DEV) for t in synth.latents(2, 1001))
-    before = attn_stack.FUSED
-    for use_graph in (False, True):
-        S = GeneratorSampler(g64, use_graph=use_graph, fused_attention=True)
-        for _ in range(2):
-            assert rel_err(S(zz, pp)[0], gold['img_default']) < TOL
-    assert attn_stack.FUSED == before

@@ -561,47 +561,6 @@ def test_pixel_norm_kernels(shape, dim):
     assert rel_err(torch.autograd.grad(a_.square().sum(), x)[0], torch.autograd.grad(b_.square().sum(), x)[0]) < 1e-4
 
 
-# ------------------------------------------------------------------------------------------------ A1 + A2 fused stack
-@pytest.mark.gpu
-@pytest.mark.parametrize('N,nb', [(4, 3), (16, 8), (2, 1)])
-def test_attention_stack_fused_vs_single_ops(N, nb):
-    """the whole stack of cross-attention blocks as one launch per direction (csrc/attn_block.hip) against the composition
-    of the single twice-differentiable ops (which the golden attention_block.npz fixtures pin to the reference,
-    model_spatial_query.py:883-936): output, input gradients and every parameter gradient; then the recorded backward."""
-    from transeditor_amd.model_spatial_query import AttentionBlock
-    from transeditor_amd.op import attn_stack as A
-    torch.manual_seed(5)
-    blocks = [AttentionBlock(528, 528, 512, lr_mul=0.01)] + [AttentionBlock(512, 512, 512, lr_mul=0.01) for _ in range(nb - 1)]
-    for i, b in enumerate(blocks):
-        synth.fill_state_dict(b.state_dict(prefix='interact.0.'), 70 + i)
-    blocks = [b.to(DEV) for b in blocks]
-    assert A.supported(blocks)
-    x0 = synth.normal((N, 16, 528), 'as.x').to(DEV).requires_grad_(True)
-    p0 = synth.normal((N, 16, 528), 'as.p0').to(DEV).requires_grad_(True)
-    p = synth.normal((N, 16, 512), 'as.p').to(DEV).requires_grad_(True) if nb > 1 else None
-    prm = [A.block_params(b) for b in blocks]
-    scale = blocks[0].atten.scale
-    y = A.attention_stack(x0, p0, p, prm, 0.01, scale)
-    y_ref = A._composite(x0, p0, p, prm, 0.01, scale)
-    assert tuple(y.shape) == (N, 16, 512)
-    assert rel_err(y, y_ref) < 1e-4
-    gy = synth.normal((N, 16, 512), 'as.g').to(DEV)
-    ins = [x0, p0] + ([p] if p is not None else []) + [t for b in prm for t in b]
-    got = torch.autograd.grad(y, ins, gy)
-    want = torch.autograd.grad(y_ref, ins, gy)
-    names = ['x0', 'p0'] + (['p'] if p is not None else []) + [f'b{i}.{A._NAMES[j]}' for i, b in enumerate(prm) for j in range(len(b))]
-    bad = [(n, rel_err(a, b)) for n, a, b in zip(names, got, want)
-           if not n.endswith('.bk') and rel_err(a, b) > 1e-3]          # key bias gradient is analytically zero (softmax shift)
-    assert not bad, bad[:8]
-    # recorded backward (path-length regulariser route): falls back to the composition, second derivatives agree
-    gx, = torch.autograd.grad(A.attention_stack(x0, p0, p, prm, 0.01, scale), x0, gy, create_graph=True)
-    gxr, = torch.autograd.grad(A._composite(x0, p0, p, prm, 0.01, scale), x0, gy, create_graph=True)
-    w = prm[0][8]
-    assert rel_err(torch.autograd.grad(gx.square().sum(), w)[0], torch.autograd.grad(gxr.square().sum(), w)[0]) < 1e-4
-    with torch.no_grad():                                   # inference: no save buffers
-        assert rel_err(A.attention_stack(x0, p0, p, prm, 0.01, scale), y_ref) < 1e-4
-
-
 # ------------------------------------------------------------------------------------------------ K1 / K2 in half and double
 @pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-13), (torch.float16, 3e-3)])
 def test_fused_leaky_relu_other_dtypes(dtype, tol):

@@ -64,10 +64,6 @@ _SIGNATURES = {
     'te_demod_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     'te_attn_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
-    'te_small_gemm_batched_rs_f32': (C.c_int, [_P, _P, _P, _P, _L, _F, _I, _L, _L, _L, _I, _I, _I, _L, _L, _L, _L, _L, _L, _F, _P]),
-    'te_attn_stack_lds_bytes': (C.c_int, []),
-    'te_attn_stack_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P]),
-    'te_attn_stack_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P]),
     'te_small_gemm_splitk_f32': (C.c_int, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _F, _F, _I, _P]),
     'te_minibatch_stddev_fwd_f32': (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
     'te_minibatch_stddev_bwd_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
@@ -601,46 +597,6 @@ def mt_ema(table, chunks, n_tensors, n_chunks, chunk_elems, decay):
            'te_mt_ema_f32')
 
 
-# --------------------------------------------------------------------------------------------- A1 + A2 fused
-def _ptr_array(tensors):
-    """host array of device pointers (None -> NULL); the tensors must stay alive until the launch is enqueued"""
-    arr = (C.c_void_p * len(tensors))()
-    for i, t in enumerate(tensors):
-        arr[i] = None if t is None else _ptr(t)
-    return arr
-
-
-def attn_stack_fwd(x0, p0, p, weights, dims, lr_mul, attn_scale, eps, save=None, sim_out=None):
-    """weights: flat list of 14 tensors (or None) per block; dims: [(cin, cp)] per block; save: list of 11 buffers or None"""
-    nb, N = len(dims), x0.shape[0]
-    xout = torch.empty(N, 16, 512, device=x0.device, dtype=x0.dtype)
-    warr = _ptr_array(weights)
-    darr = (C.c_int * (2 * nb))(*[v for d in dims for v in d])
-    sarr = _ptr_array(save) if save is not None else None
-    _check(lib().te_attn_stack_fwd_f32(_ptr(xout), _ptr(x0), _ptr(p0), _ptr(p), warr, darr, nb, N, lr_mul, attn_scale, eps, sarr,
-                                       _ptr(sim_out), _stream()), 'te_attn_stack_fwd_f32')
-    return xout
-
-
-def attn_stack_bwd(gout, weights, dims, lr_mul, attn_scale, save, gmat, cin0, cp0):
-    nb, N = len(dims), gout.shape[0]
-    gx0 = torch.empty(N, 16, cin0, device=gout.device, dtype=gout.dtype)
-    gp0 = torch.empty(N, 16, cp0, device=gout.device, dtype=gout.dtype)
-    gp = torch.empty(N, 16, 512, device=gout.device, dtype=gout.dtype) if nb > 1 else None
-    warr = _ptr_array(weights)
-    darr = (C.c_int * (2 * nb))(*[v for d in dims for v in d])
-    _check(lib().te_attn_stack_bwd_f32(_ptr(gx0), _ptr(gp0), _ptr(gp), _ptr(gout), warr, darr, nb, N, lr_mul, attn_scale,
-                                       _ptr_array(save), _ptr_array(gmat), _stream()), 'te_attn_stack_bwd_f32')
-    return gx0, gp0, gp
-
-
-def small_gemm_batched_rs(c, a, b, nz, za, zc, zb, I, J, K, sai, sak, sbk, sbj, sci, scj, alpha, arowsum=None, zrs=0, rs_scale=0.0):
-    """nz uniform-stride GEMMs in one launch with optional row sums of A per z (see te_hip.h); c written in place."""
-    _check(lib().te_small_gemm_batched_rs_f32(_raw(c), _raw(a), _raw(b), _raw(arowsum), zrs, rs_scale, nz, za, zc, zb, I, J, K, sai, sak,
-                                              sbk, sbj, sci, scj, alpha, _stream()), 'te_small_gemm_batched_rs_f32')
-    return c
-
-
 # --------------------------------------------------------------------------------------------- channel scale / dot
 def chan_scale(x, s):
     """x [B,C,...] * s[B,C] broadcast over the trailing dims"""
@@ -669,9 +625,9 @@ def _install_roctx():
     import torch.cuda.nvtx as nvtx
     names = ['bias_act', 'bias_act_bwd', 'upfirdn2d_raw', 'blur_actgrad', 'blur_gradact', 'conv_pack', 'conv_pack2', 'conv',
              'wgrad_slabs', 'wgrad_reduce', 'rgb_fwd', 'rgb_dgrad', 'rgb_expand', 'rgb_wgrad_slabs', 'small_gemm',
-             'small_gemm_splitk', 'small_gemm_batched', 'small_gemm_batched_rs', 'minibatch_stddev_fwd', 'minibatch_stddev_bwd',
+             'small_gemm_splitk', 'small_gemm_batched', 'minibatch_stddev_fwd', 'minibatch_stddev_bwd',
              'layer_norm_fwd', 'layer_norm_bwd', 'pixel_norm_fwd', 'pixel_norm_bwd', 'demod_fwd', 'demod_from_wsq', 'demod_bwd',
-             'attn_fwd', 'attn_bwd', 'attn_stack_fwd', 'attn_stack_bwd', 'mt_adam', 'mt_ema', 'chan_scale', 'chan_dot']
+             'attn_fwd', 'attn_bwd', 'mt_adam', 'mt_ema', 'chan_scale', 'chan_dot']
     g = globals()
 
     def wrap(fn, name):

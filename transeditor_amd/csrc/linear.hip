@@ -210,22 +210,6 @@ extern "C" int te_small_gemm_batched_f32(float* c, const float* a, const float* 
     return te::launch_status("te_small_gemm_batched_f32");
 }
 
-/* te_small_gemm_batched_f32 plus the row sums of A per z (arowsum[z * zrs + i] = rs_scale * sum_k A_z(i,k)): the weight AND
- * bias gradients of the same layer of several attention blocks in one launch (A_z = g_z^T). */
-extern "C" int te_small_gemm_batched_rs_f32(float* c, const float* a, const float* b, float* arowsum, int64_t zrs, float rs_scale,
-                                            int nz, int64_t za, int64_t zc, int64_t zb, int I, int J, int K, int64_t sai, int64_t sak,
-                                            int64_t sbk, int64_t sbj, int64_t sci, int64_t scj, float alpha, te_stream_t stream_) {
-    TE_REQUIRE(c && a && b, TE_ERR_NULL, "te_small_gemm_batched_rs_f32: NULL pointer");
-    TE_REQUIRE(I > 0 && J > 0 && K > 0 && nz > 0, TE_ERR_SHAPE, "te_small_gemm_batched_rs_f32: bad dims");
-    LinArgs p{};
-    p.c = c; p.a = a; p.b = b; p.arowsum = arowsum; p.rs_scale = rs_scale; p.zrs = zrs;
-    p.I = I; p.J = J; p.K = K; p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj; p.sci = sci; p.scj = scj;
-    p.alpha = alpha; p.beta = 0.f; p.act = 0;
-    p.za = za; p.zc = zc; p.zb = zb;
-    launch_small_gemm(p, nz, (hipStream_t)stream_);
-    return te::launch_status("te_small_gemm_batched_rs_f32");
-}
-
 /* wide reductions (the discriminator's 8192 -> 512 linear, model_spatial_query.py:831-834): K is cut into S chunks that run
  * as the z dimension of the same kernel (S x tiles blocks instead of `tiles`), partial tiles go to the caller's workspace
  * ws[S][I][J], a second tiny kernel sums them in fixed order and applies the epilogue.  Deterministic, no atomics. */

@@ -19,13 +19,11 @@ from .op.modconv import frozen_weights
 
 
 class GeneratorSampler:
-    def __init__(self, generator, use_graph=True, copy_outputs=True, fused_attention=None):
-        """copy_outputs=False returns views of the graph's static output buffers (valid until the next call).
-        fused_attention: run the n_trans attention blocks as one launch (op/attn_stack.py).  None = the module-wide setting."""
+    def __init__(self, generator, use_graph=True, copy_outputs=True):
+        """copy_outputs=False returns views of the graph's static output buffers (valid until the next call)."""
         self.g = generator.eval()
         self.use_graph = use_graph
         self.copy_outputs = copy_outputs
-        self.fused_attention = fused_attention
         self._cache = {}
         self._graphs = {}
         self._stamp = None
@@ -40,15 +38,8 @@ class GeneratorSampler:
 
     @torch.no_grad()
     def eager(self, style, op_param, **kw):
-        from .op import attn_stack
-        old = attn_stack.FUSED
-        if self.fused_attention is not None:
-            attn_stack.use_fused(self.fused_attention)
-        try:
-            with frozen_weights(self._cache):
-                return self.g(style, op_param, **kw)
-        finally:
-            attn_stack.use_fused(old)
+        with frozen_weights(self._cache):
+            return self.g(style, op_param, **kw)
 
     @staticmethod
     def _flatten(out):

@@ -25,7 +25,6 @@ from torch import nn
 from torch.nn import functional as F
 
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
-from .op import attn_stack
 from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
 from .op.layernorm import pixel_norm, sample_layer_norm
@@ -422,15 +421,9 @@ class Generator(nn.Module):                                                     
         if trans_interact:                                                           # :670-679
             eye = self.token_spatial.unsqueeze(0).expand(stylecode.shape[0], -1, -1)
             z0, p0 = torch.cat([stylecode, eye], 2), torch.cat([spatialcode, eye], 2)
-            if attn_stack.FUSED and attn_stack.supported(self.interact) and z0.is_cuda and z0.dtype == torch.float32:
-                # all n_trans blocks in one launch per direction (op/attn_stack.py; opt-in, see the note there)
-                x = attn_stack.attention_stack(z0, p0, spatialcode if self.n_trans > 1 else None,
-                                               [attn_stack.block_params(b) for b in self.interact], self.lr_mlp,
-                                               self.interact[0].atten.scale, second_order=_modconv_state['second_order'])
-            else:
-                x = self.interact[0](z0, p0)
-                for i in range(1, self.n_trans):
-                    x = self.interact[i](x, spatialcode)
+            x = self.interact[0](z0, p0)
+            for i in range(1, self.n_trans):
+                x = self.interact[i](x, spatialcode)
         if self.no_trans:                                                            # :682-688
             latent = self.adjust_style(stylecode.permute(0, 2, 1)).permute(0, 2, 1)
         elif not input_is_latent:

@@ -31,22 +31,42 @@ def image_transform(flip_probability=0.5):
     return run
 
 
+def _open_lmdb(path):
+    try:
+        import lmdb
+    except ImportError as e:          # same failure point as the reference's module-level import
+        raise ImportError('MultiResolutionDataset reads an LMDB environment: the `lmdb` package is required') from e
+    env = lmdb.open(path, max_readers=32, readonly=True, lock=False, readahead=False, meminit=False)
+    if not env:
+        raise IOError('Cannot open lmdb dataset', path)
+    return env
+
+
 class MultiResolutionDataset(Dataset):
     def __init__(self, path, transform, resolution=256):
-        if isinstance(path, (str, bytes)):
-            try:
-                import lmdb
-            except ImportError as e:          # same failure point as the reference's module-level import
-                raise ImportError('MultiResolutionDataset reads an LMDB environment: the `lmdb` package is required') from e
-            self.env = lmdb.open(path, max_readers=32, readonly=True, lock=False, readahead=False, meminit=False)
-        else:
-            self.env = path                   # an opened environment (anything with .begin(write=False) -> txn.get(key))
-        if not self.env:
-            raise IOError('Cannot open lmdb dataset', path)
+        # An LMDB environment must not cross a fork / be pickled into DataLoader workers: the path is kept and every
+        # process opens its own handle on first use (the reference runs num_workers=0, train_spatial_query.py:520-525, and
+        # never meets the problem; here decode runs in worker processes, see `data_loader`).
+        self._path = path if isinstance(path, (str, bytes)) else None
+        self._pid = None
+        self._env = None if self._path is not None else path       # an opened environment (.begin(write=False) -> txn.get(key))
         with self.env.begin(write=False) as txn:
             self.length = int(txn.get('length'.encode('utf-8')).decode('utf-8'))
         self.resolution = resolution
         self.transform = transform
+
+    @property
+    def env(self):
+        import os
+        if self._path is not None and (self._env is None or self._pid != os.getpid()):
+            self._env, self._pid = _open_lmdb(self._path), os.getpid()
+        return self._env
+
+    def __getstate__(self):                   # (spawned workers: the handle is re-opened on the other side)
+        st = dict(self.__dict__)
+        if self._path is not None:
+            st['_env'], st['_pid'] = None, None
+        return st
 
     def __len__(self):
         return self.length
@@ -64,6 +84,19 @@ class MultiResolutionDataset(Dataset):
         except Exception as e:                # reference behaviour: report, then serve a random other sample
             print(e)
             return self.__getitem__(random.randint(0, self.length - 1))
+
+
+def data_loader(dataset, batch_size, sampler=None, num_workers=4, drop_last=True):
+    """The reference's loader (train_spatial_query.py:520-525: batch_size, sampler, drop_last=True) with the decode moved
+    OFF the training process: `num_workers` worker processes (kept alive between epochs, two batches each in flight) decode
+    and normalise, pinned batches come back through shared memory; wrap the result in `DevicePrefetcher` for the
+    asynchronous host->device copy.  num_workers=0 reproduces the reference's in-process behaviour."""
+    from torch.utils.data import DataLoader
+    kw = dict(batch_size=batch_size, sampler=sampler, shuffle=sampler is None, drop_last=drop_last, num_workers=num_workers,
+              pin_memory=torch.cuda.is_available())
+    if num_workers > 0:
+        kw.update(persistent_workers=True, prefetch_factor=2)
+    return DataLoader(dataset, **kw)
 
 
 def sample_data(loader):
