@@ -12,6 +12,14 @@ sizes the GPU then waits for the host.  ``GeneratorSampler``:
   capture of the te_* launches on torch's capture stream) and replays it: one host call per batch instead of ~500.
 
 Same call surface as ``Generator.forward``; results are bit-identical to the eager frozen forward.
+
+Staleness contract.  Cached weights and captured graphs are validated against every parameter's (version counter, storage
+address) on each call.  A write that goes around autograd's bookkeeping is invisible to that check - the reference's own
+``accumulate()`` updates ``g_ema`` through ``.data`` (train_spatial_query.py:56-61) - so a sampler over a generator that is
+updated that way MUST call ``refresh()`` after the update (this repository's ``MultiTensorEMA`` / ``FusedAdam`` bump the
+counters themselves).  Tensor-valued keyword arguments (a ``truncation_latent``, explicit ``noise``) are never baked into a
+graph: such calls run eagerly (with the weight cache), so neither a fresh tensor per call nor an in-place edit of one can
+grow memory or replay stale values; the number of captured signatures is bounded (``max_graphs``, oldest dropped first).
 """
 import torch
 
@@ -19,11 +27,12 @@ from .op.modconv import frozen_weights
 
 
 class GeneratorSampler:
-    def __init__(self, generator, use_graph=True, copy_outputs=True):
+    def __init__(self, generator, use_graph=True, copy_outputs=True, max_graphs=8):
         """copy_outputs=False returns views of the graph's static output buffers (valid until the next call)."""
         self.g = generator.eval()
         self.use_graph = use_graph
         self.copy_outputs = copy_outputs
+        self.max_graphs = max_graphs
         self._cache = {}
         self._graphs = {}
         self._stamp = None
@@ -52,8 +61,8 @@ class GeneratorSampler:
     def __call__(self, style, op_param, **kw):
         if kw.get('noise') is not None or (self.g.layer_noise_injection and kw.get('randomize_noise', True)):
             return self.eager(style, op_param, **kw)           # per-call noise tensors: not a replayable graph
-        if not self.use_graph:
-            return self.eager(style, op_param, **kw)
+        if not self.use_graph or any(torch.is_tensor(v) or isinstance(v, (list, tuple, dict)) for v in kw.values()):
+            return self.eager(style, op_param, **kw)           # tensor-valued keywords are never captured (see the module docstring)
         stamp = self._weights_stamp()
         if stamp != self._stamp:                                # weights moved or were updated through autograd-visible ops
             self.refresh()
@@ -72,6 +81,8 @@ class GeneratorSampler:
             with torch.cuda.graph(graph):
                 out = self.eager(zs, ps, **kw)
             flat, rebuild = self._flatten(out)
+            while len(self._graphs) >= self.max_graphs:        # bounded: the oldest signature goes first
+                self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[key] = (graph, zs, ps, flat, rebuild)
         graph, zs, ps, flat, rebuild = ent
         zs.copy_(style)
