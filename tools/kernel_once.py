@@ -42,6 +42,11 @@ def main():
         _lib.bias_act_bwd(x, y, 0.2, 2 ** 0.5)
     for _ in range(REP):
         _lib.blur_actgrad(x, y, k, (1, 3, 1, 3), 0.2, 2 ** 0.5)                       # backward of blur + bias + act, one pass
+    kf = torch.flip(k, [0, 1]).contiguous()
+    for _ in range(REP):
+        _lib.upfirdn2d_raw(x, kf, (1, 1), (1, 1), (2, 2, 2, 2))                       # adjoint blur 256^2 -> 257^2
+    for _ in range(REP):
+        _lib.blur_gradact(t, y, kf, (1, 1, 1, 1), 0.2, 2 ** 0.5)                      # adjoint blur 257^2 -> 256^2 + activation gradient (D ResBlock)
     wr = torch.randn(3, 128, device=DEV)
     for _ in range(REP):
         r = _lib.rgb_fwd(x, wr, isc, bias[:3].contiguous())
@@ -49,6 +54,8 @@ def main():
         _lib.rgb_dgrad(r, wr, isc, 128)
     for _ in range(REP):
         _lib.rgb_wgrad_slabs(r, x)
+    for _ in range(REP):
+        _lib.bias_act_bwd_rgb(x, y, r, wr, isc, 1.0, 0.2, 2 ** 0.5)                   # activation gradient + ToRGB data gradient
     torch.cuda.synchronize()
 
 

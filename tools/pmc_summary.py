@@ -15,8 +15,11 @@ ALG = {
     'conv_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wgrad_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
-    'blur44_kernel<true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),
-    'blur44_kernel<false': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
+    'blur44_kernel<1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),       # AG: g + ref (256^2) -> 257^2
+    'blur44_kernel<2': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),       # gradact: g (257^2) + ref -> 256^2
+    'blur44_kernel<0, 2, true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),  # adjoint blur 256^2 -> 257^2
+    'blur44_kernel<0': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),           # blur + bias + lrelu 257^2 -> 256^2
+    'bias_act_bwd_rgb': dict(flops=0, bytes=(3 * 128 + 3) * 16 * 256 * 256 * 4),
     'fir_tile_kernel<1, 1, 4, 4, true': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),
     'fir_tile_kernel<1, 1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 256 * 256) * 4),
     'wgrad_reduce_fused': dict(flops=0, bytes=16 * 16 * 128 * 128 * 9 * 4),
@@ -45,7 +48,7 @@ def load(path):
     return agg, dur
 
 
-def main(src='gpurun_out/pmc', tag='profiles/r02'):
+def main(src='gpurun_out/pmc', tag='profiles/r03'):
     mf, dur = load(f'{src}/mfma_counter_collection.csv')
     fe, _ = load(f'{src}/fetch_counter_collection.csv')
     wr, _ = load(f'{src}/write_counter_collection.csv')

@@ -419,22 +419,44 @@ __global__ __launch_bounds__(256) void blur44_kernel(float* __restrict__ out, co
         for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) res[h][q] = 0.f;
+        // The extra column / row are BLOCK-uniform branches (last tile column / row only): three quarters of the blocks of a
+        // 257-wide plane run the plain 2 x 4 filter (128 multiply-adds per lane) instead of the 3 x 5 one (240) that round 2
+        // compiled into every lane of an EXT launch.
+        const bool ecol = EXT && p.ext_x && tid3.bx == p.tiles_x - 1;
+        const bool erow = EXT && p.ext_y && tid3.by == p.tiles_y - 1;
 #pragma unroll
-        for (int a = 0; a < NH + 3; ++a) {
-            if (a == 5 && !xrow) break;
+        for (int a = 0; a < 5; ++a) {
             const float* row = &sx[(2 * ty + a) * BST + tx];
             const f32x4v w0 = *reinterpret_cast<const f32x4v*>(row);
             const f32x4v w1 = *reinterpret_cast<const f32x4v*>(row + 4);
             const f32x4v w2 = *reinterpret_cast<const f32x4v*>(row + 8);
             const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
+            for (int h = 0; h < 2; ++h) {
                 const int ka = a - h;                 // tap row of output row h
                 if (ka < 0 || ka > 3) continue;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) res[h][q] += w[D + q + c] * kf[ka][c];
+                if (EXT && ecol) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) res[h][NQ - 1] += w[D + 4 + c] * kf[ka][c];
+                }
+            }
+        }
+        if (EXT && erow) {                            // third output row of the last tile row: input rows 2 .. 5
+#pragma unroll
+            for (int a = 2; a < 6; ++a) {
+                const float* row = &sx[(2 * ty + a) * BST + tx];
+                const f32x4v w0 = *reinterpret_cast<const f32x4v*>(row);
+                const f32x4v w1 = *reinterpret_cast<const f32x4v*>(row + 4);
+                const f32x4v w2 = *reinterpret_cast<const f32x4v*>(row + 8);
+                const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) res[NH - 1][q] += w[D + q + c] * kf[a - 2][c];
             }
         }
         const int ch = b ? (int)(mj % p.size_b) : 0;
