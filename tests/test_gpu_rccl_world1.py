@@ -53,14 +53,22 @@ def _run(force, real):
     synth.fill_state_dict(G.state_dict(), 40)
     synth.fill_state_dict(Dn.state_dict(), 41)
     ts = TrainStep(args, 'cuda', G.cuda(), Dn.cuda(), _Sampler(), force_sync=force)
-    info = {'hook_launches': 0, 'calls': 0}
+    info = {'hook_launches': 0, 'calls': 0, 'max_exchange_diff': 0.0}
     for sync in (ts.g_sync, ts.d_sync):
         orig = sync.all_reduce
 
         def wrapped(tag='default', _s=sync, _o=orig):
             info['calls'] += 1
             info['hook_launches'] += sum(w is not None for w in _s._work)      # buckets that left from the backward hooks
-            return _o(tag)
+            # the LOCAL gradients (still in .grad: the hooks only copied them into the buckets) before the exchange ...
+            local = [None if p.grad is None else p.grad.detach().clone() for p in _s.params]
+            out = _o(tag)
+            if force:
+                # ... and what the exchange hands to the optimiser: a sum over ONE rank divided by one is exact
+                for p, l in zip(_s.params, local):
+                    if l is not None:
+                        info['max_exchange_diff'] = max(info['max_exchange_diff'], float((p.grad - l).abs().max()))
+            return out
         sync.all_reduce = wrapped
     grads = {}
     for it in range(2):                     # iteration 0 learns the unused set, iteration 1 overlaps the exchange with backward
@@ -126,7 +134,8 @@ def test_gradsync_over_rccl_world1_matches_no_exchange():
     assert i0['hook_launches'] == 0                            # no group: GradSync is inert
     assert i1['calls'] == 8 and i1['hook_launches'] > 0, i1   # buckets left from the hooks while the backward was running
     assert in_bucket, '.grad must alias the all-reduced bucket (FusedAdam reads it there)'
-    for key in g0:
+    assert i1['max_exchange_diff'] == 0.0, i1           # every exchanged gradient bit-identical to the local one (all 8 calls)
+    for key in ('d0', 'r10', 'g0', 'path0'):            # (later steps of two separately evolving runs are not comparable: atomics + Adam)
         top = max(float(np.abs(a).max()) for a in g0[key] if a is not None)
         for i, (a, b) in enumerate(zip(g0[key], g1[key])):
             assert (a is None) == (b is None), (key, i)
@@ -134,12 +143,10 @@ def test_gradsync_over_rccl_world1_matches_no_exchange():
                 continue
             # sum over one rank / 1 is exact; what differs run to run is the atomic accumulation order of a few reducers
             # of the backward itself (and, from iteration 1 on, Adam's reaction to it: first steps move by lr * sign(g))
-            tol = 1e-5 if key == 'd0' else 2e-2
+            tol = 1e-5 if key == 'd0' else 5e-2
             assert float(np.abs(a - b).max()) <= tol * max(float(np.abs(a).max()), 1e-3 * top), (key, i)
     for net in ('g', 'd'):
-        moved = 0.0
         for a, b in zip(p0[net], p1[net]):
-            close = (np.abs(a - b) <= 1e-4 + 1e-3 * np.abs(a)).mean()
-            assert float(close) > 0.97, net
-            moved += float(np.abs(a - b).sum())
-        # (the optimiser really stepped in both runs: parameters differ from their initial fill)
+            assert np.isfinite(b).all()
+            close = (np.abs(a - b) <= 1e-3 + 1e-2 * np.abs(a)).mean()          # two runs, 8 Adam steps each: same trajectory
+            assert float(close) > 0.9, net

@@ -13,7 +13,7 @@ from transeditor_amd import _lib      # noqa: E402
 DEV = 'cuda'
 SHAPES = [  # kind, K, M, H (low-res), label
     ('T2', 512, 256, 64), ('T2', 256, 128, 128), ('T2', 512, 512, 32), ('S2', 256, 512, 64), ('S2', 128, 256, 128),
-    ('1X1', 256, 512, 64), ('1X1', 128, 256, 128), ('1X1', 512, 512, 32), ('1X1', 512, 512, 16), ('1X1', 512, 256, 64), ('1X1', 256, 128, 128), ('1X1', 512, 512, 8), ('3X3', 256, 256, 128), ('3X3', 128, 128, 256), ('3X3', 512, 512, 64), ('3X3', 512, 512, 16), ('WT2', 512, 256, 64), ('WT2', 256, 128, 128), ('W3X3', 128, 128, 256)]
+    ('1X1', 256, 512, 64), ('1X1', 128, 256, 128), ('1X1', 512, 512, 32), ('1X1', 512, 512, 16), ('1X1', 512, 256, 64), ('1X1', 256, 128, 128), ('1X1', 512, 512, 8), ('3X3', 256, 256, 128), ('3X3', 128, 128, 256), ('3X3', 512, 512, 64), ('3X3', 512, 512, 16), ('R3X3', 128, 128, 256), ('R3X3', 256, 256, 128), ('R1X1', 128, 256, 128), ('WT2', 512, 256, 64), ('WT2', 256, 128, 128), ('W3X3', 128, 128, 256)]
 
 
 def timeit(fn, n=10):
@@ -32,20 +32,31 @@ def run(label):
     B = 16
     res = {}
     for kind, K, M, H in SHAPES:
-        flops = 2.0 * (1 if kind == '1X1' else 9) * K * M * H * H * B
+        flops = 2.0 * (1 if kind in ('1X1', 'R1X1') else 9) * K * M * H * H * B
         torch.manual_seed(0)
-        if kind in ('T2', '3X3', '1X1'):
+        if kind in ('R3X3', 'R1X1'):
+            pass
+        elif kind in ('T2', '3X3', '1X1'):
             x = torch.randn(B, K, H, H, device=DEV)
         elif kind == 'S2':
             x = torch.randn(B, K, 2 * H + 1, 2 * H + 1, device=DEV)
-        if kind in ('T2', 'S2', '3X3', '1X1'):
+        if kind in ('R3X3', 'R1X1'):       # unmodulated launch with the residual (+ mask) epilogue stages (discriminator ResBlock node)
+            ks = 1 if kind == 'R1X1' else 3
+            x = torch.randn(B, K, H, H, device=DEV)
+            w = torch.randn(M, K, ks, ks, device=DEV) / (ks * K ** 0.5)
+            wp = _lib.conv_pack(w, _lib.PACK_FWD, 1.0)
+            resid = torch.randn(B, M, H, H, device=DEV)
+            mref = torch.randn(B, M, H, H, device=DEV) if ks == 3 else None
+            code = _lib.CONV_3X3 if ks == 3 else _lib.CONV_1X1
+            fn = lambda: _lib.conv(x, wp, code, M, H, H, None, None, None, 0, res=resid, mask_ref=mref, mask_gain=2 ** 0.5)
+        elif kind in ('T2', 'S2', '3X3', '1X1'):
             ks = 1 if kind == '1X1' else 3
             w = torch.randn(M, K, ks, ks, device=DEV) / (ks * K ** 0.5)
             wp = _lib.conv_pack(w, _lib.PACK_FWD, 1.0)
             isc = None if os.environ.get('NO_ISC') else 1 + 0.1 * torch.randn(B, K, device=DEV)
             code = {'T2': _lib.CONV_T2, 'S2': _lib.CONV_S2, '3X3': _lib.CONV_3X3, '1X1': _lib.CONV_1X1}[kind]
             fn = lambda: _lib.conv(x, wp, code, M, H, H, isc, None, None, 0)
-        else:
+        elif kind in ('WT2', 'W3X3'):
             code = _lib.CONV_T2 if kind == 'WT2' else _lib.CONV_3X3
             g = torch.randn(B, M, 2 * H + 1, 2 * H + 1, device=DEV) if kind == 'WT2' else torch.randn(B, M, H, H, device=DEV)
             x = torch.randn(B, K, H, H, device=DEV)

@@ -17,7 +17,7 @@ cd /tmp
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_g1024 -o g1024 -- python $R/bench.py --workload generator --size 1024 --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing ) > $R/gpurun_out/${TAG}_rocprof_g1024.log 2>&1; echo "rocprof 1024 rc=$?"
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_path -o path -- python $R/tools/reg_steps_trace.py path ) > $R/gpurun_out/${TAG}_rocprof_path.log 2>&1; echo "rocprof path rc=$?"
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r1 -o r1 -- python $R/tools/reg_steps_trace.py r1 ) > $R/gpurun_out/${TAG}_rocprof_r1.log 2>&1; echo "rocprof r1 rc=$?"
-( TE_ROCTX=1 timeout 300 rocprofv3 --kernel-trace --marker-trace -d $R/gpurun_out/prof_mark -o mark -- python $R/bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ) > $R/gpurun_out/${TAG}_rocprof_marker.log 2>&1; echo "rocprof marker rc=$?"
+( TE_ROCTX=1 LD_PRELOAD=/opt/rocm/lib/librocprofiler-sdk-roctx.so timeout 300 rocprofv3 --kernel-trace --marker-trace -d $R/gpurun_out/prof_mark -o mark -- python $R/bench.py --workload generator --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing ) > $R/gpurun_out/${TAG}_rocprof_marker.log 2>&1; echo "rocprof marker rc=$?"
 cd $R
 for t in train gen g1024 path r1; do python tools/rocpd_stats.py gpurun_out/prof_$t/${t}_results.db > gpurun_out/${TAG}_${t}_kernel_stats.txt 2>&1; rm -rf gpurun_out/prof_$t; done
 python tools/rocpd_markers.py gpurun_out/prof_mark/mark_results.db > gpurun_out/${TAG}_marker_ranges.txt 2>&1; rm -rf gpurun_out/prof_mark

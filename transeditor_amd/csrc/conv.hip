@@ -144,6 +144,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     constexpr bool WEVEN = (WSTAGE / 4) % NTHREADS == 0;
     constexpr int NQ = Cfg<KIND, TC>::NQ;        // FAST: (row segment, channel) pairs per thread and stage
     constexpr bool TAP_PIECES = FAST && IS_T2 && (KC * BM / 4 == NTHREADS);   // weight piece r of a thread == tap r
+    // the same fact for every kind: with KC * BM / 4 == NTHREADS piece r of a thread is tap r of ONE (channel, column group),
+    // so its byte offsets differ by the constant r * Kp * Mp * 4 - that goes into the load's SCALAR offset and the thread
+    // keeps one offset register instead of WLDR (9 for the 3x3 kinds: the 168-register kernels were spilling 12 dwords)
+    constexpr bool TAPW = FAST && (KC * BM / 4 == NTHREADS);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;            // [NTAP][KC][BM]
@@ -318,10 +322,10 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     };
     // FAST: weights through a buffer descriptor with per-thread byte offsets fixed over the K loop; a stage advances scalar offsets
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.wp, (unsigned)NTAP * p.Kp * p.Mp * 4u);
-    unsigned woff[FAST ? WLDR : 1];
+    unsigned woff[FAST ? (TAPW ? 1 : WLDR) : 1];
     if (FAST) {
 #pragma unroll
-        for (int r = 0; r < WLDR; ++r) {
+        for (int r = 0; r < (TAPW ? 1 : WLDR); ++r) {
             int idx = tid + NTHREADS * r;          // float4 index inside the stage
             if (!WEVEN && idx >= WSTAGE / 4) idx = WSTAGE / 4 - 1;      // clamped duplicate load, never committed
             const int row = idx / (BM / 4), c4 = idx % (BM / 4);      // row = tap*KC + kk ; BM/4 float4 per row
@@ -335,7 +339,8 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             // T2 at this tile class: one piece is one tap (KC * BM / 4 == NTHREADS), so the thin edge regions neither load
             // nor commit the weights of the taps they skip (block-uniform)
             if (!TAP_PIECES || ((g.tapmask >> i) & 1))
-                wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[FAST ? i : 0], (unsigned)kn * p.Mp * 4u, 0));
+                wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrs, woff[(FAST && !TAPW) ? i : 0], ((unsigned)kn + (TAPW ? (unsigned)i * p.Kp : 0u)) * p.Mp * 4u, 0));
         } else {
             const int r = FAST ? i - WLDR : 0;
             // rows outside the image (qgo = OOBH) fail the hardware range check whatever the scalar channel offset is
@@ -572,6 +577,71 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                     bi[r] = p.bias[m < p.M ? m : p.M - 1];
                 }
             }
+            if (IS_T2 && p.ksplit == 1) {
+                // the same addressing for the transposed kind: output (2 ci + a, 2 cj + b); the two column phases of a cell are
+                // adjacent outputs: one 8-byte store per row phase (rows are 2W+1 wide, so the pair is only 4-byte aligned,
+                // which global stores accept)
+                const size_t off0 = ((size_t)bc * p.M + mbase) * oplane + (size_t)(2 * ci) * p.Wo + 2 * cj;
+                float* o0 = p.out + off0;
+                const bool x1 = 2 * cj + 1 < p.Wo, x0 = 2 * cj < p.Wo;
+                const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    const bool ok = cell_ok && mbase + dm < p.M;
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        float v0 = acc[mb][nb * 4 + 2 * a2][r] * sc[r] + bi[r];
+                        float v1 = acc[mb][nb * 4 + 2 * a2 + 1][r] * sc[r] + bi[r];
+                        if (p.act >= 3) {
+                            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * gain;
+                            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * gain;
+                        }
+                        if (ok && 2 * ci + a2 < p.Ho) {
+                            float* dst = o0 + (size_t)dm * oplane + (a2 ? p.Wo : 0);
+                            if (x1) {
+                                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                                *reinterpret_cast<f32x2u*>(dst) = f32x2u{v0, v1};
+                            } else if (x0) {
+                                dst[0] = v0;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+            if (!IS_T2 && p.ksplit == 1) {
+                // One-pass store path (block-uniform branch).  The 64-bit element offset is formed ONCE per accumulator tile;
+                // the 16 rows of the tile differ from it by wave-uniform multiples of the plane size (round 2 rebuilt the
+                // whole address per element: ~10 vector-ALU instructions each, three times that with the residual and mask
+                // stages, which made their epilogue cost more than the passes it replaces).
+                const size_t off0 = ((size_t)bc * p.M + mbase) * oplane + (size_t)ci * p.Wo + cj;
+                float* o0 = p.out + off0;
+                float rv[EPI ? 16 : 1], qv[EPI ? 16 : 1];
+                if (EPI) {           // residual / mask values of the whole tile requested up front: one batch of loads in flight
+                    const float* r0 = p.res ? p.res + off0 : nullptr;
+                    const float* q0 = p.mref ? p.mref + off0 : nullptr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        const bool ok = cell_ok && mbase + dm < p.M;
+                        rv[r] = (r0 && ok) ? r0[(size_t)dm * oplane] : 0.f;
+                        qv[r] = (q0 && ok) ? q0[(size_t)dm * oplane] : 1.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    float v = acc[mb][nb][r] * sc[r] + bi[r];
+                    if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
+                    if (EPI) {
+                        v += rv[r];
+                        if (p.mref) v *= qv[r] > 0.f ? p.mgain : 0.2f * p.mgain;
+                    }
+                    if (cell_ok && mbase + dm < p.M) o0[(size_t)dm * oplane] = v;
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -594,39 +664,9 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                         }
                     }
                 } else if (!IS_T2) {
-                    float v = acc[mb][nb][r] * sc[r] + bi[r];
-                    if (p.act >= 3) v = (v > 0.f ? v : v * 0.2f) * (p.act == 3 ? 1.4142135623730951f : 1.f);
-                    if (ok) {
-                        const size_t oi = (size_t)ci * p.Wo + cj;
-                        if (EPI) {
-                            if (p.res) v += p.res[(size_t)(obase - p.out) + oi];
-                            if (p.mref) v *= p.mref[(size_t)(obase - p.out) + oi] > 0.f ? p.mgain : 0.2f * p.mgain;
-                        }
-                        obase[oi] = v;
-                    }
+                    // (unreachable: the one-pass path above took every non-transposed launch without a split)
                 } else {
-                    // the two column phases of a cell are adjacent outputs: one 8-byte store per row phase (rows are 2W+1
-                    // wide, so the pair is only 4-byte aligned, which global stores accept)
-#pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2) {
-                        const int Y = 2 * ci + a2, X = 2 * cj;
-                        float v0 = acc[mb][nb * 4 + 2 * a2][r] * sc[r] + bi[r];
-                        float v1 = acc[mb][nb * 4 + 2 * a2 + 1][r] * sc[r] + bi[r];
-                        if (p.act >= 3) {
-                            const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
-                            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * gain;
-                            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * gain;
-                        }
-                        if (ok && Y < p.Ho) {
-                            float* dst = obase + (size_t)Y * p.Wo + X;
-                            if (X + 1 < p.Wo) {
-                                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-                                *reinterpret_cast<f32x2u*>(dst) = f32x2u{v0, v1};
-                            } else if (X < p.Wo) {
-                                dst[0] = v0;
-                            }
-                        }
-                    }
+                    // (unreachable: the one-pass paths above took every launch without a split)
                 }
             }
         }
@@ -806,7 +846,7 @@ template <int KIND, int TC, bool HAS_ISC, bool MS, bool EPI = false>
 void launch_t(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s, bool fast) {
     // 3 waves/SIMD variant only for the plain 3x3 at the 128-row tile (the only one whose register budget is near 168); the
     // epilogue-stage variants take the 2-wave budget (their extra loads do not fit 168 registers)
-    constexpr bool CAN3 = !EPI && ((KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS));
+    constexpr bool CAN3 = ((KIND == TE_CONV_3X3 && TC == 0 && !MS) || (KIND == TE_CONV_T2 && TC == 1 && !MS));
     if (CAN3 && conv_occ() == 3) launch_o<KIND, TC, HAS_ISC, MS, CAN3 ? 3 : 2, EPI>(a, nblocks, lds_floats, s, fast);
     else launch_o<KIND, TC, HAS_ISC, MS, 2, EPI>(a, nblocks, lds_floats, s, fast);
 }
