@@ -642,31 +642,28 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 }
                 continue;
             }
+            // Split launches (small images): raw partial sums; scale / bias / activation happen in conv_finalize_kernel.  With a
+            // workspace every split writes its own slab (plain stores, summed in fixed order: deterministic); without one the
+            // splits meet in `out` through atomics.  Same addressing as above: one offset per tile, uniform row strides.
+            {
+                const size_t off0 = ((size_t)bc * p.M + mbase) * oplane + (size_t)(IS_T2 ? 2 * ci : ci) * p.Wo + (IS_T2 ? 2 * cj : cj);
+                float* b0 = p.ws ? p.ws + (size_t)blockIdx.z * p.B * p.M * oplane + off0 : p.out + off0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                const bool ok = cell_ok && m < p.M;
-                float* obase = p.out + ((size_t)bc * p.M + (m < p.M ? m : 0)) * oplane;
-                if (p.ksplit > 1) {      // partial sums, raw: scale / bias / activation happen in conv_finalize_kernel
-                    // with a workspace every split writes its own slab (plain stores, summed in fixed order: deterministic);
-                    // without one the splits meet in `out` through atomics
-                    float* pbase = p.ws ? p.ws + ((size_t)blockIdx.z * p.B * p.M + (size_t)bc * p.M + (m < p.M ? m : 0)) * oplane : obase;
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (!(cell_ok && mbase + dm < p.M)) continue;
+                    float* d = b0 + (size_t)dm * oplane;
                     if (!IS_T2) {
-                        if (ok) { if (p.ws) pbase[(size_t)ci * p.Wo + cj] = acc[mb][nb][r]; else atomicAdd(pbase + (size_t)ci * p.Wo + cj, acc[mb][nb][r]); }
+                        if (p.ws) d[0] = acc[mb][nb][r]; else atomicAdd(d, acc[mb][nb][r]);
                     } else {
 #pragma unroll
                         for (int ph = 0; ph < 4; ++ph) {
-                            const int Y = 2 * ci + (ph >> 1), X = 2 * cj + (ph & 1);
-                            if (ok && Y < p.Ho && X < p.Wo) {
-                                if (p.ws) pbase[(size_t)Y * p.Wo + X] = acc[mb][nb * 4 + ph][r];
-                                else atomicAdd(pbase + (size_t)Y * p.Wo + X, acc[mb][nb * 4 + ph][r]);
+                            if (2 * ci + (ph >> 1) < p.Ho && 2 * cj + (ph & 1) < p.Wo) {
+                                float* e = d + ((ph >> 1) ? p.Wo : 0) + (ph & 1);
+                                if (p.ws) e[0] = acc[mb][nb * 4 + ph][r]; else atomicAdd(e, acc[mb][nb * 4 + ph][r]);
                             }
                         }
                     }
-                } else if (!IS_T2) {
-                    // (unreachable: the one-pass path above took every non-transposed launch without a split)
-                } else {
-                    // (unreachable: the one-pass paths above took every launch without a split)
                 }
             }
         }

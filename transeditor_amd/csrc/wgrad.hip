@@ -763,7 +763,13 @@ extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
     const int64_t mn = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH) * (int64_t)B;
-    int64_t S = te::cdiv(2 * te::kNumCU, mn);     // aim at >= 2 blocks (of 8 waves) per CU
+    // blocks per CU the split aims at: the 8-wave 3x3 / T2 blocks own a CU (two 68 KB operand images), so ONE round of them
+    // does the same work as two with half the slab bytes for the reducer (same-box A/B, round 3: +0.8 % / +1.2 % on the
+    // kernels, half the te_wgrad_reduce traffic of the narrow layers); the light 1x1 blocks share a CU and want two
+#ifndef TE_WGRAD_ROUNDS
+#define TE_WGRAD_ROUNDS ((kind == TE_CONV_1X1) ? 2 : 1)
+#endif
+    int64_t S = te::cdiv((int64_t)TE_WGRAD_ROUNDS * te::kNumCU, mn);
     S = std::max<int64_t>(1, std::min<int64_t>(S, tiles));
     return (int)S;
 }
