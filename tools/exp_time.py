@@ -92,15 +92,25 @@ def fir_bench(label):
     f2 = lambda: _lib.upfirdn2d_raw(g, kf, (1, 1), (1, 1), (2, 2, 2, 2))
     f3 = lambda: _lib.blur_actgrad(g, y, kf, (2, 2, 2, 2), 0.2, 2 ** 0.5)
     f4 = lambda: _lib.bias_act_bwd(g, y, 0.2, 2 ** 0.5, want_bias=True)
+    # the same adjoint blur into rows of 260 floats (16-byte aligned rows): does the 257-wide output cost its row alignment?
+    f2a = lambda: _lib.upfirdn2d_raw(g, kf, (1, 1), (1, 1), (2, 5, 2, 2))
+    # which property of the 256 -> 257 direction costs 35 %?  255 -> 256 (aligned output rows, no extra row / column) and
+    # 252 -> 253 (unaligned output rows, no extra row / column), same taps and pads
+    g255, g252 = torch.randn(B, C, 255, 255, device=DEV), torch.randn(B, C, 252, 252, device=DEV)
+    f2b = lambda: _lib.upfirdn2d_raw(g255, kf, (1, 1), (1, 1), (2, 2, 2, 2))
+    f2c = lambda: _lib.upfirdn2d_raw(g252, kf, (1, 1), (1, 1), (2, 2, 2, 2))
     xs = torch.randn(B, C, H, H, device=DEV)
     f5 = lambda: _lib.upfirdn2d_raw(xs, k, (1, 1), (2, 2), (2, 2, 2, 2))       # D skip branch: blur + keep every 2nd pixel
     for name, fn, nbytes in (('blur+bias+lrelu 257->256', f1, 4 * (x.numel() + y.numel())),
                              ('adjoint blur 256->257', f2, 4 * (g.numel() + x.numel())),
+                             ('adjoint blur 256->257x260 (aligned rows)', f2a, 4 * (g.numel() + B * C * 257 * 260)),
+                             ('adjoint blur 255->256 (aligned out, no EXT)', f2b, 4 * B * C * (255 * 255 + 256 * 256)),
+                             ('adjoint blur 252->253 (unaligned out, no EXT)', f2c, 4 * B * C * (252 * 252 + 253 * 253)),
                              ('blur_actgrad (AG) 256->257', f3, 4 * (2 * g.numel() + x.numel())),
                              ('bias_act_bwd', f4, 4 * 3 * g.numel()),
                              ('blur-down2 256->128', f5, 4 * (xs.numel() + xs.numel() // 4))):
         ms = timeit(fn, 20)
-        print(f'[{label}] FIR {name:28s}: {ms * 1e3:8.1f} us  {nbytes / ms / 1e9:6.2f} TB/s algorithmic', flush=True)
+        print(f'[{label}] FIR {name:46s}: {ms * 1e3:8.1f} us  {nbytes / ms / 1e9:6.2f} TB/s algorithmic', flush=True)
 
 
 if __name__ == '__main__' and 'fir' in sys.argv:
