@@ -12,7 +12,7 @@ from transeditor_amd import _lib      # noqa: E402
 
 DEV = 'cuda'
 SHAPES = [  # kind, K, M, H (low-res), label
-    ('T2', 512, 256, 64), ('T2', 256, 128, 128), ('T2', 512, 512, 32), ('S2', 256, 512, 64), ('S2', 128, 256, 128),
+    ('T2', 512, 256, 64), ('T2', 256, 128, 128), ('T2', 512, 512, 32), ('T2', 512, 512, 16), ('T2', 512, 512, 8), ('T2', 512, 512, 4), ('3X3', 512, 512, 8), ('3X3', 512, 512, 4), ('S2', 512, 512, 8), ('S2', 512, 512, 4), ('S2', 256, 512, 64), ('S2', 128, 256, 128),
     ('1X1', 256, 512, 64), ('1X1', 128, 256, 128), ('1X1', 512, 512, 32), ('1X1', 512, 512, 16), ('1X1', 512, 256, 64), ('1X1', 256, 128, 128), ('1X1', 512, 512, 8), ('3X3', 256, 256, 128), ('3X3', 128, 128, 256), ('3X3', 512, 512, 64), ('3X3', 512, 512, 16), ('R3X3', 128, 128, 256), ('R3X3', 256, 256, 128), ('R1X1', 128, 256, 128), ('WT2', 512, 256, 64), ('WT2', 256, 128, 128), ('W3X3', 128, 128, 256)]
 
 

@@ -10,7 +10,20 @@ def main(path):
     tables = [r[0] for r in db.execute("select name from sqlite_master where type in ('table', 'view')") if '_0000' not in r[0]]
     agg = collections.defaultdict(lambda: [0, 0])
     used = None
-    for t in ('regions', 'regions_and_samples', 'rocpd_region') + tuple(tables):
+    # rocprofiler-sdk layout: view `regions`, category MARKER_CORE_RANGE_API, the roctx message inside the `extdata` JSON
+    if 'regions' in tables and 'extdata' in [r[1] for r in db.execute('pragma table_info(regions)')]:
+        import json
+        for ext, s_, e_ in db.execute("select extdata, start, end from regions where category like 'MARKER%'"):
+            try:
+                msg = json.loads(ext).get('message', '')
+            except (ValueError, TypeError):
+                continue
+            if msg.startswith('te:'):
+                used = 'regions.extdata'
+                op = msg.split(' ')[0]
+                agg[op][0] += 1
+                agg[op][1] += (e_ - s_)
+    for t in (() if used else ('regions', 'regions_and_samples', 'rocpd_region') + tuple(tables)):
         if t not in tables:
             continue
         cols = [r[1] for r in db.execute(f'pragma table_info({t})')]

@@ -941,6 +941,13 @@ extern "C" int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, i
     return te::launch_status("te_conv_pack_weights2_f32");
 }
 
+// transposed conv on images up to this many cells per side runs as ONE padded (H+1) x (W+1) region; larger ones as body +
+// last column + last row (build knob for A/B measurements; round 3: 16 -> 8, the 8x8 -> 17x17 layer filled 42 % of its
+// padded tiles: 152 -> 106 us at 512 -> 512, batch 16)
+#ifndef TE_T2_PAD_LIMIT
+#define TE_T2_PAD_LIMIT 8
+#endif
+
 // tile class + split-K plan of a launch (shared by te_conv_splitk_count and the launch itself)
 struct ConvPlan { int tc, ksplit, kchunk; };
 static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
@@ -961,7 +968,7 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     // split count comes from the real tile geometry of the main region and is shared by every region of the launch
     const int ntile = t2k ? (tc == 1 ? 64 : 128) : ((tc == 0 || (kind == TE_CONV_S2 && tc == 1)) ? 128 : 256);      // cells per block tile of the chosen tile class
     int rh = H, rw = W;
-    if (t2k && (W + 1 <= 16 || H + 1 <= 16)) { rh = H + 1; rw = W + 1; }
+    if (t2k && (W + 1 <= TE_T2_PAD_LIMIT || H + 1 <= TE_T2_PAD_LIMIT)) { rh = H + 1; rw = W + 1; }
     const int TW = std::min(32, pow2ceil(rw)), TH = std::min(pow2ceil(rh), ntile / TW), NS = ntile / (TW * TH);
     const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * te::cdiv(M, BM);
     const int stages = Kp / KC;
@@ -1024,7 +1031,7 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
         } break;
         default: {      // TE_CONV_T2
             a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
-            if (W + 1 <= 16 || H + 1 <= 16) {
+            if (W + 1 <= TE_T2_PAD_LIMIT || H + 1 <= TE_T2_PAD_LIMIT) {
                 const int r[1][4] = {{0, 0, H + 1, W + 1}};                       // small images: one padded region
                 rc = launch_regions<TE_CONV_T2>(a, r, 1, s, tc);
             } else {
