@@ -948,6 +948,13 @@ extern "C" int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, i
 #define TE_T2_PAD_LIMIT 8
 #endif
 
+#ifndef TE_SPLITK_MINSTAGES      // build knobs of the split-K plan: fewest stages a split keeps, blocks per CU it aims at
+#define TE_SPLITK_MINSTAGES 4
+#endif
+#ifndef TE_SPLITK_BLOCKS
+#define TE_SPLITK_BLOCKS 2
+#endif
+
 // tile class + split-K plan of a launch (shared by te_conv_splitk_count and the launch itself)
 struct ConvPlan { int tc, ksplit, kchunk; };
 static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
@@ -973,7 +980,7 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     const int64_t base_blocks = (int64_t)te::cdiv(rw, TW) * te::cdiv(rh, TH) * te::cdiv(B, NS) * te::cdiv(M, BM);
     const int stages = Kp / KC;
     int ks = 1;
-    if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(2 * te::kNumCU, base_blocks), std::max(1, stages / 2));
+    if (base_blocks < te::kNumCU) ks = (int)std::min<int64_t>(te::cdiv(TE_SPLITK_BLOCKS * te::kNumCU, base_blocks), std::max(1, stages / TE_SPLITK_MINSTAGES));
     pl.ksplit = std::max(1, ks);
     pl.kchunk = (int)te::cdiv(stages, pl.ksplit) * KC;
     pl.ksplit = (int)te::cdiv(Kp, pl.kchunk);
