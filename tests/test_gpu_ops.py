@@ -638,3 +638,40 @@ def test_chan_scale_pair_any_order(shape):
     got = run(xd, sd, gd, chan_scale, DEV, torch.float32)
     for name, a, b in zip(('y', 'gx', 'gs', 'ppx', 'pps', 'ppg'), got, ref):
         assert rel_err(a.double(), b) < 2e-5, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,widths', [(16, [512, 512, 512, 256, 256, 128, 128, 512]), (2, [64] * 18 + [32, 32]), (1, [512, 3, 512])])
+def test_batched_modulation_vs_single_layers(B, widths):
+    """op/modulation.py: all style modulations of a pass as a few batched launches against the per-layer EqualLinear calls
+    (model_spatial_query.py:286, 299): values, d latent (entries read by several layers accumulate), every dW / db; then the
+    recorded backward against the per-layer route."""
+    from transeditor_amd.model_spatial_query import EqualLinear
+    from transeditor_amd.op.modulation import batched_modulation, supported
+    L = 6
+    mods = []
+    for i, wd in enumerate(widths):
+        m = EqualLinear(512, wd, bias_init=1)
+        synth.fill_state_dict(m.state_dict(), 300 + i)
+        mods.append(m.to(DEV))
+    index = [i % L for i in range(len(widths))]
+    lat = synth.normal((B, L, 512), 'bm.lat').to(DEV).requires_grad_(True)
+    assert supported(lat, mods)
+    got = batched_modulation(lat, mods, index)
+    ref = [m(lat[:, i]) for m, i in zip(mods, index)]
+    gys = [synth.normal(tuple(r.shape), f'bm.g{j}').to(DEV) for j, r in enumerate(ref)]
+    for a, b in zip(got, ref):
+        assert tuple(a.shape) == tuple(b.shape) and rel_err(a, b) < 1e-5
+    params = [p for m in mods for p in (m.weight, m.bias)]
+    ga = torch.autograd.grad(got, [lat] + params, gys)
+    gb = torch.autograd.grad(ref, [lat] + params, gys)
+    for j, (a, b) in enumerate(zip(ga, gb)):
+        assert rel_err(a, b) < 2e-5, j
+    # recorded backward: || d(sum_j <s_j, g_j>) / d lat ||^2 differentiated w.r.t. the weights
+    lat2 = lat.detach().clone().requires_grad_(True)
+    g1, = torch.autograd.grad(batched_modulation(lat2, mods, index), lat2, gys, create_graph=True)
+    g2, = torch.autograd.grad([m(lat2[:, i]) for m, i in zip(mods, index)], lat2, gys, create_graph=True)
+    wa = torch.autograd.grad(g1.square().sum(), [m.weight for m in mods])
+    wb = torch.autograd.grad(g2.square().sum(), [m.weight for m in mods])
+    for a, b in zip(wa, wb):
+        assert rel_err(a, b) < 1e-4

@@ -31,7 +31,7 @@ from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused
 from .op.modconv import modconv, _STATE as _modconv_state
 from .op.resblock import resblock
-from .op import styled_rgb
+from .op import modulation, styled_rgb
 from .op.stddev import minibatch_stddev
 from .op.style import demod
 from .op.token_mlp import token_mlp
@@ -214,9 +214,11 @@ class ModulatedConv2d(nn.Module):                                               
         d = demod(w, s, self.scale, self.eps) if self.demodulate else None
         return w, s, d
 
-    def forward(self, input, style, bias=None, act=False):
-        """`bias`/`act` (extensions used by StyledConv / ToRGB) fuse '+ bias' and the scaled leaky-ReLU."""
-        s = self.modulation(style)
+    def forward(self, input, style, bias=None, act=False, s=None):
+        """`bias`/`act` (extensions used by StyledConv / ToRGB) fuse '+ bias' and the scaled leaky-ReLU.  `s`: the style scale
+        `self.modulation(style)` when the caller already has it (Generator batches all modulations of a pass, op/modulation.py)."""
+        if s is None:
+            s = self.modulation(style)
         w = self.weight.view(self.weight.shape[1:])
         eps = self.eps if self.demodulate else None          # demodulation is computed inside the modconv node
         if self.downsample:                                  # :323-329: blur, then the stride-2 convolution without padding
@@ -267,13 +269,13 @@ class StyledConv(nn.Module):                                                    
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, s=None):
         if self.layer_noise_injection:
-            return self.activate(self.noise(self.conv(input, style), noise=noise))
+            return self.activate(self.noise(self.conv(input, style, s=s), noise=noise))
         a = self.activate
         if a.bias is not None and a.negative_slope == 0.2 and abs(a.scale - 2 ** 0.5) < 1e-12:
-            return self.conv(input, style, bias=a.bias, act=True)       # bias + lrelu fused into the conv / blur kernel
-        return a(self.conv(input, style))
+            return self.conv(input, style, bias=a.bias, act=True, s=s)       # bias + lrelu fused into the conv / blur kernel
+        return a(self.conv(input, style, s=s))
 
 
 class ToRGB(nn.Module):                                                              # :406-425
@@ -284,8 +286,8 @@ class ToRGB(nn.Module):                                                         
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None):
-        out = self.conv(input, style, bias=self.bias.view(3))
+    def forward(self, input, style, skip=None, s=None):
+        out = self.conv(input, style, bias=self.bias.view(3), s=s)
         if skip is not None:
             out = out + self.upsample(skip)
         return out
@@ -363,7 +365,7 @@ class Generator(nn.Module):                                                     
             noises += [torch.randn(1, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
         return noises
 
-    def _conv_rgb(self, conv, to_rgb, x, style_c, style_r, skip, noise):
+    def _conv_rgb(self, conv, to_rgb, x, style_c, style_r, skip, noise, s_c=None, s_r=None):
         """`out = conv(x, style_c); skip = to_rgb(out, style_r, skip)` (:702-714).  In a training forward the plain StyledConv
         and the ToRGB reading it run as one autograd node (op/styled_rgb.py): the ToRGB data gradient is folded into the
         convolution's activation-gradient pass instead of a pass + a gradient-accumulation add of its own."""
@@ -374,11 +376,12 @@ class Generator(nn.Module):                                                     
                 and not _modconv_state.frozen_on and m.kind == '3x3' and m.demodulate and not to_rgb.conv.demodulate
                 and to_rgb.conv.kind == '1x1' and a.bias is not None and a.negative_slope == 0.2
                 and abs(a.scale - 2 ** 0.5) < 1e-12 and styled_rgb.supported(x, w, wr)):
-            out, rgb = styled_rgb.styled_conv_rgb(x, w, m.modulation(style_c), a.bias, wr, to_rgb.conv.modulation(style_r),
+            out, rgb = styled_rgb.styled_conv_rgb(x, w, m.modulation(style_c) if s_c is None else s_c, a.bias, wr,
+                                                  to_rgb.conv.modulation(style_r) if s_r is None else s_r,
                                                   to_rgb.bias.view(3), m.scale, m.eps, to_rgb.conv.scale)
             return out, (rgb if skip is None else rgb + to_rgb.upsample(skip))
-        out = conv(x, style_c, noise=noise)
-        return out, to_rgb(out, style_r, skip)
+        out = conv(x, style_c, noise=noise, s=s_c)
+        return out, to_rgb(out, style_r, skip, s=s_r)
 
     def _map_tokens(self, net, codes, n_map):
         """:626-646 — PixelNorm, then token i through its own EqualLinear + fused lrelu: all tokens of a network in one
@@ -442,13 +445,26 @@ class Generator(nn.Module):                                                     
         # per-layer styles latent[:, i]: one contiguous copy + one unbind, so the backward is a single stack instead of
         # a zero-fill + add of the whole latent per layer
         lat = latent.contiguous().unbind(1)
-        out, skip = self._conv_rgb(self.conv1, self.to_rgb1, out, lat[0], lat[1], None, noise[0])
+        # every style modulation of the pass up front, as a few batched launches (op/modulation.py); sm[j] = the scale of the
+        # j-th modulated convolution in execution order, None when the batched form does not apply
+        mods, index = [self.conv1.conv.modulation, self.to_rgb1.conv.modulation], [0, 1]
         i = 1
+        for conv_up, conv, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            mods += [conv_up.conv.modulation, conv.conv.modulation, to_rgb.conv.modulation]
+            index += [i, i + 1, i + 2]
+            i += 2
+        if not _modconv_state['second_order'] and modulation.supported(latent, mods):
+            sm = modulation.batched_modulation(latent.contiguous(), mods, index)
+        else:
+            sm = [None] * len(mods)
+        out, skip = self._conv_rgb(self.conv1, self.to_rgb1, out, lat[0], lat[1], None, noise[0], sm[0], sm[1])
+        i, j = 1, 2
         for conv_up, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                  self.to_rgbs):
-            out = conv_up(out, lat[i], noise=n1)
-            out, skip = self._conv_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], skip, n2)
+            out = conv_up(out, lat[i], noise=n1, s=sm[j])
+            out, skip = self._conv_rgb(conv, to_rgb, out, lat[i + 1], lat[i + 2], skip, n2, sm[j + 1], sm[j + 2])
             i += 2
+            j += 3
         image = skip
 
         if return_style:
