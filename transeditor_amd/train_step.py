@@ -110,9 +110,9 @@ class TrainStep:
         self.sampler = sampler if sampler is not None else RandomSampler(args, device)
         self._packs = {}
         self.mean_path_length = 0
-        self.mean_path_length_avg = 0
+        self._mpl_avg = 0
         self.mean_spatial_path_length = 0
-        self.mean_spatial_path_length_avg = 0
+        self._mspl_avg = 0
         self.accum = 0.5 ** (32 / (10 * 1000))
         D.broadcast_module(self.generator)
         D.broadcast_module(self.discriminator)
@@ -176,7 +176,9 @@ class TrainStep:
         weighted.backward()
         self.g_sync.all_reduce('path')
         self.g_optim.step()
-        self.mean_path_length_avg = D.reduce_sum(self.mean_path_length).item() / D.get_world_size()
+        # :249 — the reference reads this scalar back with .item() right here (a host-device sync in the middle of the step that
+        # leaves the GPU waiting for the next step's first launches); it is only ever logged, so the read-back happens on access
+        self._mpl_avg = D.reduce_sum(self.mean_path_length)
         self.loss.update(path=path_loss.detach(), path_length=path_lengths.mean().detach())
 
     def spatial_step(self):
@@ -203,8 +205,19 @@ class TrainStep:
         weighted.backward()
         self.g_sync.all_reduce('spatial')
         self.g_optim.step()
-        self.mean_spatial_path_length_avg = D.reduce_sum(self.mean_spatial_path_length).item() / D.get_world_size()
+        self._mspl_avg = D.reduce_sum(self.mean_spatial_path_length)
         self.loss.update(spatial_path=loss.detach(), spatial_path_length=lengths.mean().detach())
+
+    @property
+    def mean_path_length_avg(self):
+        """mean path length over ranks (train_spatial_query.py:249-251), read back from the device when asked for"""
+        v = self._mpl_avg
+        return (float(v) if torch.is_tensor(v) else v) / D.get_world_size()
+
+    @property
+    def mean_spatial_path_length_avg(self):
+        v = self._mspl_avg
+        return (float(v) if torch.is_tensor(v) else v) / D.get_world_size()
 
     # ---- checkpoints in the reference's layout (train_spatial_query.py:361-371 writes, :478-492 / test_spatial_query.py:285 read)
     def checkpoint(self):
