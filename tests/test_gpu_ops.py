@@ -675,3 +675,43 @@ def test_batched_modulation_vs_single_layers(B, widths):
     wb = torch.autograd.grad(g2.square().sum(), [m.weight for m in mods])
     for a, b in zip(wa, wb):
         assert rel_err(a, b) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,K,J,n', [((16, 16, 512), 512, 128, 7), ((16, 16, 128), 128, 128, 2), ((3, 5, 64), 64, 32, 3),
+                                         ((2, 1200, 64), 64, 16, 2)])
+def test_shared_input_linears_vs_single_layers(shape, K, J, n):
+    """op/linear.py::shared_input_linears - the key / value projections of an attention block and the query projections of
+    blocks 1..7 (model_spatial_query.py:889-890, :675-678) as one launch - against the per-layer EqualLinear calls: values,
+    dx (the sum over the layers), every dW / db, and the recorded backward."""
+    from transeditor_amd.model_spatial_query import EqualLinear
+    from transeditor_amd.op.linear import shared_input_linears, _SharedInputLinears
+    mods = []
+    for i in range(n):
+        m = EqualLinear(K, J)
+        synth.fill_state_dict(m.state_dict(), 400 + i)
+        mods.append(m.to(DEV))
+    x = synth.normal(shape, 'sil.x').to(DEV).requires_grad_(True)
+    got = shared_input_linears(x, mods)
+    assert got[0].grad_fn is not None and 'SharedInputLinears' in type(got[0].grad_fn).__name__
+    ref = [m(x) for m in mods]
+    gys = [synth.normal(tuple(r.shape), f'sil.g{j}').to(DEV) for j, r in enumerate(ref)]
+    for a, b in zip(got, ref):
+        assert tuple(a.shape) == tuple(b.shape) and rel_err(a, b) < 1e-5
+    params = [p for m in mods for p in (m.weight, m.bias)]
+    ga = torch.autograd.grad(got, [x] + params, gys)
+    gb = torch.autograd.grad(ref, [x] + params, gys)
+    for j, (a, b) in enumerate(zip(ga, gb)):
+        assert rel_err(a, b) < 2e-5, j
+    # only some outputs used downstream (the others get zero gradients from autograd)
+    ga = torch.autograd.grad(shared_input_linears(x, mods)[0].square().sum(), [x, mods[0].weight])
+    gb = torch.autograd.grad(mods[0](x).square().sum(), [x, mods[0].weight])
+    for a, b in zip(ga, gb):
+        assert rel_err(a, b) < 2e-5
+    x2 = x.detach().clone().requires_grad_(True)
+    g1, = torch.autograd.grad(shared_input_linears(x2, mods), x2, gys, create_graph=True)
+    g2, = torch.autograd.grad([m(x2) for m in mods], x2, gys, create_graph=True)
+    wa = torch.autograd.grad(g1.square().sum(), [m.weight for m in mods])
+    wb = torch.autograd.grad(g2.square().sum(), [m.weight for m in mods])
+    for a, b in zip(wa, wb):
+        assert rel_err(a, b) < 1e-4

@@ -28,7 +28,7 @@ from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
 from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
 from .op.layernorm import pixel_norm, sample_layer_norm
-from .op.linear import linear_fused
+from .op.linear import linear_fused, shared_input_linears
 from .op.modconv import modconv, _STATE as _modconv_state
 from .op.resblock import resblock
 from .op import modulation, styled_rgb
@@ -425,8 +425,10 @@ class Generator(nn.Module):                                                     
             eye = self.token_spatial.unsqueeze(0).expand(stylecode.shape[0], -1, -1)
             z0, p0 = torch.cat([stylecode, eye], 2), torch.cat([spatialcode, eye], 2)
             x = self.interact[0](z0, p0)
-            for i in range(1, self.n_trans):
-                x = self.interact[i](x, spatialcode)
+            if self.n_trans > 1:          # P is never updated between blocks (:675-678): every later block's query projection
+                qs = shared_input_linears(spatialcode, [self.interact[i].atten.q_transform for i in range(1, self.n_trans)])
+                for i in range(1, self.n_trans):
+                    x = self.interact[i](x, spatialcode, q=qs[i - 1])
         if self.no_trans:                                                            # :682-688
             latent = self.adjust_style(stylecode.permute(0, 2, 1)).permute(0, 2, 1)
         elif not input_is_latent:
@@ -631,9 +633,12 @@ class Attention(nn.Module):                                                     
         self.v_transform = EqualLinear(in_dim, self.planes, lr_mul=lr_mul)
         self.proj = EqualLinear(self.planes, out_dim, lr_mul=lr_mul)
 
-    def forward(self, attention, op_param, return_similarity=False, residual=None):
-        q = self.q_transform(op_param)                     # [N, M, planes]; head g = channels g*gp..
-        k, v = self.k_transform(attention), self.v_transform(attention)
+    def forward(self, attention, op_param, return_similarity=False, residual=None, q=None):
+        """`q` (extension used by Generator): `self.q_transform(op_param)` when the caller already has it (the blocks after the
+        first all project the same P code: one batched launch, op/linear.py::shared_input_linears)."""
+        if q is None:
+            q = self.q_transform(op_param)                 # [N, M, planes]; head g = channels g*gp..
+        k, v = shared_input_linears(attention, [self.k_transform, self.v_transform])      # same input: one launch
         # softmax(scale q k^T) v per head; the reference's reshape(N, planes, L).permute(0,2,1) (:894, with
         # L == M) lands exactly on this token-major [N, M, planes] layout
         stacked, similarity = attention_core(q, k, v, self.scale, self.groups)
@@ -651,9 +656,9 @@ class AttentionBlock(nn.Module):                                                
         if out_dim != in_dim:
             self.proj = EqualLinear(in_dim, out_dim, lr_mul=lr_mul)
 
-    def forward(self, x, op_param, return_similarity=False):
+    def forward(self, x, op_param, return_similarity=False, q=None):
         skip = self.proj(x) if self.out_dim != self.in_dim else x
-        a = self.atten(sample_layer_norm(x), op_param, return_similarity=return_similarity, residual=skip)
+        a = self.atten(sample_layer_norm(x), op_param, return_similarity=return_similarity, residual=skip, q=q)
         x, similarity = a if return_similarity else (a, None)           # x = skip + attention (:926-930)
         h = self.mlp[0](sample_layer_norm(x), act='gelu')      # Linear + GELU, then Linear + skip (:932-934)
         x = self.mlp[2](h, residual=x)

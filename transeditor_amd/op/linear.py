@@ -189,3 +189,81 @@ def linear_fused(x, weight, bias=None, alpha=1.0, beta=1.0, act=None, residual=N
         # the caller announced a create_graph backward (regulariser steps): build the differentiable form right away
         return _closed_expr(x, weight, bias, alpha, beta, act, residual)
     return _Linear.apply(x, weight, bias, residual, alpha, beta, act)
+
+
+# ------------------------------------------------------------------------------------------------ several layers, one input
+class _SharedInputLinears(Function):
+    """y_z = alpha * x W_z^T + beta * b_z for nz <= 16 EqualLinear layers of equal shape that read the SAME input, as one
+    batched launch (te_small_gemm_batched_f32 with a zero operand stride for x): the key / value projections of an
+    attention block (model_spatial_query.py:889-890) and the query projections of all blocks after the first, which every
+    block applies to the same P code (:675-678).  Backward: one batched launch for the nz weight gradients, one for the
+    nz input-gradient slabs + their sum, bias gradients as one reduction."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, beta, nz, *params):
+        weights, biases = params[:nz], params[nz:]
+        J, K = weights[0].shape
+        x2 = x.reshape(-1, K).contiguous()
+        R = x2.shape[0]
+        buf = torch.empty(nz, R, J, device=x.device, dtype=x.dtype)
+        base_w, base_b = weights[0].data_ptr(), biases[0].data_ptr()
+        _lib.small_gemm_batched(buf, x2, weights[0], biases[0], nz, 0, R * J, R, J, K, K, 1, 1, K, J, 1,
+                                b_tab=[(w.data_ptr() - base_w) // 4 for w in weights],
+                                bias_tab=[(b.data_ptr() - base_b) // 4 for b in biases], alpha=alpha, beta=beta, act=0)
+        ctx.save_for_backward(x, *params)
+        ctx.cfg = (alpha, beta, nz)
+        return tuple(buf[z].reshape(*x.shape[:-1], J) for z in range(nz))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, *params = ctx.saved_tensors
+        alpha, beta, nz = ctx.cfg
+        weights, biases = params[:nz], params[nz:]
+        need = ctx.needs_input_grad
+        J, K = weights[0].shape
+        if torch.is_grad_enabled():              # recorded backward: layer by layer through the closed trio
+            with torch.enable_grad():
+                xa = x.view_as(x)
+                pa = [p.view_as(p) for p in params]
+                ys = [_closed_expr(xa, pa[z], pa[nz + z], alpha, beta, None, None) for z in range(nz)]
+                ins = [t for t, f in zip([xa] + pa, [need[0]] + list(need[4:])) if f]
+                res = iter(torch.autograd.grad(ys, ins, list(gs), create_graph=True, allow_unused=True))
+            gx = next(res) if need[0] else None
+            return (gx, None, None, None) + tuple(next(res) if f else None for f in need[4:])
+        x2 = x.reshape(-1, K).contiguous()
+        R = x2.shape[0]
+        g = torch.stack([t.reshape(R, J) for t in gs])                      # [nz, R, J]
+        gx = None
+        if need[0]:          # slab_z[r, k] = alpha * sum_j g[z, r, j] W_z[j, k];  dx = sum_z slab_z
+            base_w = weights[0].data_ptr()
+            slabs = torch.empty(nz, R, K, device=g.device, dtype=g.dtype)
+            _lib.small_gemm_batched(slabs, g, weights[0], None, nz, R * J, R * K, R, K, J, J, 1, K, 1, K, 1,
+                                    b_tab=[(w.data_ptr() - base_w) // 4 for w in weights], alpha=alpha)
+            gx = (slabs.sum(dim=0) if nz > 1 else slabs[0]).reshape(x.shape)
+        gws, gbs = [None] * nz, [None] * nz
+        if any(need[4:4 + nz]):      # dW_z[j, k] = alpha * sum_r g[z, r, j] x[r, k]   (reduction over the rows: split when tall)
+            if R <= MAX_K:
+                gw = torch.empty(nz, J, K, device=g.device, dtype=g.dtype)
+                _lib.small_gemm_batched(gw, g, x2, None, nz, R * J, J * K, J, K, R, 1, J, K, 1, K, 1, zb=0, alpha=alpha)
+                gws = [gw[z] if need[4 + z] else None for z in range(nz)]
+            else:
+                gws = [_LinDw.apply(g[z], x2, alpha) if need[4 + z] else None for z in range(nz)]
+        if any(need[4 + nz:]):
+            gb = g.sum(dim=1)
+            gb = gb * beta if beta != 1.0 else gb
+            gbs = [gb[z] if need[4 + nz + z] else None for z in range(nz)]
+        return (gx, None, None, None) + tuple(gws) + tuple(gbs)
+
+
+def shared_input_linears(x, mods):
+    """[m(x) for m in mods] for EqualLinear modules of equal shape without activation, as one launch when the batched
+    kernel applies (fp32 on the GPU, <= 16 layers, reduction <= MAX_K, not inside second_order())."""
+    m0 = mods[0]
+    ok = (x.is_cuda and x.dtype == torch.float32 and 1 < len(mods) <= 16 and m0.weight.shape[1] <= MAX_K
+          and not _modconv_state.second_order
+          and all(m.activation is None and m.bias is not None and m.weight.shape == m0.weight.shape and m.scale == m0.scale
+                  and m.lr_mul == m0.lr_mul and m.weight.is_contiguous() and m.bias.is_contiguous() for m in mods))
+    if not ok:
+        return [m(x) for m in mods]
+    return list(_SharedInputLinears.apply(x, float(m0.scale), float(m0.lr_mul), len(mods), *[m.weight for m in mods],
+                                          *[m.bias for m in mods]))
