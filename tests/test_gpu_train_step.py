@@ -203,3 +203,28 @@ def test_spatial_path_regulariser_matches_reference(golden, space):
             if abs(got - w) / w > 5e-3:          # second-order quantity of a squared deviation: 5x the first-order bar (as the path-length test)
                 bad.append((n, got, float(w)))
     assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize('size,B', [(32, 4), (64, 8), (256, 16)])
+def test_discriminator_joint_pass_equals_two_passes(size, B):
+    """Discriminator.forward(cat([fake, real]), chunks=2) - how d_step runs train_spatial_query.py:190-191 - against the two
+    separate passes: predictions (the minibatch-stddev statistic must stay per pass, model_spatial_query.py:844-852), the
+    logistic loss and every parameter gradient; and the switch `d_joint=False` restores the two-pass form."""
+    from transeditor_amd.model_spatial_query import Discriminator
+    from transeditor_amd.train_step import d_logistic_loss
+    torch.manual_seed(5)
+    D = Discriminator(size).to(DEV)
+    synth.fill_state_dict(D.state_dict(), 77)
+    fake, real = torch.randn(B, 3, size, size, device=DEV), torch.randn(B, 3, size, size, device=DEV).clamp(-1, 1)
+    params = list(D.parameters())
+    fp, rp = D(torch.cat([fake, real]), chunks=2).chunk(2)
+    fp2, rp2 = D(fake), D(real)
+    assert rel_err(fp, fp2) < 1e-5 and rel_err(rp, rp2) < 1e-5
+    mixed = D(torch.cat([fake, real]))[:B]                  # one minibatch of 2B: the statistic mixes the passes
+    assert rel_err(mixed, fp2) > 1e-5
+    ga = torch.autograd.grad(d_logistic_loss(rp, fp), params)
+    gb = torch.autograd.grad(d_logistic_loss(rp2, fp2), params)
+    for (n, _), a, b in zip(D.named_parameters(), ga, gb):
+        assert rel_err(a, b) < 2e-4, n
+    with pytest.raises(ValueError):
+        D(torch.cat([fake, real])[:2 * B - 1], chunks=2)

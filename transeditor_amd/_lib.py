@@ -455,21 +455,28 @@ def small_gemm_splitk(I, J, K, S, a, sai, sak, b, sbk, sbj, bias=None, residual=
     return c, pre
 
 
-def minibatch_stddev_fwd(x, group, eps):
-    """x [B, C, H, W] -> y [B, C + 1, H, W] (input copied, stddev channel appended)"""
+def minibatch_stddev_fwd(x, group, eps, chunks=1):
+    """x [B, C, H, W] -> y [B, C + 1, H, W] (input copied, stddev channel appended); `chunks` > 1: the batch is `chunks`
+    independent minibatches laid end to end (one launch each on its slice)"""
     x = x.contiguous()
     B, Cn, H, W = x.shape
     y = torch.empty(B, Cn + 1, H, W, device=x.device, dtype=x.dtype)
-    _check(lib().te_minibatch_stddev_fwd_f32(_ptr(y), _ptr(x), B, group, Cn, H * W, eps, _stream()), 'te_minibatch_stddev_fwd_f32')
+    Bc = B // chunks
+    for c in range(chunks):
+        _check(lib().te_minibatch_stddev_fwd_f32(_ptr(y[c * Bc:(c + 1) * Bc]), _ptr(x[c * Bc:(c + 1) * Bc]), Bc, group, Cn, H * W, eps,
+                                                 _stream()), 'te_minibatch_stddev_fwd_f32')
     return y
 
 
-def minibatch_stddev_bwd(gy, x, group, eps):
+def minibatch_stddev_bwd(gy, x, group, eps, chunks=1):
     gy = gy.contiguous()
     B, Cn, H, W = x.shape
     gx = torch.empty_like(x)
-    _check(lib().te_minibatch_stddev_bwd_f32(_ptr(gx), _ptr(gy), _ptr(x), B, group, Cn, H * W, eps, _stream()),
-           'te_minibatch_stddev_bwd_f32')
+    Bc = B // chunks
+    for c in range(chunks):
+        sl = slice(c * Bc, (c + 1) * Bc)
+        _check(lib().te_minibatch_stddev_bwd_f32(_ptr(gx[sl]), _ptr(gy[sl]), _ptr(x[sl]), Bc, group, Cn, H * W, eps, _stream()),
+               'te_minibatch_stddev_bwd_f32')
     return gx
 
 

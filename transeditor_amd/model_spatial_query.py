@@ -605,7 +605,12 @@ class Discriminator(nn.Module):                                                 
                 and abs(st[1].scale - 2 ** 0.5) < 1e-12 and input.shape[1] == 3 and st[0].weight.shape[0] <= 512
                 and (input.shape[2] * input.shape[3]) % 4 == 0 and self.convs[1].fusable(input))
 
-    def forward(self, input):
+    def forward(self, input, chunks=1):
+        """`chunks` (extension; 1 = the reference's forward): `input` holds that many independent minibatches of equal size
+        laid end to end, and the minibatch-stddev statistic (:844-852) - the only place where the samples of a batch meet -
+        is formed inside each of them:  D(cat([fake, real]), chunks=2) == cat([D(fake), D(real)]).  The discriminator step
+        (train_spatial_query.py:190-192) runs its two passes as one this way: half the launches, and the 4x4 - 16x16 layers
+        see 32 samples instead of 16."""
         if self._stem_fusable(input):
             out = self.convs[1](input, stem=self.convs[0])
             for m in list(self.convs)[2:]:
@@ -614,7 +619,7 @@ class Discriminator(nn.Module):                                                 
             out = self.convs(input)
         batch = out.shape[0]
         # :844-852 minibatch stddev + concat: one launch (op/stddev.py)
-        out = minibatch_stddev(out, self.stddev_group, self.stddev_feat, second_order=_modconv_state['second_order'])
+        out = minibatch_stddev(out, self.stddev_group, self.stddev_feat, second_order=_modconv_state['second_order'], chunks=chunks)
         out = self.final_conv(out)
         return self.final_linear(out.view(batch, -1))
 

@@ -32,7 +32,8 @@ def default_args(**kw):
     """The reference's CLI defaults that matter for one iteration (train_spatial_query.py:377-433)."""
     a = dict(size=256, batch=16, para_num=16, latent=512, r1=10.0, path_regularize=2.0, path_batch_shrink=2,
              d_reg_every=16, g_reg_every=4, lr=0.002, channel_multiplier=2, num_trans=8, pixel_norm_op_dim=1,
-             spatial_regu=False, regu_sapce='p+', spatial_path_regularize=2.0)       # (`regu_sapce`: the reference's spelling, :406)
+             spatial_regu=False, regu_sapce='p+', spatial_path_regularize=2.0,      # (`regu_sapce`: the reference's spelling, :406)
+             d_joint=True)       # extension: D's fake and real passes as one batch of 2B (Discriminator.forward(chunks=2))
     a.update(kw)
     a['token'] = 2 * (int(math.log2(a['size'])) - 1)
     return SimpleNamespace(**a)
@@ -128,7 +129,11 @@ class TrainStep:
         requires_grad(Dn, True)
         noise, param = self.sampler.latents(a.batch)
         fake_img, _, _ = G(noise, param)                                     # G frozen: no graph is built
-        fake_pred, real_pred = Dn(fake_img), Dn(real_img)
+        if getattr(a, 'd_joint', True) and fake_img.shape == real_img.shape:
+            # the two passes of train_spatial_query.py:190-191 as one batch of 2B; the minibatch-stddev statistic stays per pass
+            fake_pred, real_pred = Dn(torch.cat([fake_img, real_img]), chunks=2).chunk(2)
+        else:
+            fake_pred, real_pred = Dn(fake_img), Dn(real_img)
         d_loss = d_logistic_loss(real_pred, fake_pred)
         self.loss.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
         Dn.zero_grad()
