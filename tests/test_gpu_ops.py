@@ -265,7 +265,8 @@ def test_discriminator_conv_kinds_fused_bias_act(kind, shape):
 @pytest.mark.parametrize('shape', [(16, 512, 512, 9), (3, 40, 24, 9), (2, 3, 130, 1), (64, 128, 256, 9)])
 def test_demod_kernels(shape):
     """d = rsqrt(sum (wscale w s)^2 + eps) (model_spatial_query.py:300-304): forward, gw / gs, and the recorded backward."""
-    from transeditor_amd.op.style import _torch_expr, demod
+    from transeditor_amd.op.style import demod
+    from plain_torch import demod as _torch_expr
     B, Co, Ci, T = shape
     k = 3 if T == 9 else 1
     w = synth.normal((Co, Ci, k, k), 'dm.w').requires_grad_(True)
@@ -377,19 +378,34 @@ def test_modulated_conv2d_downsample_golden(golden, name):
 
 
 # ------------------------------------------------------------------------------------------------ F2
-def test_attention_core_vs_torch():
-    from transeditor_amd.op.attention import attention_core, _torch_expr
-    q, k, v = (synth.normal((5, 16, 128), f'at.{n}').requires_grad_(True) for n in 'qkv')
-    scale = 128 ** -0.5 * 3.0
-    o_ref, sim_ref = _torch_expr(q, k, v, scale, 4)
-    go, gs = synth.normal((5, 16, 128), 'at.go'), synth.normal((5, 4, 16, 16), 'at.gs')
-    ref = torch.autograd.grad([o_ref, sim_ref], (q, k, v), [go, gs])
+@pytest.mark.parametrize('N,M,L,C', [(5, 16, 16, 128), (16, 16, 16, 128), (1, 16, 16, 128)])
+def test_attention_core_vs_torch(N, M, L, C):
+    """attention core (model_spatial_query.py:888-894) against the einsum / softmax restatement (tests/plain_torch.py):
+    values, first-order gradients (kernel), and the recorded backward (closed batched-GEMM family of op/linear.py::_Bmm +
+    framework softmax) through a second differentiation w.r.t. q, k and v."""
+    from transeditor_amd.op.attention import attention_core
+    from plain_torch import attention_core as plain
+    q = synth.normal((N, M, C), 'at.q').requires_grad_(True)
+    k, v = (synth.normal((N, L, C), f'at.{n}').requires_grad_(True) for n in 'kv')
+    scale = C ** -0.5 * 3.0
+    o_ref, sim_ref = plain(q.double(), k.double(), v.double(), scale, 4)
+    go, gs = synth.normal((N, M, C), 'at.go'), synth.normal((N, 4, M, L), 'at.gs')
+    ref = torch.autograd.grad([o_ref, sim_ref], (q, k, v), [go.double(), gs.double()])
     d = [t.detach().to(DEV).requires_grad_(True) for t in (q, k, v)]
     o, sim = attention_core(d[0], d[1], d[2], scale, 4)
-    assert rel_err(o, o_ref) < OP_TOL and rel_err(sim, sim_ref) < OP_TOL
+    assert rel_err(o, o_ref.float()) < OP_TOL and rel_err(sim, sim_ref.float()) < OP_TOL
     got = torch.autograd.grad([o, sim], d, [go.to(DEV), gs.to(DEV)])
     for a, b in zip(got, ref):
-        assert rel_err(a, b) < 1e-4
+        assert rel_err(a, b.float()) < 1e-4
+
+    def second(f, qkv, go, gs):
+        o, sim = f(*qkv, scale, 4)
+        g1 = torch.autograd.grad([o, sim], qkv, [go, gs], create_graph=True)
+        return torch.autograd.grad(sum(t.square().sum() for t in g1), qkv)
+    want = second(plain, [t.detach().double().requires_grad_(True) for t in (q, k, v)], go.double(), gs.double())
+    got = second(attention_core, d, go.to(DEV), gs.to(DEV))
+    for a, b in zip(got, want):
+        assert rel_err(a, b.float()) < 2e-4
 
 
 @pytest.mark.parametrize('name,cin', [('b0_528', 528), ('b_512', 512)])
@@ -426,7 +442,8 @@ LINEAR_CASES = [   # rows-shape, K, N, act, residual, bias
 @pytest.mark.gpu
 @pytest.mark.parametrize('rows,K,N,act,use_res,use_bias', LINEAR_CASES)
 def test_linear_fused_matches_torch(rows, K, N, act, use_res, use_bias):
-    from transeditor_amd.op.linear import _torch_expr, linear_fused
+    from transeditor_amd.op.linear import linear_fused
+    from plain_torch import equal_linear as _torch_expr
     g = torch.Generator().manual_seed(K * 7 + N)
     dev = 'cuda'
     x = torch.randn(*rows, K, generator=g).to(dev).requires_grad_(True)
@@ -457,13 +474,14 @@ def test_linear_fused_matches_torch(rows, K, N, act, use_res, use_bias):
 
 @pytest.mark.gpu
 def test_linear_fused_strided_rows():
-    from transeditor_amd.op.linear import _torch_expr, linear_fused
+    from transeditor_amd.op.linear import linear_fused
+    from plain_torch import equal_linear as _torch_expr
     g = torch.Generator().manual_seed(3)
     lat = torch.randn(16, 14, 512, generator=g).cuda().requires_grad_(True)
     w = torch.randn(64, 512, generator=g).cuda().requires_grad_(True)
     b = torch.randn(64, generator=g).cuda()
     y = linear_fused(lat[:, 5], w, b, 0.04, 1.0)
-    y_ref = _torch_expr(lat[:, 5], w, b, 0.04, 1.0, None, None)
+    y_ref = _torch_expr(lat[:, 5], w, b, 0.04, 1.0)
     assert rel_err(y, y_ref) < 1e-5
     gy = torch.randn(16, 64, generator=g).cuda()
     for a_, b_ in zip(torch.autograd.grad(y, (lat, w), gy), torch.autograd.grad(y_ref, (lat, w), gy)):
@@ -475,7 +493,8 @@ def test_linear_fused_strided_rows():
 def test_minibatch_stddev_kernel(B, C, H):
     """D1: minibatch stddev + concat as one launch vs the reference formula (model_spatial_query.py:844-852): forward,
     backward, and the recorded (R1) backward through the torch expression."""
-    from transeditor_amd.op.stddev import _torch_expr, minibatch_stddev
+    from transeditor_amd.op.stddev import minibatch_stddev
+    from plain_torch import minibatch_stddev as _torch_expr
     x = synth.normal((B, C, H, H), f'sd.x.{B}').to(DEV).requires_grad_(True)
     group = min(B, 4)
     y = minibatch_stddev(x, 4)
@@ -496,8 +515,9 @@ def test_minibatch_stddev_kernel(B, C, H):
 @pytest.mark.parametrize('B,D,Cn,T', [(16, 512, 16, 16), (3, 96, 8, 5), (33, 64, 16, 16)])
 def test_token_mlp_batched_launch(B, D, Cn, T):
     """one launch for the T per-token EqualLinear + fused lrelu layers (model_spatial_query.py:626-646): values, every
-    gradient and the recorded backward against the per-token torch expression in fp64 / fp32."""
-    from transeditor_amd.op.token_mlp import _torch_expr, token_mlp
+    gradient and the recorded backward against the per-token F.linear restatement (tests/plain_torch.py) in fp64 / fp32."""
+    from transeditor_amd.op.token_mlp import token_mlp
+    from plain_torch import token_mlp as _torch_expr
     g = torch.Generator().manual_seed(B * 100 + D)
     x = torch.randn(B, D, Cn, generator=g).cuda().requires_grad_(True)
     ws = [(torch.randn(D, D, generator=g) / 0.01).cuda().requires_grad_(True) for _ in range(T)]
@@ -546,7 +566,8 @@ def test_sample_layer_norm_kernels(shape):
 @pytest.mark.parametrize('shape,dim', [((16, 512, 16), 1), ((3, 40, 8), 1), ((4, 512, 16), 2), ((2, 7, 5), 1)])
 def test_pixel_norm_kernels(shape, dim):
     """PixelNorm (model_spatial_query.py:80-81): kernel path for [B, D, C] / dim 1, torch expression otherwise."""
-    from transeditor_amd.op.layernorm import _pixel_norm_expr, pixel_norm
+    from transeditor_amd.op.layernorm import pixel_norm
+    from plain_torch import pixel_norm as _pixel_norm_expr
     g = torch.Generator().manual_seed(sum(shape) + dim)
     x = torch.randn(*shape, generator=g).cuda().requires_grad_(True)
     gy = torch.randn(*shape, generator=g).cuda()
@@ -715,3 +736,29 @@ def test_shared_input_linears_vs_single_layers(shape, K, J, n):
     wb = torch.autograd.grad(g2.square().sum(), [m.weight for m in mods])
     for a, b in zip(wa, wb):
         assert rel_err(a, b) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('Z,I,J,K', [(64, 16, 16, 32), (3, 37, 5, 70), (16, 16, 512, 512)])
+def test_bmm_closed_family(Z, I, J, K, ta, tb):
+    """op/linear.py::bmm - the batched product the recorded backward of the attention core / token-wise mapping is built from -
+    against torch.matmul in fp64 for all four transposition forms: value, both gradients, and a second differentiation (every
+    derivative is another member of the family, so this walks all of its branches)."""
+    from transeditor_amd.op.linear import bmm
+    a = synth.normal((Z, K, I) if ta else (Z, I, K), 'bmm.a').to(DEV).requires_grad_(True)
+    b = synth.normal((Z, J, K) if tb else (Z, K, J), 'bmm.b').to(DEV).requires_grad_(True)
+    gc = synth.normal((Z, I, J), 'bmm.g').to(DEV)
+
+    def plain(a, b):
+        return 0.37 * torch.matmul(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b)
+
+    def run(f, a, b, gc):
+        c = f(a, b)
+        ga, gb = torch.autograd.grad(c, (a, b), gc, create_graph=True)
+        return (c, ga, gb) + torch.autograd.grad(ga.square().sum() + (gb * gb.detach().roll(1, 0)).sum(), (a, b))
+    want = run(plain, a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True), gc.double())
+    got = run(lambda a, b: bmm(a, b, ta, tb, 0.37), a, b, gc)
+    grow = max(1.0, math.sqrt(K / 512))
+    for name, x, y in zip(('c', 'ga', 'gb', 'gga', 'ggb'), got, want):
+        assert rel_err(x, y.float()) < 3e-5 * grow, name

@@ -228,3 +228,28 @@ def test_discriminator_joint_pass_equals_two_passes(size, B):
         assert rel_err(a, b) < 2e-4, n
     with pytest.raises(ValueError):
         D(torch.cat([fake, real])[:2 * B - 1], chunks=2)
+
+
+def test_path_step_latent_hint_changes_nothing():
+    """second_order(wrt='latent') - the mapping networks / attention blocks / adjust_style keep their fused first-order nodes
+    because the recorded backward of the path-length regulariser stops at the latent (train_spatial_query.py:92-105, 226-250) -
+    against the plain second_order() route: penalty, path lengths and every parameter gradient."""
+    from transeditor_amd.model_spatial_query import Generator
+    from transeditor_amd.op.modconv import second_order
+    from transeditor_amd.train_step import g_path_regularize
+    torch.manual_seed(11)
+    G = Generator(64, 512, 512, 10, n_trans=8, pixel_norm_op_dim=1).to(DEV)
+    z, p = torch.randn(4, 512, 16, device=DEV), torch.randn(4, 512, 16, device=DEV)
+    pl_noise = torch.randn(4, 3, 64, 64, device=DEV)
+    res = []
+    for wrt in (None, 'latent'):
+        G.zero_grad()
+        with second_order(wrt=wrt):
+            img, latents, _ = G(z, p, return_latents=True, randomize_noise=False)
+        loss, _, lengths = g_path_regularize(img, latents, torch.zeros((), device=DEV), pl_noise)
+        (loss + 0 * img[0, 0, 0, 0]).backward()
+        res.append((loss.detach(), lengths.detach(), {n: q.grad.clone() for n, q in G.named_parameters() if q.grad is not None}))
+    assert rel_err(res[1][0], res[0][0]) < 1e-5 and rel_err(res[1][1], res[0][1]) < 1e-5
+    assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) > 200
+    for n in res[0][2]:
+        assert rel_err(res[1][2][n], res[0][2][n]) < 5e-4, n

@@ -29,7 +29,7 @@ from .op.attention import attention_core
 from .op.fir_act import blur_bias_act
 from .op.layernorm import pixel_norm, sample_layer_norm
 from .op.linear import linear_fused, shared_input_linears
-from .op.modconv import modconv, _STATE as _modconv_state
+from .op.modconv import latent_producer_section, modconv, _STATE as _modconv_state
 from .op.resblock import resblock
 from .op import modulation, styled_rgb
 from .op.stddev import minibatch_stddev
@@ -404,41 +404,43 @@ class Generator(nn.Module):                                                     
         if input_is_latent:
             use_spatial_mapping, use_style_mapping, trans_interact = True, False, False
 
-        spatialcode = (self._map_tokens(self.spatial_mapping_network, op_param, self.num_spatial_mapping)
-                       if use_spatial_mapping else op_param)
-        stylecode = (self._map_tokens(self.style_mapping_network, style, self.num_style_mapping)
-                     if use_style_mapping else style)
-        if return_mapped_codes:
-            return stylecode, spatialcode
-        if return_only_mapped_p:
-            return spatialcode
-        if return_only_mapped_z:
-            return stylecode
+        # everything that PRODUCES the latent; under second_order(wrt='latent') it keeps its fused first-order nodes
+        with latent_producer_section():
+            spatialcode = (self._map_tokens(self.spatial_mapping_network, op_param, self.num_spatial_mapping)
+                           if use_spatial_mapping else op_param)
+            stylecode = (self._map_tokens(self.style_mapping_network, style, self.num_style_mapping)
+                         if use_style_mapping else style)
+            if return_mapped_codes:
+                return stylecode, spatialcode
+            if return_only_mapped_p:
+                return spatialcode
+            if return_only_mapped_z:
+                return stylecode
 
-        if noise is None:                                                            # :658-664
-            noise = ([None] * self.num_layers if randomize_noise
-                     else [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)])
+            if noise is None:                                                        # :658-664
+                noise = ([None] * self.num_layers if randomize_noise
+                         else [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)])
 
-        stylecode, spatialcode = stylecode.permute(0, 2, 1), spatialcode.permute(0, 2, 1)   # [B,16,512]
-        x = None
-        if trans_interact:                                                           # :670-679
-            eye = self.token_spatial.unsqueeze(0).expand(stylecode.shape[0], -1, -1)
-            z0, p0 = torch.cat([stylecode, eye], 2), torch.cat([spatialcode, eye], 2)
-            x = self.interact[0](z0, p0)
-            if self.n_trans > 1:          # P is never updated between blocks (:675-678): every later block's query projection
-                qs = shared_input_linears(spatialcode, [self.interact[i].atten.q_transform for i in range(1, self.n_trans)])
-                for i in range(1, self.n_trans):
-                    x = self.interact[i](x, spatialcode, q=qs[i - 1])
-        if self.no_trans:                                                            # :682-688
-            latent = self.adjust_style(stylecode.permute(0, 2, 1)).permute(0, 2, 1)
-        elif not input_is_latent:
-            if x is None:
-                # same failure as the reference (:686 reads `x`, which :675 never assigned)
-                raise UnboundLocalError("local variable 'x' referenced before assignment (trans_interact=False on a "
-                                        "generator built with no_trans=False, as in the reference)")
-            latent = self.adjust_style(x.permute(0, 2, 1)).permute(0, 2, 1)
-        else:
-            latent = style
+            stylecode, spatialcode = stylecode.permute(0, 2, 1), spatialcode.permute(0, 2, 1)   # [B,16,512]
+            x = None
+            if trans_interact:                                                           # :670-679
+                eye = self.token_spatial.unsqueeze(0).expand(stylecode.shape[0], -1, -1)
+                z0, p0 = torch.cat([stylecode, eye], 2), torch.cat([spatialcode, eye], 2)
+                x = self.interact[0](z0, p0)
+                if self.n_trans > 1:          # P is never updated between blocks (:675-678): every later block's query projection
+                    qs = shared_input_linears(spatialcode, [self.interact[i].atten.q_transform for i in range(1, self.n_trans)])
+                    for i in range(1, self.n_trans):
+                        x = self.interact[i](x, spatialcode, q=qs[i - 1])
+            if self.no_trans:                                                            # :682-688
+                latent = self.adjust_style(stylecode.permute(0, 2, 1)).permute(0, 2, 1)
+            elif not input_is_latent:
+                if x is None:
+                    # same failure as the reference (:686 reads `x`, which :675 never assigned)
+                    raise UnboundLocalError("local variable 'x' referenced before assignment (trans_interact=False on a "
+                                            "generator built with no_trans=False, as in the reference)")
+                latent = self.adjust_style(x.permute(0, 2, 1)).permute(0, 2, 1)
+            else:
+                latent = style
         if return_only_style_latent or return_only_style:
             return latent
 

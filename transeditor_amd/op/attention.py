@@ -9,17 +9,20 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .linear import bmm
 
 
 def _torch_expr(q, k, v, scale, groups):
+    """the same function for the recorded backward: the two batched products on the closed small-GEMM family
+    (op/linear.py::_Bmm, any order on our kernel), softmax and the head reshapes as framework elementwise ops"""
     N, M, C = q.shape
     L, D = k.shape[1], C // groups
-    qh = q.reshape(N, M, groups, D).permute(0, 2, 1, 3)
-    kh = k.reshape(N, L, groups, D).permute(0, 2, 1, 3)
-    vh = v.reshape(N, L, groups, D).permute(0, 2, 1, 3)
-    sim = torch.softmax(torch.matmul(qh, kh.transpose(2, 3)) * scale, dim=3)
-    o = torch.matmul(sim, vh).permute(0, 2, 1, 3).reshape(N, M, C)
-    return o, sim
+    qh = q.reshape(N, M, groups, D).permute(0, 2, 1, 3).reshape(N * groups, M, D)
+    kh = k.reshape(N, L, groups, D).permute(0, 2, 1, 3).reshape(N * groups, L, D)
+    vh = v.reshape(N, L, groups, D).permute(0, 2, 1, 3).reshape(N * groups, L, D)
+    sim = torch.softmax(bmm(qh, kh, False, True, scale), dim=2)                      # [N*G, M, L]
+    o = bmm(sim, vh).reshape(N, groups, M, D).permute(0, 2, 1, 3).reshape(N, M, C)
+    return o, sim.reshape(N, groups, M, L)
 
 
 class _AttnCore(Function):

@@ -99,6 +99,48 @@ class _LinDw(Function):
         return g_g, g_x, None
 
 
+class _Bmm(Function):
+    """C_z = alpha * op_a(A_z) op_b(B_z) over a leading batch dimension, on te_small_gemm_batched_f32; a, b are [Z, ., .] and
+    `ta` / `tb` say which of them is read transposed.  The family is closed under differentiation (every gradient below is
+    another _Bmm), so the recorded backward of the attention core (q k^T, sim v), of the token-wise mapping network and of
+    anything else built from batched products stays on our kernel to any order - no library GEMM (torch.bmm / matmul)."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        Z, p, q = a.shape
+        _, r, t = b.shape
+        I, K = (q, p) if ta else (p, q)
+        K2, J = (t, r) if tb else (r, t)
+        if K != K2 or b.shape[0] != Z:
+            raise ValueError(f'te_hip: batched product of {tuple(a.shape)} (transposed={ta}) and {tuple(b.shape)} (transposed={tb})')
+        c = torch.empty(Z, I, J, device=a.device, dtype=a.dtype)
+        sai, sak = (1, q) if ta else (q, 1)
+        sbk, sbj = (1, t) if tb else (t, 1)
+        _lib.small_gemm_batched(c, a, b, None, Z, p * q, I * J, I, J, K, sai, sak, sbk, sbj, J, 1, zb=r * t, alpha=alpha)
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (ta, tb, alpha)
+        return c
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.cfg
+        ga = gb = None
+        if ctx.needs_input_grad[0]:      # d op_a(A) = gC op_b(B)^T
+            ga = _Bmm.apply(b, gc, tb, True, alpha) if ta else _Bmm.apply(gc, b, False, not tb, alpha)
+        if ctx.needs_input_grad[1]:      # d op_b(B) = op_a(A)^T gC
+            gb = _Bmm.apply(gc, a, True, ta, alpha) if tb else _Bmm.apply(a, gc, not ta, False, alpha)
+        return ga, gb, None, None, None
+
+
+def bmm(a, b, ta=False, tb=False, alpha=1.0):
+    """alpha * op_a(a) @ op_b(b) for [Z, ., .] fp32 tensors on the GPU, differentiable to any order on our own kernel"""
+    if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
+        raise RuntimeError('te_hip: expected fp32 tensors on the GPU (no CPU path exists)')
+    return _Bmm.apply(a, b, bool(ta), bool(tb), float(alpha))
+
+
 def _closed_expr(x, weight, bias, alpha, beta, act, residual):
     """the same function as the fused launch, built from any-order differentiable pieces that run on our kernels"""
     N, K = weight.shape
@@ -109,7 +151,7 @@ def _closed_expr(x, weight, bias, alpha, beta, act, residual):
         y = fused_leaky_relu(y2, None if bias is None else (bias * beta if beta != 1.0 else bias)).reshape(y.shape)
     else:
         if bias is not None:
-            y = y + (bias * beta if beta != 1.0 else bias)
+            y = torch.add(y, bias, alpha=beta)
         if act == 'gelu':
             y = F.gelu(y)
     return y if residual is None else y + residual

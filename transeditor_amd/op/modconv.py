@@ -60,6 +60,7 @@ class _Local(threading.local):
 
     def __init__(self):
         self.second_order = False
+        self.second_wrt = None               # second_order(wrt=...): where the recorded backward will stop
         self.graph = _DEFAULT_GRAPH          # token of the current / most recent second_order() context of this thread
         self.frozen_on = False
         self.frozen_cache = None
@@ -83,17 +84,36 @@ def current_graph():
 
 
 @contextlib.contextmanager
-def second_order():
+def second_order(wrt=None):
     """Forward passes inside this context are built from the any-order differentiable pieces right away (the caller knows
-    a create_graph backward follows), which saves the forward recomputation inside the recorded backward."""
-    old = (_STATE.second_order, _STATE.graph)
-    _STATE.second_order, _STATE.graph = True, _Graph()
+    a create_graph backward follows), which saves the forward recomputation inside the recorded backward.
+    `wrt='latent'`: the recorded backward will stop at the generator's W+ latent (path-length regulariser,
+    train_spatial_query.py:92-105 with `return_latents=True`), so everything that PRODUCES the latent - mapping networks,
+    attention blocks, adjust_style - is differentiated once only and keeps its fused first-order nodes
+    (Generator.forward suspends the hint for that section)."""
+    old = (_STATE.second_order, _STATE.graph, _STATE.second_wrt)
+    _STATE.second_order, _STATE.graph, _STATE.second_wrt = True, _Graph(), wrt
     try:
         yield _STATE.graph
     finally:
         _STATE.second_order = old[0]         # (the token stays current for the no_weight_grads() that follows the forward)
+        _STATE.second_wrt = old[2]
         if old[0]:
             _STATE.graph = old[1]
+
+
+@contextlib.contextmanager
+def latent_producer_section():
+    """Generator.forward wraps the part that produces the latent in this: under second_order(wrt='latent') the hint is off
+    inside (see there); otherwise nothing changes."""
+    if not (_STATE.second_order and _STATE.second_wrt == 'latent'):
+        yield
+        return
+    _STATE.second_order = False
+    try:
+        yield
+    finally:
+        _STATE.second_order = True
 
 
 @contextlib.contextmanager

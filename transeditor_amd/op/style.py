@@ -8,10 +8,14 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from .linear import _LinFwd
 
 
 def _torch_expr(w, s, wscale, eps):
+    """the same function for the recorded backward; the [B,Ci] x [Ci,Co] product on the closed small-GEMM trio"""
     wsq = (w * wscale).pow(2).sum(dim=(2, 3))
+    if s.is_cuda and s.dtype == torch.float32:
+        return torch.rsqrt(_LinFwd.apply(s.pow(2), wsq, 1.0) + eps)
     return torch.rsqrt(s.pow(2) @ wsq.t() + eps)
 
 

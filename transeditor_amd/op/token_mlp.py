@@ -14,6 +14,7 @@ from torch.autograd import Function
 
 from .. import _lib
 from .fused_act import fused_leaky_relu
+from .linear import bmm
 
 
 def _torch_expr(x, weights, biases, scale, lr_mul):
@@ -21,7 +22,7 @@ def _torch_expr(x, weights, biases, scale, lr_mul):
     T = len(weights)
     W = torch.stack(list(weights)) * scale                              # [T, out, in]
     bias = torch.cat(list(biases)) * lr_mul
-    y = torch.bmm(x[:, :, :T].permute(2, 0, 1), W.transpose(1, 2))      # [T, B, out]
+    y = bmm(x[:, :, :T].permute(2, 0, 1), W, False, True)               # [T, B, out]  (closed family: any order on our kernel)
     B, D = y.shape[1], y.shape[2]
     return fused_leaky_relu(y.permute(1, 0, 2).reshape(B, T * D), bias).view(B, T, D)
 

@@ -170,7 +170,7 @@ class TrainStep:
         G, a = self.generator, self.args
         n = max(1, a.batch // a.path_batch_shrink)
         noise, param = self.sampler.latents(n)
-        with second_order():
+        with second_order(wrt='latent'):          # the recorded backward stops at `latents`: only the synthesis needs the any-order route
             fake_img, latents, _ = G(noise, param, return_latents=True)
         path_loss, self.mean_path_length, path_lengths = g_path_regularize(
             fake_img, latents, self.mean_path_length, self.sampler.randn_like(fake_img))
