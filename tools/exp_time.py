@@ -16,6 +16,12 @@ SHAPES = [  # kind, K, M, H (low-res), label
     ('1X1', 256, 512, 64), ('1X1', 128, 256, 128), ('1X1', 512, 512, 32), ('1X1', 512, 512, 16), ('1X1', 512, 256, 64), ('1X1', 256, 128, 128), ('1X1', 512, 512, 8), ('3X3', 256, 256, 128), ('3X3', 128, 128, 256), ('3X3', 512, 512, 64), ('3X3', 512, 512, 16), ('R3X3', 128, 128, 256), ('R3X3', 256, 256, 128), ('R1X1', 128, 256, 128), ('WT2', 512, 256, 64), ('WT2', 256, 128, 128), ('W3X3', 128, 128, 256)]
 
 
+if os.environ.get('SMALL'):      # the layers <= 16^2 only (split-K plan experiments)
+    SHAPES = [s for s in SHAPES if s[3] <= 16 and s[0] in ('T2', 'S2', '3X3', '1X1')] + [
+        ('3X3', 512, 512, 16), ('S2', 512, 512, 16), ('W3X3', 512, 512, 16), ('W3X3', 512, 512, 8), ('W3X3', 512, 512, 4),
+        ('WT2', 512, 512, 16), ('WT2', 512, 512, 8), ('WT2', 512, 512, 4)]
+
+
 def timeit(fn, n=10):
     fn()
     torch.cuda.synchronize()

@@ -59,12 +59,19 @@ namespace {
 #ifndef TE_FAST_IL           // the global loads of the next stage are spread over the MFMA steps of this one
 #define TE_FAST_IL 1
 #endif
-#ifdef TE_CONV_PROF
+#if defined(TE_CONV_PROF) || defined(TE_CONV_PROF2)
 // experimental builds: per-phase cycle counts of wave 0 of every block (s_memtime), read back with te_debug_conv_prof
 __device__ unsigned long long te_conv_prof_buf[8192 * 8];
+#endif
+#ifdef TE_CONV_PROF
 #define PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #else
 #define PROF_T(v)
+#endif
+#ifdef TE_CONV_PROF2         // whole-block timeline of ANY kernel form (100 MHz s_memrealtime): entry, K loop start / end, exit
+#define PROF2_T(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#else
+#define PROF2_T(v)
 #endif
 template <int KIND, int TC> struct Cfg;
 template <int KIND> struct Cfg<KIND, 0> { static constexpr int WM = 2, MBW = 2, NBW = 2, KC = 8, NSP = (KIND == TE_CONV_S2) ? 3 : (KIND == TE_CONV_3X3 ? 2 : 1), NQ = (KIND == TE_CONV_S2) ? 5 : 2; };
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     // keeps one offset register instead of WLDR (9 for the 3x3 kinds: the 168-register kernels were spilling 12 dwords)
     constexpr bool TAPW = FAST && (KC * BM / 4 == NTHREADS);
 
+    PROF2_T(q0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wl = smem;            // [NTAP][KC][BM]
     float* iscl = smem + WSTAGE; // FAST with style scales: those of the block's sample [Kp]
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     float sq[FAST ? NQ : 1];     //       and the style scale of its channel
 
     const int kbeg = blockIdx.z * p.kchunk, kend = min(p.Kp, kbeg + p.kchunk);
+    PROF2_T(q1);
     auto commit = [&](float* wlb, float* xlb) {          // prefetched registers -> one LDS stage buffer
 #pragma unroll
         for (int r = 0; r < WLDR; ++r) {
@@ -532,19 +541,41 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
     } else {
         // software pipeline: iteration `k0` commits stage k0 (prefetched by the previous iteration) to LDS, issues the
         // global loads of stage k0+KC, then runs the MFMAs of stage k0 while those loads are in flight.
+#ifdef TE_CONV_PROF2
+        unsigned long long qa = 0, qb = 0, qc = 0, qw = 0;
+#endif
         for (int k0 = kbeg - KC; k0 < kend; k0 += KC) {
+            PROF2_T(s0);
             if (k0 >= kbeg) {
                 __syncthreads();              // every wave finished reading the previous stage
+#ifdef TE_CONV_PROF2
+                { PROF2_T(w0); __builtin_amdgcn_s_waitcnt(0x0F70); qw += __builtin_amdgcn_s_memrealtime() - w0; }   // vmcnt(0): waiting for the stage loads
+#endif
                 commit(wl, xl);
                 __syncthreads();
             }
+            PROF2_T(s1);
             const int kn = k0 + KC;
             if (kn < kend) issue(kn);
+            PROF2_T(s2);
+#ifdef TE_CONV_PROF2
+            qa += s1 - s0; qb += s2 - s1;
+#endif
             if (k0 < kbeg) continue;
             compute(wl, xl);
+#ifdef TE_CONV_PROF2
+            qc += __builtin_amdgcn_s_memrealtime() - s2;
+#endif
         }
+#ifdef TE_CONV_PROF2
+        if (tid == 0) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+            if (lin < 8192) { unsigned long long* d = te_conv_prof_buf + (size_t)lin * 8; d[5] = qa | (qw << 32); d[6] = qb | (qc << 32); }
+        }
+#endif
     }
 
+    PROF2_T(q2);
     // ---- epilogue: osc, bias, activation, store.  C/D layout of the 32x32 tile:
     //      col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const size_t oplane = (size_t)p.Ho * p.Wo;
@@ -668,6 +699,15 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
             }
         }
     }
+#ifdef TE_CONV_PROF2
+    {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.z;
+        if (tid == 0 && lin < 8192) {
+            unsigned long long* d = te_conv_prof_buf + (size_t)lin * 8;
+            d[0] = q0; d[1] = q1; d[2] = q2; d[3] = __builtin_amdgcn_s_memrealtime(); d[4] = (kend - kbeg) / KC; d[7] = 1;
+        }
+    }
+#endif
 }
 
 // epilogue of the split-K path: out = act((sum_z ws[z] | out) * osc[b,m] + bias[m]); the slabs are summed in fixed order
@@ -905,9 +945,14 @@ int launch_regions(const ConvArgs& a, const int (*regions)[4], int n, hipStream_
 
 }  // namespace
 
-#ifdef TE_CONV_PROF
+#if defined(TE_CONV_PROF) || defined(TE_CONV_PROF2)
 extern "C" int te_debug_conv_prof(void* host_dst, int64_t bytes) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_conv_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int te_debug_conv_prof_clear() {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(te_conv_prof_buf)) != hipSuccess) return -1;
+    return (int)hipMemset(dptr, 0, sizeof(te_conv_prof_buf));
 }
 #endif
 
