@@ -224,8 +224,16 @@ def test_discriminator_joint_pass_equals_two_passes(size, B):
     assert rel_err(mixed, fp2) > 1e-5
     ga = torch.autograd.grad(d_logistic_loss(rp, fp), params)
     gb = torch.autograd.grad(d_logistic_loss(rp2, fp2), params)
+    # Same sums in a different order, so pre-activations differ in the last bit - and a leaky-ReLU whose pre-activation sits
+    # within that distance of zero takes the other slope.  ONE such element changes every gradient upstream of it by
+    # ~sqrt(1 / elements of the layer) (measured against the fp64 oracle, tools/d_joint_probe.py: both routes are at 5e-7 behind
+    # the flipped element and at 4e-4 - 8e-4 in front of it, each with its own flips; every kernel of the backward is at 3e-7
+    # on random data, tools/resblock_bisect.py).  The bar is set for a handful of flips, not for rounding.
     for (n, _), a, b in zip(D.named_parameters(), ga, gb):
-        assert rel_err(a, b) < 2e-4, n
+        assert rel_err(a, b) < 1e-2, n
+    tail = [i for i, (n, _) in enumerate(D.named_parameters()) if n.startswith('final_linear')]
+    for i in tail:               # behind the last activation nothing can flip
+        assert rel_err(ga[i], gb[i]) < 2e-5
     with pytest.raises(ValueError):
         D(torch.cat([fake, real])[:2 * B - 1], chunks=2)
 
@@ -251,5 +259,7 @@ def test_path_step_latent_hint_changes_nothing():
         res.append((loss.detach(), lengths.detach(), {n: q.grad.clone() for n, q in G.named_parameters() if q.grad is not None}))
     assert rel_err(res[1][0], res[0][0]) < 1e-5 and rel_err(res[1][1], res[0][1]) < 1e-5
     assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) > 200
-    for n in res[0][2]:
-        assert rel_err(res[1][2][n], res[0][2][n]) < 5e-4, n
+    scale = max(float(g.norm()) for g in res[0][2].values())
+    for n in res[0][2]:          # (the key bias of an attention block has an exactly-zero gradient - softmax is shift-invariant -
+        a, b = res[1][2][n], res[0][2][n]      # so both routes return rounding noise there: absolute floor)
+        assert float((a - b).norm()) <= 5e-4 * float(b.norm()) + 1e-9 * scale, n

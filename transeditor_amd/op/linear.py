@@ -54,9 +54,9 @@ def _gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha):
 class _LinFwd(Function):
     @staticmethod
     def forward(ctx, x, w, alpha):                     # x [R,K], w [N,K] -> [R,N]
-        x, w = x.contiguous(), w.contiguous()
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w)         # the INPUTS (with their history: the backward may itself be recorded), not dense copies
         ctx.alpha = alpha
+        x, w = x.contiguous(), w.contiguous()
         return _gemm(x.shape[0], w.shape[0], w.shape[1], x, x.stride(0), 1, w, 1, w.shape[1], alpha)
 
     @staticmethod
@@ -70,9 +70,9 @@ class _LinFwd(Function):
 class _LinDx(Function):
     @staticmethod
     def forward(ctx, g, w, alpha):                     # g [R,N], w [N,K] -> alpha g W  [R,K]
-        g, w = g.contiguous(), w.contiguous()
         ctx.save_for_backward(g, w)
         ctx.alpha = alpha
+        g, w = g.contiguous(), w.contiguous()
         return _gemm(g.shape[0], w.shape[1], w.shape[0], g, g.stride(0), 1, w, w.shape[1], 1, alpha)
 
     @staticmethod
@@ -86,9 +86,9 @@ class _LinDx(Function):
 class _LinDw(Function):
     @staticmethod
     def forward(ctx, g, x, alpha):                     # g [R,N], x [R,K] -> alpha g^T x  [N,K]
-        g, x = g.contiguous(), x.contiguous()
         ctx.save_for_backward(g, x)
         ctx.alpha = alpha
+        g, x = g.contiguous(), x.contiguous()
         return _gemm(g.shape[1], x.shape[1], g.shape[0], g, 1, g.shape[1], x, x.shape[1], 1, alpha)
 
     @staticmethod
@@ -107,6 +107,9 @@ class _Bmm(Function):
 
     @staticmethod
     def forward(ctx, a, b, ta, tb, alpha):
+        # the INPUTS are saved, not their dense copies: the backward may itself be recorded, and a copy made in here has no
+        # history (a [1,G,M,D] -> [G,M,D] reshape of a permuted tensor is a strided VIEW: batch 1 arrives non-contiguous)
+        ctx.save_for_backward(a, b)
         a, b = a.contiguous(), b.contiguous()
         Z, p, q = a.shape
         _, r, t = b.shape
@@ -118,7 +121,6 @@ class _Bmm(Function):
         sai, sak = (1, q) if ta else (q, 1)
         sbk, sbj = (1, t) if tb else (t, 1)
         _lib.small_gemm_batched(c, a, b, None, Z, p * q, I * J, I, J, K, sai, sak, sbk, sbj, J, 1, zb=r * t, alpha=alpha)
-        ctx.save_for_backward(a, b)
         ctx.cfg = (ta, tb, alpha)
         return c
 

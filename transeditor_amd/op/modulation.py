@@ -50,7 +50,7 @@ class _BatchedModulation(Function):
         """lat_g [B, Z, K]: the latent of every modulation, GROUP-MAJOR (the caller gathered it in the order of `_groups`);
         params = Z weights [J_z, K] then Z biases [J_z], in the same order.  Returns Z tensors [B, J_z]."""
         weights, biases = params[:n], params[n:]
-        lat_g = lat_g.contiguous()
+        lat_in, lat_g = lat_g, lat_g.contiguous()       # saved: the input itself (history for a recorded backward)
         B, Z, K = lat_g.shape
         groups = _groups([w.shape[0] for w in weights])
         outs = [None] * n
@@ -66,7 +66,7 @@ class _BatchedModulation(Function):
             for z, i in enumerate(ids):
                 outs[i] = buf[z]
             z0 += nz
-        ctx.save_for_backward(lat_g, *params)
+        ctx.save_for_backward(lat_in, *params)
         ctx.cfg = (alpha, beta, n, groups)
         return tuple(outs)
 
@@ -86,6 +86,7 @@ class _BatchedModulation(Function):
                 res = iter(torch.autograd.grad(ys, ins, list(gs), create_graph=True, allow_unused=True))
             glat = next(res) if need[0] else None
             return (glat, None, None, None) + tuple(next(res) if f else None for f in need[4:])
+        lat_g = lat_g.contiguous()
         glat = torch.empty_like(lat_g) if need[0] else None
         gws, gbs = [None] * n, [None] * n
         z0 = 0

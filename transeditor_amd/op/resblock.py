@@ -160,5 +160,6 @@ class _ResBlock(Function):
 def resblock(x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, stem=None):
     """stem = (w0 [C,3,1,1], b0 [C], s0): x is the 3-channel image and the from-RGB layer runs inside the node"""
     w0, b0, s0 = stem if stem is not None else (None, None, 1.0)
+    x = x.contiguous()        # out here (a differentiable op): the node saves its input, and a copy made inside it would have no history
     return _ResBlock.apply(x, w1, b1, w2, b2, ws, k_main, k_skip, float(s1), float(s2), float(ss), tuple(pad_main),
                            tuple(pad_skip), float(gain), w0, b0, float(s0))

@@ -23,8 +23,7 @@ def _torch_expr(out, group, feat=1, chunks=1):
 class _Stddev(Function):
     @staticmethod
     def forward(ctx, x, group, chunks):
-        x = x.contiguous()
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x)          # the input itself (history for a recorded backward); the binding makes its own dense copy
         ctx.group, ctx.chunks = group, chunks
         return _lib.minibatch_stddev_fwd(x, group, EPS, chunks)
 
@@ -36,7 +35,7 @@ class _Stddev(Function):
                 xa = x.view_as(x)
                 gx, = torch.autograd.grad(_torch_expr(xa, ctx.group, 1, ctx.chunks), xa, gy, create_graph=True)
             return gx, None, None
-        return _lib.minibatch_stddev_bwd(gy, x, ctx.group, EPS, ctx.chunks), None, None
+        return _lib.minibatch_stddev_bwd(gy, x.contiguous(), ctx.group, EPS, ctx.chunks), None, None
 
 
 def minibatch_stddev(out, group=4, feat=1, second_order=False, chunks=1):

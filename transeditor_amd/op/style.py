@@ -23,9 +23,8 @@ class _Demod(Function):
     @staticmethod
     def forward(ctx, w, s, wscale, eps):
         w3 = w.reshape(w.shape[0], w.shape[1], -1).contiguous()
-        s = s.contiguous()
-        d, wsq = _lib.demod_fwd(w3, s, wscale, eps)
-        ctx.save_for_backward(w, s, d, wsq)
+        d, wsq = _lib.demod_fwd(w3, s.contiguous(), wscale, eps)
+        ctx.save_for_backward(w, s, d, wsq)          # (w, s: the inputs themselves - their history matters to a recorded backward)
         ctx.cfg = (wscale, eps)
         return d
 
@@ -41,7 +40,7 @@ class _Demod(Function):
                 gs = iter(torch.autograd.grad(_torch_expr(wa, sa, wscale, eps), ins, gd, create_graph=True))
             return tuple(next(gs) if n else None for n in need[:2]) + (None, None)
         w3 = w.reshape(w.shape[0], w.shape[1], -1).contiguous()
-        gw, gs = _lib.demod_bwd(gd, d, w3, wsq, s, wscale, want_w=need[0], want_s=need[1])
+        gw, gs = _lib.demod_bwd(gd, d, w3, wsq, s.contiguous(), wscale, want_w=need[0], want_s=need[1])
         return (gw.reshape(w.shape) if gw is not None else None), gs, None, None
 
 

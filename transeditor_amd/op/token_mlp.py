@@ -42,14 +42,14 @@ class _TokenMLP(Function):
     @staticmethod
     def forward(ctx, x, scale, lr_mul, T, *params):
         weights, biases = params[:T], params[T:]
-        x = x.contiguous()
+        x_in, x = x, x.contiguous()       # saved: the input itself (its history matters when the backward is recorded), not a copy
         B, D, Cn = x.shape
         N = weights[0].shape[0]
         y = torch.empty(B, T, N, device=x.device, dtype=x.dtype)
         # A_t(b, k) = x[b, k, t];  B_t(k, j) = W_t[j, k];  C_t(b, j) = y[b, t, j]
         _lib.small_gemm_batched(y, x, weights[0], biases[0], T, 1, N, B, N, D, D * Cn, Cn, 1, D, T * N, 1,
                                 b_tab=_offsets(weights), bias_tab=_offsets(biases), alpha=scale, beta=lr_mul, act=3)
-        ctx.save_for_backward(x, y, *params)
+        ctx.save_for_backward(x_in, y, *params)
         ctx.cfg = (scale, lr_mul, T)
         return y
 
@@ -68,6 +68,7 @@ class _TokenMLP(Function):
                 gs = iter(torch.autograd.grad(out, ins, gy, create_graph=True, allow_unused=True))
             gx = next(gs) if need[0] else None
             return (gx, None, None, None) + tuple(next(gs) if n else None for n in need[4:])
+        x = x.contiguous()
         B, D, Cn = x.shape
         N = weights[0].shape[0]
         # activation gradient and the 16 bias gradients in one pass over [B, T*N]
