@@ -231,7 +231,7 @@ def test_discriminator_joint_pass_equals_two_passes(size, B):
     # on random data, tools/resblock_bisect.py).  The bar is set for a handful of flips, not for rounding.
     for (n, _), a, b in zip(D.named_parameters(), ga, gb):
         assert rel_err(a, b) < 1e-2, n
-    tail = [i for i, (n, _) in enumerate(D.named_parameters()) if n.startswith('final_linear')]
+    tail = [i for i, (n, _) in enumerate(D.named_parameters()) if n.startswith('final_linear.1')]
     for i in tail:               # behind the last activation nothing can flip
         assert rel_err(ga[i], gb[i]) < 2e-5
     with pytest.raises(ValueError):
