@@ -146,6 +146,12 @@ int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_p
 int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, int kind_b, const float* w, float wscale, int Co, int Ci,
                               int ksize, te_stream_t stream);
 
+/* n (weight, layout) jobs in one launch per 64: job e packs w[e] [Co[e]][Ci[e]][ksize[e]]^2 into wp[e] with layout
+ * kind_pack[e] and constant wscale[e] (host arrays).  The training step refreshes every packed layout of a model with it right
+ * after the optimiser step (torch.optim.Adam's step, train_spatial_query.py:207 / :224) instead of ~60 tiny launches per iteration. */
+int te_conv_pack_weights_multi_f32(int n, float* const* wp, const float* const* w, const float* wscale, const int* kind_pack,
+                                   const int* Co, const int* Ci, const int* ksize, te_stream_t stream);
+
 /* `H`,`W` are ALWAYS the low-resolution size (the H,W of the table above).  isc [B,K], osc [B,M],
  * bias [M] may be NULL.  act: 0 linear, 3 lrelu(0.2)*sqrt(2), 4 lrelu(0.2) with gain 1 (a residual branch that folds the
  * 1/sqrt(2) of `(out + skip) / sqrt(2)`, model_spatial_query.py:796) — applied after osc and bias. */

@@ -126,3 +126,33 @@ def test_fused_adam_rejects_cpu_parameters():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match='GPU'):
         FusedAdam([p], lr=0.1).step()
+
+
+@pytest.mark.gpu
+def test_refresh_packed_weights_equals_single_packs():
+    """te_conv_pack_weights_multi_f32 (every stale layout of a cache in one launch, after an optimiser step) against the
+    per-layer packing launches: all three layouts, 3x3 and 1x1, ragged channel counts, the [1,Co,Ci,k,k] parameter layout of
+    ModulatedConv2d; untouched parameters are left alone and a stale entry is really rewritten."""
+    import torch
+    from transeditor_amd import _lib
+    from transeditor_amd.op.modconv import packed, packed2, packed_weights_cache, refresh_packed_weights
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(*s, device='cuda')) for s in [(1, 24, 40, 3, 3), (64, 3, 1, 1), (512, 512, 3, 3), (130, 66, 1, 1)]]
+    views = [p[0] if p.dim() == 5 else p for p in ps]
+    cache = {}
+    with packed_weights_cache(cache):
+        for w in views:
+            packed2(w, _lib.PACK_FWD, _lib.PACK_DGRAD, 0.37)
+        packed(views[2], _lib.PACK_SWAP, 1.5)
+        assert len(cache) == 9 and refresh_packed_weights(cache) == 0          # nothing stale yet
+        held = {k: v[1] for k, v in cache.items()}
+        with torch.no_grad():
+            for p in ps[:3]:
+                p.add_(torch.randn_like(p))                                    # an optimiser step (bumps the version counters)
+        assert refresh_packed_weights(cache) == 7                              # ps[3]'s two layouts are not touched
+        for key, (ver, wp, base) in cache.items():
+            assert wp is held[key] and ver == base._version                    # rewritten in place, entry current again
+            want = _lib.conv_pack(base.detach().view(key[1]), key[2], key[3])
+            assert torch.equal(wp, want), key
+        hits = packed(views[0], _lib.PACK_FWD, 0.37)
+        assert hits is held[(views[0].data_ptr(), tuple(views[0].shape), _lib.PACK_FWD, 0.37)]

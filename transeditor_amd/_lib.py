@@ -34,6 +34,7 @@ _SIGNATURES = {
     'te_conv_packed_numel': (C.c_int64, [_I, _I, _I, _I]),
     'te_conv_pack_weights_f32': (C.c_int, [_P, _P, _F, _I, _I, _I, _I, _P]),
     'te_conv_pack_weights2_f32': (C.c_int, [_P, _I, _P, _I, _P, _F, _I, _I, _I, _P]),
+    'te_conv_pack_weights_multi_f32': (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -316,6 +317,23 @@ def conv_pack2(w, kind_a, kind_b, wscale=1.0):
     _check(lib().te_conv_pack_weights2_f32(_ptr(wa), kind_a, _ptr(wb), kind_b, _ptr(w), wscale, Co, Ci, ks, _stream()),
            'te_conv_pack_weights2_f32')
     return wa, wb
+
+
+def conv_pack_multi(jobs):
+    """jobs: [(wp, w, kind_pack, wscale)] with w [Co,Ci,k,k] dense and wp an already allocated packed buffer of the right
+    size: every layout is (re)written in one launch per 64 jobs."""
+    n = len(jobs)
+    if not n:
+        return
+    for wp, w, _, _ in jobs:
+        if not (w.is_contiguous() and wp.is_contiguous()):
+            raise RuntimeError('te_hip: conv_pack_multi needs dense weights and buffers')
+    arr = lambda ty, vals: (ty * n)(*vals)
+    _check(lib().te_conv_pack_weights_multi_f32(
+        n, arr(C.c_void_p, [_ptr(j[0]) for j in jobs]), arr(C.c_void_p, [_ptr(j[1]) for j in jobs]),
+        arr(C.c_float, [float(j[3]) for j in jobs]), arr(C.c_int, [int(j[2]) for j in jobs]),
+        arr(C.c_int, [j[1].shape[0] for j in jobs]), arr(C.c_int, [j[1].shape[1] for j in jobs]),
+        arr(C.c_int, [j[1].shape[2] for j in jobs]), _stream()), 'te_conv_pack_weights_multi_f32')
 
 
 def conv_out_shape(kind, B, M, H, W):
@@ -630,7 +648,7 @@ def chan_dot(a, b):
 def _install_roctx():
     import functools
     import torch.cuda.nvtx as nvtx
-    names = ['bias_act', 'bias_act_bwd', 'upfirdn2d_raw', 'blur_actgrad', 'blur_gradact', 'conv_pack', 'conv_pack2', 'conv',
+    names = ['bias_act', 'bias_act_bwd', 'upfirdn2d_raw', 'blur_actgrad', 'blur_gradact', 'conv_pack', 'conv_pack2', 'conv_pack_multi', 'conv',
              'wgrad_slabs', 'wgrad_reduce', 'rgb_fwd', 'rgb_dgrad', 'rgb_expand', 'rgb_wgrad_slabs', 'small_gemm',
              'small_gemm_splitk', 'small_gemm_batched', 'minibatch_stddev_fwd', 'minibatch_stddev_bwd',
              'layer_norm_fwd', 'layer_norm_bwd', 'pixel_norm_fwd', 'pixel_norm_bwd', 'demod_fwd', 'demod_from_wsq', 'demod_bwd',

@@ -776,6 +776,27 @@ __global__ __launch_bounds__(256) void pack_weights2_kernel(float* __restrict__ 
     }
 }
 
+// up to 64 (weight, layout) jobs in one launch: the packed layouts of a whole model are refreshed right after an optimiser step
+// (blockIdx.y = job) instead of one tiny launch per layer at first use
+struct PackJob { float* wp; const float* w; float wscale; int kind, Ci, ntap, K, M, Kp, Mp; };
+struct PackJobs { PackJob j[64]; };
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJobs P) {
+    const PackJob& q = P.j[blockIdx.y];
+    const int64_t total = (int64_t)q.ntap * q.Kp * q.Mp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int m = (int)(e % q.Mp);
+        const int k = (int)((e / q.Mp) % q.Kp);
+        const int tap = (int)(e / ((int64_t)q.Mp * q.Kp));
+        float v = 0.f;
+        if (m < q.M && k < q.K) {
+            if (q.kind == TE_PACK_FWD) v = q.w[((size_t)m * q.Ci + k) * q.ntap + tap];
+            else if (q.kind == TE_PACK_DGRAD) v = q.w[((size_t)k * q.Ci + m) * q.ntap + (q.ntap - 1 - tap)];
+            else v = q.w[((size_t)k * q.Ci + m) * q.ntap + tap];
+        }
+        q.wp[e] = v * q.wscale;
+    }
+}
+
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline int pow2ceil(int v) { return 1 << ilog2(v); }
 inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
@@ -984,6 +1005,31 @@ extern "C" int te_conv_pack_weights2_f32(float* wp_a, int kind_a, float* wp_b, i
     pack_weights2_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(wp_a, wp_b, w, wscale, kind_a, kind_b, Ci, a.ntap, a.K, a.M, a.Kp,
                                                                 a.Mp, b.K, b.M, b.Kp, b.Mp);
     return te::launch_status("te_conv_pack_weights2_f32");
+}
+
+extern "C" int te_conv_pack_weights_multi_f32(int n, float* const* wp, const float* const* w, const float* wscale,
+                                              const int* kind_pack, const int* Co, const int* Ci, const int* ksize,
+                                              te_stream_t stream_) {
+    TE_REQUIRE(n >= 0 && (n == 0 || (wp && w && wscale && kind_pack && Co && Ci && ksize)), TE_ERR_NULL,
+               "te_conv_pack_weights_multi_f32: NULL table");
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = std::min(64, n - base);
+        PackJobs P{};
+        int64_t biggest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int e = base + i;
+            TE_REQUIRE(wp[e] && w[e], TE_ERR_NULL, "te_conv_pack_weights_multi_f32: NULL pointer in job %d", e);
+            TE_REQUIRE(Co[e] > 0 && Ci[e] > 0 && (ksize[e] == 1 || ksize[e] == 3), TE_ERR_SHAPE, "te_conv_pack_weights_multi_f32: bad dims in job %d", e);
+            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 2, TE_ERR_UNSUPPORTED, "te_conv_pack_weights_multi_f32: bad kind in job %d", e);
+            const PackDims d = pack_dims(kind_pack[e], Co[e], Ci[e], ksize[e]);
+            P.j[i] = PackJob{wp[e], w[e], wscale[e], kind_pack[e], Ci[e], d.ntap, d.K, d.M, d.Kp, d.Mp};
+            biggest = std::max<int64_t>(biggest, (int64_t)d.ntap * d.Kp * d.Mp);
+        }
+        // enough blocks per job that the big 512x512x9 weights stream at full rate; small jobs walk their few elements and exit
+        dim3 grid((unsigned)std::min<int64_t>(te::cdiv(biggest, 256 * 8), 256), (unsigned)cnt);
+        pack_weights_multi_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(P);
+    }
+    return te::launch_status("te_conv_pack_weights_multi_f32");
 }
 
 // transposed conv on images up to this many cells per side runs as ONE padded (H+1) x (W+1) region; larger ones as body +

@@ -181,6 +181,29 @@ def _cacheable(w):
     return base if isinstance(base, torch.nn.Parameter) else None
 
 
+def refresh_packed_weights(cache):
+    """Rewrite every stale layout held by `cache` in ONE launch (te_conv_pack_weights_multi_f32).  Called right after an
+    optimiser step: the layers that use the weights next then hit the cache instead of issuing ~60 small packing launches per
+    iteration.  An entry whose parameter is gone / resized is dropped; entries of untouched parameters cost nothing."""
+    jobs, fresh = [], []
+    for key, (ver, wp, base) in list(cache.items()):
+        ptr, shape, pack_kind, wscale = key
+        if base._version == ver:
+            continue
+        n = 1
+        for d in shape:
+            n *= d
+        if not (base.data_ptr() == ptr and base.numel() == n and base.is_contiguous() and len(shape) == 4):
+            del cache[key]                # a partial view of the parameter (or a resized one): repacked at its next use
+            continue
+        jobs.append((wp, base.detach().view(shape), pack_kind, wscale))      # (ModulatedConv2d.weight is [1,Co,Ci,k,k]: same storage)
+        fresh.append((key, base))
+    _lib.conv_pack_multi(jobs)
+    for (key, base), job in zip(fresh, jobs):
+        cache[key] = (base._version, job[0], base)
+    return len(jobs)
+
+
 def packed(w, pack_kind, wscale=1.0):
     """packed layout `pack_kind` of w (through the cache when one is open)"""
     base = _cacheable(w)

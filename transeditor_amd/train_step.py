@@ -22,7 +22,7 @@ from torch import autograd
 from torch.nn import functional as F
 
 from .model_spatial_query import Discriminator, Generator
-from .op.modconv import no_weight_grads, packed_weights_cache, second_order
+from .op.modconv import no_weight_grads, packed_weights_cache, refresh_packed_weights, second_order
 from .optim import FusedAdam, MultiTensorEMA
 from .utils import distributed as D
 from .utils.sample import prepare_noise_new, prepare_param
@@ -140,6 +140,7 @@ class TrainStep:
         d_loss.backward()
         self.d_sync.all_reduce('d')
         self.d_optim.step()
+        refresh_packed_weights(self._packs)          # every packed layout of the updated model: one launch
 
     def r1_step(self, real_img):
         Dn, a = self.discriminator, self.args
@@ -151,6 +152,7 @@ class TrainStep:
         (a.r1 / 2 * r1_loss * a.d_reg_every + 0 * real_pred[0]).backward()
         self.d_sync.all_reduce('r1')
         self.d_optim.step()
+        refresh_packed_weights(self._packs)          # every packed layout of the updated model: one launch
         self.loss['r1'] = r1_loss.detach()
 
     def g_step(self):
@@ -165,6 +167,7 @@ class TrainStep:
         g_loss.backward()
         self.g_sync.all_reduce('g')
         self.g_optim.step()
+        refresh_packed_weights(self._packs)          # every packed layout of the updated model: one launch
 
     def path_step(self):
         G, a = self.generator, self.args
@@ -181,6 +184,7 @@ class TrainStep:
         weighted.backward()
         self.g_sync.all_reduce('path')
         self.g_optim.step()
+        refresh_packed_weights(self._packs)          # every packed layout of the updated model: one launch
         # :249 — the reference reads this scalar back with .item() right here (a host-device sync in the middle of the step that
         # leaves the GPU waiting for the next step's first launches); it is only ever logged, so the read-back happens on access
         self._mpl_avg = D.reduce_sum(self.mean_path_length)
@@ -210,6 +214,7 @@ class TrainStep:
         weighted.backward()
         self.g_sync.all_reduce('spatial')
         self.g_optim.step()
+        refresh_packed_weights(self._packs)          # every packed layout of the updated model: one launch
         self._mspl_avg = D.reduce_sum(self.mean_spatial_path_length)
         self.loss.update(spatial_path=loss.detach(), spatial_path_length=lengths.mean().detach())
 
