@@ -47,6 +47,11 @@ def _gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha):
     return _lib.small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
 
 
+def _rows2(x):
+    """a 2-D operand with unit inner stride is used through its row stride; anything else is densified"""
+    return x if (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1]) else x.contiguous()
+
+
 # The bilinear map y = alpha * x W^T as a trio closed under differentiation (each one's backward is the other two), like the
 # convolution trio of op/modconv.py: whatever is built from it differentiates to any order on te_small_gemm_f32 alone.  The
 # recorded backward of every EqualLinear (path-length regulariser: the 20 style modulations; `--spatial_regu`: the mapping
@@ -56,7 +61,7 @@ class _LinFwd(Function):
     def forward(ctx, x, w, alpha):                     # x [R,K], w [N,K] -> [R,N]
         ctx.save_for_backward(x, w)         # the INPUTS (with their history: the backward may itself be recorded), not dense copies
         ctx.alpha = alpha
-        x, w = x.contiguous(), w.contiguous()
+        x, w = _rows2(x), w.contiguous()           # (a row slice of a wider tensor - latent[:, i] - is read in place)
         return _gemm(x.shape[0], w.shape[0], w.shape[1], x, x.stride(0), 1, w, 1, w.shape[1], alpha)
 
     @staticmethod
@@ -88,8 +93,8 @@ class _LinDw(Function):
     def forward(ctx, g, x, alpha):                     # g [R,N], x [R,K] -> alpha g^T x  [N,K]
         ctx.save_for_backward(g, x)
         ctx.alpha = alpha
-        g, x = g.contiguous(), x.contiguous()
-        return _gemm(g.shape[1], x.shape[1], g.shape[0], g, 1, g.shape[1], x, x.shape[1], 1, alpha)
+        g, x = g.contiguous(), _rows2(x)
+        return _gemm(g.shape[1], x.shape[1], g.shape[0], g, 1, g.shape[1], x, x.stride(0), 1, alpha)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -196,7 +201,9 @@ class _Linear(Function):
             return tuple(next(gs) if (n and t is not None) else None for t, n in zip(al, need[:4])) + (None, None, None)
         N, K = weight.shape
         g = gy.reshape(-1, N).contiguous()
-        g_res = gy if (residual is not None and need[3]) else None
+        # the skip connection hands on the DENSE gradient: a strided one (the permute in front of adjust_style makes the first)
+        # would otherwise be densified again by both linear layers of every block upstream
+        g_res = g.view(gy.shape) if (residual is not None and need[3]) else None
         if act == 'gelu':
             g = torch.ops.aten.gelu_backward(g, aux)
         elif act == 'lrelu':       # residual is not combined with lrelu anywhere in the model
