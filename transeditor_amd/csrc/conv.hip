@@ -1059,6 +1059,8 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
 #define TE_T2_TC1_LIMIT (1024 * 128)
 #endif
     if (t2k && tc == 0 && (int64_t)B * H * W * te::cdiv(M, 64) <= (int64_t)TE_T2_TC1_LIMIT) tc = 1;
+    // (narrower tile classes for the 4x4 / 8x8 layers were measured and lose: 3x3 512->512 @4x4 65 -> 112 (64 rows) / 119 us (32 rows),
+    // profiles/experiments/r03_tiny_tile_class.log)
     pl.tc = tc;
     const int KC = t2k ? (tc == 0 ? T2KC0 : 16) : 8;
     const int BM = t2k ? (tc == 2 ? 32 : 64) : (tc == 0 ? 128 : (tc == 1 ? 64 : 32));
