@@ -93,14 +93,14 @@ class KernelTimer:
             timer.records.append((names[kind], flops, s, e))
             return out
 
-        def wgrad(g, x, kind, H, W):
+        def wgrad(g, x, kind, H, W, *a, **k):
             if not timer.enabled:
-                return orig_wgrad(g, x, kind, H, W)
+                return orig_wgrad(g, x, kind, H, W, *a, **k)
             taps = 1 if kind == _lib.CONV_1X1 else 9
             flops = 2.0 * taps * g.shape[1] * x.shape[1] * H * W * g.shape[0]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            out = orig_wgrad(g, x, kind, H, W)
+            out = orig_wgrad(g, x, kind, H, W, *a, **k)
             e.record()
             timer.records.append(('wgrad_' + names[kind], flops, s, e))
             return out

@@ -185,6 +185,14 @@ int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, con
 int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W);
 int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H,
                  int W, int S, te_stream_t stream);
+/* GROUPED form for the PLAIN (unmodulated) weight gradient of small images: NB consecutive samples share one slab
+ * (slabs [B / NB][S][Co][Ci][taps]), a block walks the cell tiles of its NB samples.  te_wgrad_group_plan picks NB (a divisor
+ * of B; 1 when grouping does not apply) and S.  Not for layers whose reducer needs per-sample slabs (style / demodulation
+ * gradients of ModulatedConv2d): those keep te_wgrad_f32.  Replaces torch's conv2d weight gradient of the discriminator's
+ * 4x4 ... 32x32 layers (model_spatial_query.py:731-798), where B slabs of 9.4 MB were the traffic. */
+int te_wgrad_group_plan(int kind, int B, int Co, int Ci, int H, int W, int* NB, int* S);
+int te_wgrad_group_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB,
+                       te_stream_t stream);
 
 /* Combine slabs (SURVEY §7 step 6 "reductions for ds, dd"):
  *   gw[co,ci,t]  = wscale * sum_{b,s} osc[b,co]*isc[b,ci] * slab          (gw   may be NULL)

@@ -762,3 +762,35 @@ def test_bmm_closed_family(Z, I, J, K, ta, tb):
     grow = max(1.0, math.sqrt(K / 512))
     for name, x, y in zip(('c', 'ga', 'gb', 'gga', 'ggb'), got, want):
         assert rel_err(x, y.float()) < 3e-5 * grow, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['3x3', 'T2', '1x1'])
+@pytest.mark.parametrize('B,C,H,W', [(32, 512, 4, 4), (16, 512, 8, 8), (32, 512, 16, 16), (32, 256, 32, 32), (16, 128, 64, 64),
+                                     (32, 512, 5, 3), (24, 384, 32, 64)])
+def test_wgrad_grouped_slabs_equal_per_sample_slabs(kind, B, C, H, W):
+    """te_wgrad_group_f32 (NB samples share a slab: the plain weight gradient of the discriminator's small layers) against the
+    per-sample form te_wgrad_f32 and against torch's fp64 convolution weight gradient: scalar and 16-byte staging paths, odd
+    image sizes, the transposed kind's (2H+1)-sized operand; and the plan really groups where it should."""
+    from transeditor_amd import _lib
+    code = {'3x3': _lib.CONV_3X3, 'T2': _lib.CONV_T2, '1x1': _lib.CONV_1X1}[kind]
+    x = synth.normal((B, C, H, W), 'wgg.x').to(DEV)
+    g = synth.normal((B, C, 2 * H + 1, 2 * W + 1) if kind == 'T2' else (B, C, H, W), 'wgg.g').to(DEV)
+    per = _lib.wgrad_slabs(g, x, code, H, W)
+    grp = _lib.wgrad_slabs(g, x, code, H, W, group=True)
+    assert per.shape[0] == B and grp.shape[2:] == per.shape[2:]
+    if C % 128 == 0 and per.shape[1] == 1 and B * (C // 128) * (C // 64) // 2 >= 256:
+        assert grp.shape[0] < B and B % grp.shape[0] == 0, tuple(grp.shape)          # grouping applies to these shapes
+    a, b = grp.sum(dim=(0, 1)), per.sum(dim=(0, 1))
+    assert rel_err(a, b) < 2e-5
+    xd, gd = x.double().cpu(), g.double().cpu()
+    if kind == 'T2':        # conv_transpose2d(x, w, stride 2) -> d w[ci, co, ky, kx];  slabs are [co, ci, tap]
+        w = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+        ref, = torch.autograd.grad(F.conv_transpose2d(xd[:, :64], w[:64], stride=2), w, gd)
+        ref = ref[:64].permute(1, 0, 2, 3).reshape(C, 64, 9)
+        assert rel_err(a[:, :64], ref.float()) < 2e-5
+    else:
+        ks = 3 if kind == '3x3' else 1
+        w = torch.zeros(64, C, ks, ks, dtype=torch.float64, requires_grad=True)
+        ref, = torch.autograd.grad(F.conv2d(xd, w, padding=ks // 2), w, gd[:, :64])
+        assert rel_err(a[:64], ref.reshape(64, C, ks * ks).float()) < 2e-5

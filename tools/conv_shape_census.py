@@ -29,12 +29,12 @@ def conv(x, wp, kind, M, H, W, *a, **k):
     return out
 
 
-def wgrad(g, x, kind, H, W):
+def wgrad(g, x, kind, H, W, *a, **k):
     if not ON[0]:
-        return orig_wgrad(g, x, kind, H, W)
+        return orig_wgrad(g, x, kind, H, W, *a, **k)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    out = orig_wgrad(g, x, kind, H, W)
+    out = orig_wgrad(g, x, kind, H, W, *a, **k)
     e.record()
     taps = 1 if kind == _lib.CONV_1X1 else 9
     recs.append((('wgrad_' + names[kind], g.shape[0], x.shape[1], g.shape[1], H, W), 2.0 * taps * g.shape[1] * x.shape[1] * H * W * g.shape[0], s, e))

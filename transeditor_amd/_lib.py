@@ -41,6 +41,8 @@ _SIGNATURES = {
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'te_wgrad_group_plan': (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P]),
+    'te_wgrad_group_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     'te_rgb_supported': (C.c_int, [_I, _I, _I]),
     'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
@@ -365,10 +367,20 @@ def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0, res=None, m
     return out
 
 
-def wgrad_slabs(g, x, kind, H, W):
+def wgrad_slabs(g, x, kind, H, W, group=False):
+    """correlation slabs [B, S, Co, Ci, taps]; group=True (PLAIN gradient only - nothing per sample is derived from the slabs):
+    [B / NB, S, Co, Ci, taps] with NB samples per slab where the plan finds that worthwhile (small images, big weights)"""
     g, x = g.contiguous(), x.contiguous()
     B, Co, Ci = g.shape[0], g.shape[1], x.shape[1]
     taps = 1 if kind == CONV_1X1 else 9
+    if group:
+        nb, sc = C.c_int(0), C.c_int(0)
+        _check(lib().te_wgrad_group_plan(kind, B, Co, Ci, H, W, C.byref(nb), C.byref(sc)), 'te_wgrad_group_plan')
+        if nb.value > 1:
+            slabs = torch.empty(B // nb.value, sc.value, Co, Ci, taps, device=g.device, dtype=g.dtype)
+            _check(lib().te_wgrad_group_f32(_ptr(slabs), _ptr(g), _ptr(x), kind, B, Co, Ci, H, W, sc.value, nb.value, _stream()),
+                   'te_wgrad_group_f32')
+            return slabs
     S = lib().te_wgrad_slab_count(kind, B, Co, Ci, H, W)
     if S <= 0:
         raise RuntimeError(f'te_wgrad_slab_count failed ({S})')

@@ -31,7 +31,9 @@ struct WgArgs {
     const float* x;
     int B, Co, Ci, H, W;     // low-res (cell grid) size
     int Hg, Wg, Hx, Wx;      // spatial size of g and x
-    int S;                   // chunks per sample
+    int S;                   // chunks per sample group
+    int NB;                  // samples per group (1: a slab per sample; > 1: the plain, unmodulated gradient of small images -
+                             // a block walks the cell tiles of NB consecutive samples and the group shares one slab)
     int TH, TW, lgTW, NC, lgNC;   // cell tile (NC = TH*TW cells per stage)
     int tiles_x, tiles_y;
     int QH, QW, QS;          // shifted-operand tile: rows, cols, channel stride (odd)
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int l31 = lane & 31, half = lane >> 5;
     const int wp = wid >> 1, wq = wid & 1;          // wave -> (plain channel block, shifted channel block)
 
-    const int s_chunk = blockIdx.x % p.S, b = blockIdx.x / p.S;
+    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;     // b: first sample of the group
     // rows of the result = co (A operand = g), cols = ci (B operand = x)
     const int co0 = blockIdx.y * (GSHIFT ? QCH : PCH), ci0 = blockIdx.z * (GSHIFT ? PCH : QCH);
 
@@ -95,8 +97,10 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int pH = GSHIFT ? p.Hx : p.Hg, pW = GSHIFT ? p.Wx : p.Wg;
     const int qH = GSHIFT ? p.Hg : p.Hx, qW = GSHIFT ? p.Wg : p.Wx;
     // one buffer descriptor per operand and sample: 32-bit offsets, hardware zero fill for masked elements
-    const __amdgpu_buffer_rsrc_t prs = make_rsrc(GSHIFT ? xP : gP, (unsigned)pC * pH * pW * 4u);
-    const __amdgpu_buffer_rsrc_t qrs = make_rsrc(GSHIFT ? gP : xP, (unsigned)qC * qH * qW * 4u);
+    // (a group's descriptors span its NB samples: host-checked to stay below the 2 GiB the zero-fill offset needs)
+    const unsigned p_sample = (unsigned)pC * pH * pW * 4u, q_sample = (unsigned)qC * qH * qW * 4u;      // bytes per sample
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(GSHIFT ? xP : gP, p_sample * (unsigned)p.NB);
+    const __amdgpu_buffer_rsrc_t qrs = make_rsrc(GSHIFT ? gP : xP, q_sample * (unsigned)p.NB);
     const int q_tile = p.QH * p.QW;
 
     f32x16 acc[NT];
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int a_ch = (GSHIFT ? qb : pb) * 32 + l31;     // co of this lane inside the block tile
     const int b_ch = (GSHIFT ? pb : qb) * 32 + l31;     // ci of this lane inside the block tile
 
-    const int n_tiles = p.tiles_x * p.tiles_y;
+    const int tiles_1 = p.tiles_x * p.tiles_y;      // cell tiles of one sample
+    const int n_tiles = tiles_1 * p.NB;             // tile index -> (sample of the group, cell tile)
     const int t_begin = (int)((int64_t)n_tiles * s_chunk / p.S), t_end = (int)((int64_t)n_tiles * (s_chunk + 1) / p.S);
 
     float preg[NP], qreg[NQ];
@@ -160,13 +165,16 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int v_qgo = (qc0 + v_qch) * qH * qW + 4 * v_sub;
     const int v_qlo = v_qch * QSV + ((KIND == TE_CONV_3X3) ? 1 : 0) + 4 * v_sub;
     auto issue_vec = [&](int tn) {
+        unsigned pso = 0, qso = 0;                       // byte offset of the tile's sample inside the group
+        if (p.NB > 1) { const int bb = tn / tiles_1; tn -= bb * tiles_1; pso = bb * p_sample; qso = bb * q_sample; }
         const int ty0 = (tn / p.tiles_x) * p.TH, tx0 = (tn % p.tiles_x) * p.TW;   // first cell of the tile
         const int qy0 = (KIND == TE_CONV_3X3) ? ty0 - 1 : (KIND == TE_CONV_T2 ? 2 * ty0 : ty0);
         const int qx0 = (KIND == TE_CONV_T2) ? 2 * tx0 : tx0;
         const int pb4 = (v_pgo + ty0 * pW + tx0) * 4;
 #pragma unroll
         for (int r = 0; r < NP4; ++r) {
-            const f32x4 v = buf_load4(prs, (unsigned)(pb4 + r * CSTEP * pH * pW * 4));     // channels past pC: beyond num_records -> 0
+            // channels past pC: beyond num_records -> 0 (one sample per group; a group's layers have whole channel blocks, host-checked)
+            const f32x4 v = buf_load4(prs, pso + (unsigned)(pb4 + r * CSTEP * pH * pW * 4));
 #pragma unroll
             for (int j = 0; j < 4; ++j) preg[4 * r + j] = v[j];
         }
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
             for (int r = 0; r < QRL; ++r) {
                 const int ry = (KIND == TE_CONV_T2) ? (r >> 1) : r, hx = (KIND == TE_CONV_T2) ? 32 * (r & 1) : 0;
                 const bool rok = (unsigned)(qy0 + ry) < (unsigned)qH;                       // wave-uniform
-                const f32x4 v = buf_load4(qrs, rok ? (unsigned)((qb + sw * (NTHREADS / 8) * qH * qW + ry * qW + hx) * 4) : OOB);
+                const f32x4 v = buf_load4(qrs, rok ? qso + (unsigned)((qb + sw * (NTHREADS / 8) * qH * qW + ry * qW + hx) * 4) : OOB);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qreg[4 * (sw * QRL + r) + j] = v[j];
             }
@@ -187,12 +195,12 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
             const bool ok = (unsigned)(qy0 + ry) < (unsigned)qH && (side ? tx0 + 32 < qW : tx0 > 0);
 #pragma unroll
             for (int sw = 0; sw < QSW; ++sw)
-                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + ry * qW + (side ? 32 : -1)) * 4) : OOB);
+                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? qso + (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + ry * qW + (side ? 32 : -1)) * 4) : OOB);
         } else if (KIND == TE_CONV_T2) {  // column 64 of the 65-wide rows: threads with sub < 3 take row sub
             const bool ok = v_sub < QHV;
 #pragma unroll
             for (int sw = 0; sw < QSW; ++sw)
-                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + v_sub * qW + 64) * 4) : OOB);
+                qreg[4 * QSW * QRL + sw] = buf_load(qrs, ok ? qso + (unsigned)((qb - 4 * v_sub + sw * (NTHREADS / 8) * qH * qW + v_sub * qW + 64) * 4) : OOB);
         }
     };
     auto commit_vec = [&](float* pl, float* ql) {
@@ -243,6 +251,8 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     };
     auto issue = [&](int tn) {                      // global loads of tile tn -> registers
         if (p.vec) { issue_vec(tn); return; }
+        unsigned pso = 0, qso = 0;
+        if (p.NB > 1) { const int bb = tn / tiles_1; tn -= bb * tiles_1; pso = bb * p_sample; qso = bb * q_sample; }
         const int ty0 = (tn / p.tiles_x) * p.TH, tx0 = (tn % p.tiles_x) * p.TW;   // first cell of the tile
         int qy0, qx0;
         if (KIND == TE_CONV_3X3) { qy0 = ty0 - 1; qx0 = tx0 - 1; }
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 const int chl = e >> p.lgNC, cell = e & (p.NC - 1);
                 const int y = ty0 + (cell >> p.lgTW), xx = tx0 + (cell & (p.TW - 1)), ch = pc0 + chl;
                 const bool ok = chl < PCH && y < p.H && xx < p.W && ch < pC;    // plain operand lives on the cell grid
-                preg[r] = buf_load(prs, ok ? (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
+                preg[r] = buf_load(prs, ok ? pso + (unsigned)((ch * pH + y) * pW + xx) * 4u : OOB);
             }
 #pragma unroll
             for (int r = 0; r < NQ; ++r) {
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
                 const unsigned ry = __umulhi(rem, p.magic_qw), rx = rem - ry * p.QW;
                 const int y = qy0 + (int)ry, xx = qx0 + (int)rx, ch = qc0 + (int)chl;
                 const bool ok = chl < QCH && (unsigned)y < (unsigned)qH && (unsigned)xx < (unsigned)qW && ch < qC;
-                qreg[r] = buf_load(qrs, ok ? (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
+                qreg[r] = buf_load(qrs, ok ? qso + (unsigned)((ch * qH + y) * qW + xx) * 4u : OOB);
             }
             }
     };
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     (void)ngrp;
 
     // ---- write the slab tile: rows = co, cols = ci;  slab[b][s][co][ci][tap]
-    float* sl = p.slabs + ((size_t)b * p.S + s_chunk) * p.Co * p.Ci * NT;
+    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * NT;
     const int ci = ci0 + b_ch;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -459,15 +469,15 @@ void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);
-    dim3 grid((unsigned)(a.B * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
+    dim3 grid((unsigned)(a.B / a.NB * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
     wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);
 }
 
 template <int KIND>
 int launch_wgrad(WgArgs a, hipStream_t s) {
     if (!fill_geometry<KIND>(a)) return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: unsupported image size %dx%d", a.H, a.W);
-    if ((int64_t)a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
-        return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: per-sample tensor exceeds 2 GiB");
+    if ((int64_t)a.NB * a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.NB * a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
+        return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: a sample group exceeds 2 GiB");
     if (pick_nwp(a.Co, a.Ci) == 2) launch_wgrad_t<KIND, 2>(a, s);
     else launch_wgrad_t<KIND, 4>(a, s);
     return 0;
@@ -774,14 +784,52 @@ extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W
     return (int)S;
 }
 
+// Plan of the GROUPED form (te_wgrad_group_f32): *NB samples share a slab, *S chunks per group.  Grouping pays where the slabs
+// are the traffic - small images under big weights (512 x 512 x 9 floats = 9.4 MB per slab: 302 MB written and read back for a
+// 4x4 ... 32x32 layer at batch 32 against 0.1 - 34 MB of activations) - and is only valid for the PLAIN gradient (no per-sample
+// modulation, no style / demodulation gradients: the discriminator's layers and the closed trio of op/modconv.py).
+// NB = the largest divisor of B that still leaves every CU a block; 1 when a sample alone already splits into chunks.
+extern "C" int te_wgrad_group_plan(int kind, int B, int Co, int Ci, int H, int W, int* NB_out, int* S_out) {
+    if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0 || !NB_out || !S_out) return TE_ERR_SHAPE;
+    const int tiles = n_cell_tiles(kind, H, W);
+    const int64_t mn1 = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH);
+    const int64_t per_sample = std::max<int64_t>((int64_t)Co * (kind == TE_CONV_T2 ? (2 * H + 1) * (2 * W + 1) : H * W), (int64_t)Ci * H * W) * 4;
+    int NB = 1;
+    // whole channel blocks only: the 16-byte staging path masks a channel tail through the END of the sample's buffer range, and
+    // a group's range continues into the next sample
+    if (te_wgrad_slab_count(kind, B, Co, Ci, H, W) == 1 && Co % 128 == 0 && Ci % 128 == 0) {
+        for (int d = 2; d <= B; ++d)
+            if (B % d == 0 && (B / d) * mn1 >= te::kNumCU && (int64_t)d * per_sample < (int64_t)OOB) NB = d;
+    }
+    const int64_t mn = mn1 * (B / NB);
+    int64_t S = te::cdiv((int64_t)((kind == TE_CONV_1X1) ? 2 : 1) * te::kNumCU, mn);
+    S = std::max<int64_t>(1, std::min<int64_t>(S, (int64_t)tiles * NB));
+    *NB_out = NB; *S_out = (int)S;
+    return 0;
+}
+
+static int wgrad_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB,
+                        te_stream_t stream_);
+
+extern "C" int te_wgrad_group_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W,
+                                  int S, int NB, te_stream_t stream_) {
+    TE_REQUIRE(NB > 0 && B > 0 && B % NB == 0, TE_ERR_SHAPE, "te_wgrad_group_f32: the group size must divide the batch");
+    return wgrad_launch(slabs, g, x, kind, B, Co, Ci, H, W, S, NB, stream_);
+}
+
 extern "C" int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W,
                             int S, te_stream_t stream_) {
+    return wgrad_launch(slabs, g, x, kind, B, Co, Ci, H, W, S, 1, stream_);
+}
+
+static int wgrad_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB,
+                        te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && H > 0 && W > 0 && S > 0, TE_ERR_SHAPE, "te_wgrad_f32: bad dims");
     TE_REQUIRE((int64_t)B * S <= 0x7FFFFFFF && te::cdiv(Co, QCH) <= 65535 && te::cdiv(Ci, QCH) <= 65535, TE_ERR_SHAPE,
                "te_wgrad_f32: grid too large");
     WgArgs a{};
-    a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S;
+    a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB;
     a.Hx = H; a.Wx = W;
     hipStream_t s = (hipStream_t)stream_;
     int rc;

@@ -323,13 +323,14 @@ def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
     return _lib.conv(g, wp, _KIND[kind], w.shape[1], H, W, isc, osc)
 
 
-def _wgrad_raw(g, x, kind):
-    """per-sample correlation slabs [B, S, Co, Ci, taps] ('down': [B, S, Ci, Co, taps], see _slab_sum)."""
+def _wgrad_raw(g, x, kind, group=False):
+    """per-sample correlation slabs [B, S, Co, Ci, taps] ('down': [B, S, Ci, Co, taps], see _slab_sum).  group=True: the caller
+    only sums them (plain gradient), so several samples may share a slab (_lib.wgrad_slabs)."""
     if kind == 'down':     # same correlation as 'up' with the roles of the two tensors swapped
         H, W = g.shape[2], g.shape[3]
-        return _lib.wgrad_slabs(x, g, _lib.CONV_T2, H, W)
+        return _lib.wgrad_slabs(x, g, _lib.CONV_T2, H, W, group)
     H, W = x.shape[2], x.shape[3]
-    return _lib.wgrad_slabs(g, x, _KIND[kind], H, W)
+    return _lib.wgrad_slabs(g, x, _KIND[kind], H, W, group)
 
 
 def _slab_sum(slabs, kind):
@@ -341,7 +342,7 @@ def _slab_sum(slabs, kind):
 def _wgrad_plain(gy, x, kind, ksize, wscale):
     """wscale * sum of the correlation slabs -> [Co, Ci, k, k] (te_wgrad_reduce_f32 without modulation; 'down' slabs come
     transposed and go through the framework's reduction)"""
-    slabs = _wgrad_raw(gy, x, kind)
+    slabs = _wgrad_raw(gy, x, kind, group=True)
     Co, Ci = gy.shape[1], x.shape[1]
     if kind == 'down':
         gw = _slab_sum(slabs, kind)
