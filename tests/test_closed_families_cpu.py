@@ -103,3 +103,121 @@ def test_attention_recorded_backward_expression(emulated_gemms, monkeypatch, N):
         return (o, sim) + tuple(g1) + tuple(torch.autograd.grad(sum(t.square().sum() for t in g1), (q, k, v)))
     for name, x, y in zip(('o', 'sim', 'gq', 'gk', 'gv', 'ggq', 'ggk', 'ggv'), second(att._torch_expr), second(plain_attention)):
         assert torch.allclose(x, y, rtol=1e-9, atol=1e-11), name
+
+
+# ------------------------------------------------------------------------------------------------ convolution trio + composite
+import math
+
+import torch.nn.functional as F
+
+from transeditor_amd.op import chanscale, modconv
+
+
+def _conv_ref(x, w, kind):
+    """the four kinds as stock framework convolutions (op/modconv.py::_KIND; 'up' = transposed stride 2 -> 2H+1, 'down' = stride 2)"""
+    if kind == '3x3':
+        return F.conv2d(x, w, padding=1)
+    if kind == '1x1':
+        return F.conv2d(x, w)
+    if kind == 'up':
+        return F.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+    return F.conv2d(x, w, stride=2)
+
+
+@pytest.fixture
+def emulated_conv_ops(monkeypatch):
+    """helper-level restatements (op/modconv.py docstrings): forward, data gradient, plain weight gradient of a kind; the
+    per-channel scale pair; the fused bias + leaky-ReLU kernels (te_hip.h: out = lrelu(x + b) * scale; grad mode: (x + b) *
+    slope(ref) * scale; backward pass: g * slope(ref) * scale and its sum over everything but the channel)."""
+    def in_shape(g, w, kind):
+        B, H, W = g.shape[0], g.shape[2], g.shape[3]
+        return {'3x3': (B, w.shape[1], H, W), '1x1': (B, w.shape[1], H, W), 'up': (B, w.shape[1], (H - 1) // 2, (W - 1) // 2),
+                'down': (B, w.shape[1], 2 * H + 1, 2 * W + 1)}[kind]
+
+    def fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0, with_bwd_pack=False):
+        assert isc is None and osc is None and bias is None and not act and not with_bwd_pack
+        return _conv_ref(x, w * wscale, kind)
+
+    def dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
+        assert isc is None and osc is None
+        with torch.enable_grad():
+            x0 = torch.zeros(in_shape(g, w, kind), dtype=g.dtype, requires_grad=True)
+            gx, = torch.autograd.grad(_conv_ref(x0, w.detach() * wscale, kind), x0, g.detach())
+        return gx
+
+    def wgrad_plain(gy, x, kind, ksize, wscale):
+        with torch.enable_grad():
+            w0 = torch.zeros(gy.shape[1], x.shape[1], ksize, ksize, dtype=gy.dtype, requires_grad=True)
+            gw, = torch.autograd.grad(_conv_ref(x.detach(), w0 * wscale, kind), w0, gy.detach())
+        return gw
+
+    slope = lambda ref, alpha: torch.where(ref > 0, 1.0, alpha).to(ref.dtype)
+    bshape = lambda x: (1, -1) + (1,) * (x.dim() - 2)
+
+    def bias_act(x, b, ref, act, grad, alpha, scale):
+        assert act == 3
+        v = x if b is None else x + b.reshape(bshape(x))
+        return (F.leaky_relu(v, alpha) if grad == 0 else v * slope(ref, alpha)) * scale
+
+    def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
+        gi = g * slope(ref, alpha) * scale
+        return gi, (gi.sum(dim=[0] + list(range(2, gi.dim()))) if want_bias else None)
+    monkeypatch.setattr(modconv, '_fwd_raw', fwd_raw)
+    monkeypatch.setattr(modconv, '_dgrad_raw', dgrad_raw)
+    monkeypatch.setattr(modconv, '_wgrad_plain', wgrad_plain)
+    monkeypatch.setattr(_lib, 'chan_scale', lambda x, s: x * s.reshape(*s.shape, *([1] * (x.dim() - 2))))
+    monkeypatch.setattr(_lib, 'chan_dot', lambda a, b: (a * b).flatten(2).sum(2))
+    monkeypatch.setattr(_lib, 'bias_act', bias_act)
+    monkeypatch.setattr(_lib, 'bias_act_bwd', bias_act_bwd)
+    monkeypatch.setattr(modconv, 'chan_scale', lambda x, s: chanscale._ChanScale.apply(x, s))       # (the wrapper asks for a GPU tensor)
+
+
+@pytest.mark.parametrize('kind', ['3x3', '1x1', 'up', 'down'])
+def test_conv_trio_algebra(emulated_conv_ops, kind):
+    """y = conv(x, wscale w) through _ConvFwd and, by differentiation, _ConvDgrad / _ConvWgrad (each one's backward is the
+    other two, with the same constant): value, both gradients, second differentiation, for the four kinds"""
+    torch.manual_seed(3)
+    ks = 1 if kind == '1x1' else 3
+    x = torch.randn(2, 3, 7 if kind == 'down' else 4, 9 if kind == 'down' else 5, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 3, ks, ks, dtype=torch.float64, requires_grad=True)
+    ref = lambda x, w: _conv_ref(x, w * 0.37, kind)
+    gy = torch.randn_like(ref(x, w))
+    want = _second_order(ref, (x, w), gy)
+    got = _second_order(lambda x, w: modconv.conv_core(x, w, kind, 0.37), (x, w), gy)
+    for name, a, b in zip(('y', 'gx', 'gw', 'ggx', 'ggw'), got, want):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-12), name
+
+
+@pytest.mark.parametrize('kind,act', [('3x3', True), ('up', False), ('down', True), ('1x1', 1.0)])
+def test_modulated_conv_composite_algebra(emulated_conv_ops, kind, act):
+    """the any-order composite of the modulated convolution (style scale -> trio -> demodulation scale -> bias + leaky ReLU,
+    op/modconv.py::_composite) against the broadcast expression, through a path-length-style probe: gradients w.r.t. the input
+    and the style with create_graph, then the gradient of their squares w.r.t. EVERY input (model_spatial_query.py:296-337 +
+    train_spatial_query.py:92-105)"""
+    torch.manual_seed(4)
+    B, Ci, Co = 2, 3, 4
+    ks = 1 if kind == '1x1' else 3
+    x = torch.randn(B, Ci, 7 if kind == 'down' else 4, 7 if kind == 'down' else 4, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, ks, ks, dtype=torch.float64, requires_grad=True)
+    s = (1 + 0.3 * torch.randn(B, Ci, dtype=torch.float64)).requires_grad_(True)
+    d = (1 + 0.3 * torch.randn(B, Co, dtype=torch.float64)).requires_grad_(True)
+    bias = torch.randn(Co, dtype=torch.float64, requires_grad=True)
+    ins = (x, w, s, d, bias)
+
+    def plain(x, w, s, d, bias):
+        y = _conv_ref(x * s[:, :, None, None], w * 0.21, kind) * d[:, :, None, None] + bias[None, :, None, None]
+        return F.leaky_relu(y, 0.2) * (math.sqrt(2) if act is True else float(act)) if act else y
+
+    def ours(x, w, s, d, bias):
+        return modconv._composite(x, w, s, d, bias, act, kind, 0.21)
+    gy = torch.randn_like(plain(*ins))
+
+    def probe(f):
+        y = f(*ins)
+        gx, gs = torch.autograd.grad(y, (x, s), gy, create_graph=True)
+        return (y, gx, gs) + tuple(torch.autograd.grad(gx.square().sum() + gs.square().sum(), ins, allow_unused=True))
+    for name, a, b in zip(('y', 'gx', 'gs', 'Gx', 'Gw', 'Gs', 'Gd', 'Gbias'), probe(ours), probe(plain)):
+        if b is None:            # (without an activation the probe does not depend on the bias)
+            assert a is None or float(a.abs().max()) == 0, name
+        else:
+            assert torch.allclose(a, b, rtol=1e-9, atol=1e-11), name
