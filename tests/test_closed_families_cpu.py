@@ -151,7 +151,7 @@ def emulated_conv_ops(monkeypatch):
             gw, = torch.autograd.grad(_conv_ref(x.detach(), w0 * wscale, kind), w0, gy.detach())
         return gw
 
-    slope = lambda ref, alpha: torch.where(ref > 0, 1.0, alpha).to(ref.dtype)
+    slope = lambda ref, alpha: torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, alpha))      # (in ref's precision)
     bshape = lambda x: (1, -1) + (1,) * (x.dim() - 2)
 
     def bias_act(x, b, ref, act, grad, alpha, scale):
