@@ -260,3 +260,33 @@ def test_fused_adam_loads_reference_style_optimizer_state():
     opt.state[p[0]]['step'] = 9                          # assigned behind the optimiser's back: normalised at the next step
     FusedAdam._host_step(opt.state[p[0]])
     assert float(opt.state[p[0]]['step']) == 9.0 and torch.is_tensor(opt.state[p[0]]['step'])
+
+
+def test_wgrad_group_plan_invariants():
+    """te_wgrad_group_plan is host code (no GPU): NB divides B, is 1 wherever grouping must not apply (channel tails - the 16-byte
+    staging path masks a tail through the end of the sample's buffer range -, a sample that already splits into chunks, too few
+    blocks left), keeps every CU a block when it groups, and a group stays below the 2 GiB the zero-fill offset needs."""
+    import ctypes as C
+    from transeditor_amd import _lib
+    L = _lib.lib()
+
+    def plan(kind, B, Co, Ci, H, W):
+        nb, s = C.c_int(0), C.c_int(0)
+        assert L.te_wgrad_group_plan(kind, B, Co, Ci, H, W, C.byref(nb), C.byref(s)) == 0
+        return nb.value, s.value
+    for kind in (_lib.CONV_3X3, _lib.CONV_T2, _lib.CONV_1X1):
+        for B in (1, 2, 8, 12, 16, 32, 64):
+            for Co, Ci in ((512, 512), (512, 513), (130, 512), (128, 128), (256, 512)):
+                for H in (1, 4, 8, 33, 64, 256):
+                    nb, s = plan(kind, B, Co, Ci, H, H)
+                    assert nb >= 1 and B % nb == 0 and s >= 1, (kind, B, Co, Ci, H, nb, s)
+                    if Co % 128 or Ci % 128 or L.te_wgrad_slab_count(kind, B, Co, Ci, H, H) > 1:
+                        assert nb == 1, (kind, B, Co, Ci, H, nb)
+                    if nb > 1:
+                        tiles = -(-Co * Ci // (128 * 64))
+                        assert (B // nb) * tiles >= 256
+                        biggest = max(Co * ((2 * H + 1) ** 2 if kind == _lib.CONV_T2 else H * H), Ci * H * H) * 4
+                        assert nb * biggest < 2 ** 31
+    assert plan(_lib.CONV_3X3, 32, 512, 512, 4, 4) == (4, 1) and plan(_lib.CONV_3X3, 16, 512, 512, 16, 16)[0] == 2
+    nb, s = C.c_int(0), C.c_int(0)
+    assert L.te_wgrad_group_plan(_lib.CONV_3X3, 0, 512, 512, 4, 4, C.byref(nb), C.byref(s)) != 0      # bad dims are refused
