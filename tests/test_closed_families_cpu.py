@@ -221,3 +221,115 @@ def test_modulated_conv_composite_algebra(emulated_conv_ops, kind, act):
             assert a is None or float(a.abs().max()) == 0, name
         else:
             assert torch.allclose(a, b, rtol=1e-9, atol=1e-11), name
+
+
+# ------------------------------------------------------------------------------------------------ batched launches (pointer tables)
+import ctypes
+
+
+@pytest.fixture
+def emulated_batched_gemm(monkeypatch, emulated_gemms):
+    """te_small_gemm_batched_f32 with its per-z pointer tables (te_hip.h: operand z = b + b_tab[z] elements, bias + bias_tab[z]):
+    the emulation resolves the tables through the CPU tensors' addresses, so the launches below really read separately
+    allocated parameters the way the kernel does (fp32: the tables count 4-byte elements)."""
+    def at(base, off, n):
+        return torch.frombuffer((ctypes.c_float * n).from_address(base.data_ptr() + 4 * off), dtype=torch.float32)
+
+    def small_gemm_batched(c, a, b, bias, nz, za, zc, I, J, K, sai, sak, sbk, sbj, sci, scj, zb=0, zbias=0, b_tab=None,
+                           bias_tab=None, alpha=1.0, beta=1.0, act=0):
+        assert a.dtype == torch.float32
+        for z in range(nz):
+            A = torch.as_strided(a, (I, K), (sai, sak), a.storage_offset() + z * za)
+            if b_tab is not None:
+                span = (K - 1) * sbk + (J - 1) * sbj + 1
+                B = torch.as_strided(at(b, b_tab[z], span), (K, J), (sbk, sbj))
+            else:
+                B = torch.as_strided(b, (K, J), (sbk, sbj), b.storage_offset() + z * zb)
+            y = alpha * (A @ B)
+            if bias is not None:
+                y = y + beta * (at(bias, bias_tab[z], J) if bias_tab is not None else
+                                torch.as_strided(bias, (J,), (1,), bias.storage_offset() + z * zbias))
+            if act == 3:
+                y = F.leaky_relu(y, 0.2) * math.sqrt(2)
+            else:
+                assert act == 0
+            torch.as_strided(c, (I, J), (sci, scj), c.storage_offset() + z * zc).copy_(y)
+        return c
+    slope = lambda ref, alpha: torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, alpha))
+
+    def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
+        gi = g * slope(ref, alpha) * scale
+        return gi, (gi.sum(dim=[0] + list(range(2, gi.dim()))) if want_bias else None)
+    monkeypatch.setattr(_lib, 'small_gemm_batched', small_gemm_batched)
+    monkeypatch.setattr(_lib, 'bias_act_bwd', bias_act_bwd)
+
+
+def _layers(n, K, J, seed):
+    g = torch.Generator().manual_seed(seed)
+    ws = [torch.randn(J, K, generator=g).requires_grad_(True) for _ in range(n)]          # separately allocated, like nn.Parameters
+    bs = [torch.randn(J, generator=g).requires_grad_(True) for _ in range(n)]
+    return ws, bs
+
+
+def _compare(got, want, tol=2e-5):
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-7, i
+
+
+def test_shared_input_linears_plumbing(emulated_batched_gemm):
+    """_SharedInputLinears (k / v and the query projections of the attention blocks as one launch): strides, pointer tables, the
+    slab sum of dx, every dW / db, and the recorded backward, against per-layer F.linear"""
+    ws, bs = _layers(3, 12, 5, 0)
+    x = torch.randn(2, 4, 12, requires_grad=True)
+    gys = [torch.randn(2, 4, 5) for _ in range(3)]
+    ours = lambda: lin._SharedInputLinears.apply(x, 0.3, 0.7, 3, *ws, *bs)
+    plain = lambda: [F.linear(x, w * 0.3, b * 0.7) for w, b in zip(ws, bs)]
+    for a, b in zip(ours(), plain()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    _compare(torch.autograd.grad(ours(), [x] + ws + bs, gys), torch.autograd.grad(plain(), [x] + ws + bs, gys))
+    g1, = torch.autograd.grad(ours(), x, gys, create_graph=True)
+    g2, = torch.autograd.grad(plain(), x, gys, create_graph=True)
+    _compare(torch.autograd.grad(g1.square().sum(), ws), torch.autograd.grad(g2.square().sum(), ws))
+
+
+def test_batched_modulation_plumbing(emulated_batched_gemm):
+    """_BatchedModulation (all style modulations of a pass, grouped by width): group-major gather, per-group launches with the
+    latent's strides, scatter of d latent, dW / db, recorded backward"""
+    from transeditor_amd.op import modulation
+    K, widths = 8, [6, 6, 3, 6, 3]
+    order = [i for _, ids in modulation._groups(widths) for i in ids]
+    g = torch.Generator().manual_seed(1)
+    ws = [torch.randn(wd, K, generator=g).requires_grad_(True) for wd in widths]
+    bs = [torch.randn(wd, generator=g).requires_grad_(True) for wd in widths]
+    lat = torch.randn(3, 4, K, requires_grad=True)
+    index = [0, 1, 1, 3, 2]
+    gys = [torch.randn(3, wd) for wd in widths]
+
+    def ours():
+        lat_g = lat.index_select(1, torch.tensor([index[i] for i in order]))
+        outs = modulation._BatchedModulation.apply(lat_g, 0.5, 1.0, len(widths), *[ws[i] for i in order], *[bs[i] for i in order])
+        res = [None] * len(widths)
+        for pos, i in enumerate(order):
+            res[i] = outs[pos]
+        return res
+    plain = lambda: [F.linear(lat[:, index[i]], ws[i] * 0.5, bs[i]) for i in range(len(widths))]
+    for a, b in zip(ours(), plain()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    _compare(torch.autograd.grad(ours(), [lat] + ws + bs, gys), torch.autograd.grad(plain(), [lat] + ws + bs, gys))
+    g1, = torch.autograd.grad(ours(), lat, gys, create_graph=True)
+    g2, = torch.autograd.grad(plain(), lat, gys, create_graph=True)
+    _compare(torch.autograd.grad(g1.square().sum(), ws), torch.autograd.grad(g2.square().sum(), ws))
+
+
+def test_token_mlp_plumbing(emulated_batched_gemm):
+    """_TokenMLP (model_spatial_query.py:626-646: token t through its own EqualLinear + fused lrelu, one launch): the in-place
+    read of the [B, D, tokens] code, the [B, T, D] write, dx back into the code's layout (tokens >= T get zeros), dW / db"""
+    from transeditor_amd.op import token_mlp as tm
+    B, D, Cn, T = 3, 8, 6, 4
+    ws, bs = _layers(T, D, D, 2)
+    x = torch.randn(B, D, Cn, requires_grad=True)
+    gy = torch.randn(B, T, D)
+    ours = lambda: tm._TokenMLP.apply(x, 0.2, 0.5, T, *ws, *bs)
+    plain = lambda: torch.stack([F.leaky_relu(F.linear(x[:, :, t], ws[t] * 0.2, bs[t] * 0.5), 0.2) * math.sqrt(2) for t in range(T)], 1)
+    assert torch.allclose(ours(), plain(), rtol=1e-5, atol=1e-6)
+    _compare(torch.autograd.grad(ours(), [x] + ws + bs, gy), torch.autograd.grad(plain(), [x] + ws + bs, gy))
