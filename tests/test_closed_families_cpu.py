@@ -333,3 +333,57 @@ def test_token_mlp_plumbing(emulated_batched_gemm):
     plain = lambda: torch.stack([F.leaky_relu(F.linear(x[:, :, t], ws[t] * 0.2, bs[t] * 0.5), 0.2) * math.sqrt(2) for t in range(T)], 1)
     assert torch.allclose(ours(), plain(), rtol=1e-5, atol=1e-6)
     _compare(torch.autograd.grad(ours(), [x] + ws + bs, gy), torch.autograd.grad(plain(), [x] + ws + bs, gy))
+
+
+# ------------------------------------------------------------------------------------------------ ResBlock composite (R1 route)
+def _upfirdn2d_general(x, k, up, down, pad):
+    """te_upfirdn2d_f32's contract (te_hip.h / upfirdn2d_kernel.cu:85-129) with per-axis factors and per-side pads: zero-insert,
+    pad (negative = crop), TRUE convolution with k, keep every down-th sample.  up / down = (x, y), pad = (px0, px1, py0, py1)."""
+    B, C, H, W = x.shape
+    px0, px1, py0, py1 = pad
+    z = x.new_zeros(B * C, 1, H * up[1], W * up[0])
+    z[:, :, ::up[1], ::up[0]] = x.reshape(B * C, 1, H, W)
+    z = F.pad(z, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+    z = z[:, :, max(-py0, 0): z.shape[2] - max(-py1, 0), max(-px0, 0): z.shape[3] - max(-px1, 0)]
+    y = F.conv2d(z, torch.flip(k, [0, 1]).to(x.dtype).reshape(1, 1, *k.shape))[:, :, ::down[1], ::down[0]]
+    return y.reshape(B, C, y.shape[2], y.shape[3])
+
+
+@pytest.mark.parametrize('stem', [False, True])
+def test_resblock_composite_algebra(emulated_conv_ops, monkeypatch, stem):
+    """the any-order form of the discriminator's ResBlock (op/resblock.py::resblock_composite: what R1 differentiates twice, with
+    the from-RGB stem in front for the first block) against the reference's layer sequence (model_spatial_query.py:731-798:
+    conv3x3 + lrelu, Blur(2,2) + stride-2 conv + lrelu, skip = Blur(1,1) + stride-2 1x1 conv, (out + skip) / sqrt(2)), through an
+    R1-style probe: d pred / d input with create_graph, then the gradient of its square w.r.t. every parameter"""
+    from oracle import te_oracle as O
+    from transeditor_amd.op import resblock as rb
+    monkeypatch.setattr(_lib, 'upfirdn2d_raw',
+                        lambda x, k, up, down, pad, bias=None, act=0, alpha=0.2, scale=1.0: _upfirdn2d_general(x, k, up, down, pad))
+    torch.manual_seed(5)
+    dt = torch.float64
+    Cin, C1, C2 = (3 if stem else 4), 4, 6
+    k = O.fir_kernel((1, 3, 3, 1)).to(dt)
+    x = torch.randn(2, Cin, 8, 8, dtype=dt, requires_grad=True)
+    P = [torch.randn(*s, dtype=dt, requires_grad=True) for s in [(C1, C1, 3, 3), (C1,), (C2, C1, 3, 3), (C2,), (C2, C1, 1, 1)]]
+    S = [torch.randn(*s, dtype=dt, requires_grad=True) for s in [(C1, 3, 1, 1), (C1,)]] if stem else []
+    s1, s2, ss, s0, gain = 0.3, 0.25, 0.5, 0.6, 1 / math.sqrt(2)
+    lrelu = lambda t: F.leaky_relu(t, 0.2) * math.sqrt(2)
+
+    def plain(x, w1, b1, w2, b2, ws, *st):
+        if st:
+            x = lrelu(F.conv2d(x, st[0] * s0) + st[1][None, :, None, None])
+        out = lrelu(F.conv2d(x, w1 * s1, padding=1) + b1[None, :, None, None])
+        out = lrelu(F.conv2d(O.upfirdn2d(out, k, pad=(2, 2)), w2 * s2, stride=2) + b2[None, :, None, None])
+        skip = F.conv2d(O.upfirdn2d(x, k, pad=(1, 1)), ws * ss, stride=2)
+        return (out + skip) / math.sqrt(2)
+
+    def ours(x, w1, b1, w2, b2, ws, *st):
+        return rb.resblock_composite(x, w1, b1, w2, b2, ws, k, k, s1, s2, ss, (2, 2), (1, 1), gain, *(st + ((s0,) if st else ())))
+    gy = torch.randn_like(plain(x, *P, *S))
+
+    def probe(f):
+        y = f(x, *P, *S)
+        gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+        return (y, gx) + tuple(torch.autograd.grad(gx.square().sum(), P + S))
+    for i, (a, b) in enumerate(zip(probe(ours), probe(plain))):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-11), i
