@@ -290,3 +290,18 @@ def test_wgrad_group_plan_invariants():
     assert plan(_lib.CONV_3X3, 32, 512, 512, 4, 4) == (4, 1) and plan(_lib.CONV_3X3, 16, 512, 512, 16, 16)[0] == 2
     nb, s = C.c_int(0), C.c_int(0)
     assert L.te_wgrad_group_plan(_lib.CONV_3X3, 0, 512, 512, 4, 4, C.byref(nb), C.byref(s)) != 0      # bad dims are refused
+
+
+def test_minibatch_stddev_chunks_expression():
+    """the recorded-backward expression of the minibatch stddev with `chunks` (Discriminator.forward(x, chunks=2): the D step's
+    fake and real passes as one batch) is the per-pass statistic of model_spatial_query.py:844-852 laid end to end - and differs
+    from the statistic of the joined batch"""
+    import torch
+    from transeditor_amd.op.stddev import _torch_expr
+    from plain_torch import minibatch_stddev as plain
+    torch.manual_seed(0)
+    a, b = torch.randn(8, 6, 4, 4, dtype=torch.float64), torch.randn(8, 6, 4, 4, dtype=torch.float64)
+    joint = _torch_expr(torch.cat([a, b]), 4, 1, chunks=2)
+    assert torch.allclose(joint, torch.cat([plain(a, 4), plain(b, 4)]), rtol=1e-12, atol=1e-14)
+    assert not torch.allclose(joint, plain(torch.cat([a, b]), 4))
+    assert torch.equal(_torch_expr(a, 4, 1, chunks=1), plain(a, 4))
