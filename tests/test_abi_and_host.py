@@ -305,3 +305,49 @@ def test_minibatch_stddev_chunks_expression():
     assert torch.allclose(joint, torch.cat([plain(a, 4), plain(b, 4)]), rtol=1e-12, atol=1e-14)
     assert not torch.allclose(joint, plain(torch.cat([a, b]), 4))
     assert torch.equal(_torch_expr(a, 4, 1, chunks=1), plain(a, 4))
+
+
+def test_packed_weight_cache_refresh_logic(monkeypatch):
+    """host logic of the packed-weight cache (op/modconv.py) with the packing launches replaced by fakes: hits while the version
+    counter stands, ONE multi-tensor refresh of exactly the stale entries after an optimiser step (in place), entries of partial
+    views dropped, temporaries never cached"""
+    import torch
+    from transeditor_amd import _lib
+    from transeditor_amd.op import modconv as mc
+    calls = {'single': 0, 'multi': []}
+
+    def conv_pack(w, kind, wscale=1.0):
+        calls['single'] += 1
+        return (w.detach().flatten() * wscale + kind).clone()
+
+    def conv_pack2(w, ka, kb, wscale=1.0):
+        return conv_pack(w, ka, wscale), conv_pack(w, kb, wscale)
+
+    def conv_pack_multi(jobs):
+        calls['multi'].append(len(jobs))
+        for wp, w, kind, wscale in jobs:
+            wp.copy_(w.flatten() * wscale + kind)
+    monkeypatch.setattr(_lib, 'conv_pack', conv_pack)
+    monkeypatch.setattr(_lib, 'conv_pack2', conv_pack2)
+    monkeypatch.setattr(_lib, 'conv_pack_multi', conv_pack_multi)
+    p5 = torch.nn.Parameter(torch.randn(1, 4, 3, 3, 3))          # ModulatedConv2d layout: the op sees weight[0]
+    p4 = torch.nn.Parameter(torch.randn(4, 3, 1, 1))
+    p2 = torch.nn.Parameter(torch.randn(2, 4, 3, 3, 3))          # a PARTIAL view of it is cached but cannot be refreshed in bulk
+    cache = {}
+    with mc.packed_weights_cache(cache):
+        a = mc.packed(p5[0], 0, 0.5)
+        mc.packed2(p4, 0, 1, 2.0)
+        mc.packed(p2[1], 0, 1.0)
+        assert mc.packed(p5[0], 0, 0.5) is a and calls['single'] == 4 and len(cache) == 4
+        mc.packed(torch.randn(4, 3, 3, 3), 0, 1.0)                # a temporary: packed, not cached
+        assert len(cache) == 4 and calls['single'] == 5
+        assert mc.refresh_packed_weights(cache) == 0 and calls['multi'] == [0]
+        with torch.no_grad():
+            for p in (p5, p4, p2):
+                p.mul_(2.0)                                       # "optimiser step": version counters move
+        assert mc.refresh_packed_weights(cache) == 3 and calls['multi'][-1] == 3      # p5 (1 layout) + p4 (2 layouts); the partial view is dropped
+        assert len(cache) == 3
+        assert mc.packed(p5[0], 0, 0.5) is a and torch.equal(a, p5.detach()[0].flatten() * 0.5)      # rewritten in place, a hit again
+        assert calls['single'] == 5
+        mc.packed(p2[1], 0, 1.0)                                  # the dropped entry is repacked at its next use
+        assert calls['single'] == 6 and len(cache) == 4
