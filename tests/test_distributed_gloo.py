@@ -277,3 +277,81 @@ def test_gradsync_global_used_mask_and_stragglers_world2():
             assert ma is not None and mb is not None, (key, i)
             assert np.abs(ma - mean).max() < 1e-6 and np.abs(mb - mean).max() < 1e-6, (key, i)
             assert (ma == mb).all(), (key, i)
+
+
+class _TwoOrders(torch.nn.Module):
+    """two parameters of one bucket whose gradients arrive in an order the caller chooses (autograd runs the younger branch first)"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.ones(4))
+        self.b = torch.nn.Parameter(torch.ones(4))
+
+    def forward(self, x, use_b, b_first):
+        if not use_b:
+            return (x * self.a).sum()
+        if b_first:                       # b's branch is the younger one: its gradient is reported first
+            ta = (x * self.a).sum()
+            return ta + (2 * x * self.b).sum()
+        tb = (2 * x * self.b).sum()
+        return tb + (x * self.a).sum()
+
+
+def _worker_mixed_straggler(rank, world, port, q):
+    import torch.distributed as dist
+    from transeditor_amd.utils import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        net = _TwoOrders()
+        sync = D.GradSync(net)
+        assert len(sync.buckets) == 1
+
+        def run(tag, use_b, b_first, seed):
+            for prm in net.parameters():
+                prm.grad = None
+            torch.manual_seed(seed + rank)
+            x = torch.randn(4)
+            loss = net(x, use_b, b_first)
+            ref = torch.autograd.grad(loss, [net.a, net.b], retain_graph=True, allow_unused=True)
+            loss.backward()
+            late = [p is net.b for p in sync._late]
+            sync.all_reduce(tag)
+            return ([None if g is None else g.numpy() for g in ref],
+                    [None if prm.grad is None else prm.grad.clone().numpy() for prm in net.parameters()], late)
+        out = {}
+        for i in range(3):                # kind 'x': b unused everywhere -> learnt as unused, the hooks stop waiting for it
+            out[f'x{i}'] = run('x', False, False, 10 * i)
+        assert net.b in sync._unused
+        # kind 'y': b used on both ranks; on rank 0 its gradient is ON TIME (reported before a's, packed into the bucket), on
+        # rank 1 it is LATE (a's gradient launches the bucket first): rank 0's share must not be lost (ADVICE round 3)
+        out['y0'] = run('y', True, rank == 0, 100)
+        assert out['y0'][2] == ([] if rank == 0 else [True]), out['y0'][2]
+        out['y1'] = run('y', True, rank == 0, 110)
+        q.put((rank, {k: v[:2] for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_straggler_on_one_rank_keeps_the_on_time_share_world2():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_mixed_straggler, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, oa), (_, ob) = res
+    for key in oa:
+        (ra, ga), (rb, gb) = oa[key], ob[key]
+        for i, (x, y, ma, mb) in enumerate(zip(ra, rb, ga, gb)):
+            if x is None and y is None:
+                assert ma is None and mb is None, key
+                continue
+            mean = (x + y) / 2
+            assert np.abs(ma - mean).max() < 1e-6 and np.abs(mb - mean).max() < 1e-6, (key, i, ma, mb, mean)
+            assert (ma == mb).all(), (key, i)

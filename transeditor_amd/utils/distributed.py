@@ -49,6 +49,25 @@ def gather_grad(params):
             param.grad.data.div_(world_size)
 
 
+def all_gather(data):
+    """Every rank's picklable `data` as a list in rank order (utils/distributed.py:67-99: byte tensors padded to the longest
+    payload, one size exchange + one all_gather).  The payload travels on the device the backend communicates from."""
+    import pickle
+    world_size = get_world_size()
+    if world_size == 1:
+        return [data]
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    payload = torch.frombuffer(bytearray(pickle.dumps(data)), dtype=torch.uint8).to(dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world_size)]
+    dist.all_gather(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device=dev))
+    sizes = [int(s.item()) for s in sizes]
+    buf = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
+    buf[:payload.numel()] = payload
+    parts = [torch.empty_like(buf) for _ in range(world_size)]
+    dist.all_gather(parts, buf)
+    return [pickle.loads(t[:n].cpu().numpy().tobytes()) for n, t in zip(sizes, parts)]
+
+
 def reduce_loss_dict(loss_dict):
     """Mean of each loss over ranks, valid on rank 0 (reduce to dst=0), keys in sorted order."""
     world_size = get_world_size()
@@ -263,9 +282,13 @@ class GradSync:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX)
             for p, f in zip(cands, flags.tolist()):
                 if f > 0.5:
+                    # ranks on which the gradient was on time have their share in the bucket already (a late rank packed zeros
+                    # there): reduce the late shares only and add the bucket's averaged slice, identical on every rank
+                    bi, off = self._slot[p]
+                    share = self._flat[bi][off:off + p.numel()].view_as(p)
                     g = p.grad if p in late_local else torch.zeros_like(p)
                     dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                    p.grad = g.div_(world)
+                    p.grad = g.div_(world).add_(share)
         elif late_local:
             raise RuntimeError('GradSync: a gradient arrived after its bucket was launched outside a warm-up call')
         self._late.clear()
