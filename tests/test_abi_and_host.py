@@ -309,7 +309,7 @@ def test_minibatch_stddev_chunks_expression():
 
 def test_packed_weight_cache_refresh_logic(monkeypatch):
     """host logic of the packed-weight cache (op/modconv.py) with the packing launches replaced by fakes: hits while the version
-    counter stands, ONE multi-tensor refresh of exactly the stale entries after an optimiser step (in place), entries of partial
+    counter stands, ONE multi-tensor refresh of exactly the stale entries after an optimiser step (into fresh buffers), entries of partial
     views dropped, temporaries never cached"""
     import torch
     from transeditor_amd import _lib
@@ -347,7 +347,10 @@ def test_packed_weight_cache_refresh_logic(monkeypatch):
                 p.mul_(2.0)                                       # "optimiser step": version counters move
         assert mc.refresh_packed_weights(cache) == 3 and calls['multi'][-1] == 3      # p5 (1 layout) + p4 (2 layouts); the partial view is dropped
         assert len(cache) == 3
-        assert mc.packed(p5[0], 0, 0.5) is a and torch.equal(a, p5.detach()[0].flatten() * 0.5)      # rewritten in place, a hit again
+        a_old = a.clone()
+        a2 = mc.packed(p5[0], 0, 0.5)                             # a hit again, on a NEW buffer: the old layout (possibly still
+        assert a2 is not a and torch.equal(a, a_old)              # held by an autograd node) is left untouched
+        assert torch.equal(a2, p5.detach()[0].flatten() * 0.5) and mc.packed(p5[0], 0, 0.5) is a2
         assert calls['single'] == 5
         mc.packed(p2[1], 0, 1.0)                                  # the dropped entry is repacked at its next use
         assert calls['single'] == 6 and len(cache) == 4

@@ -28,15 +28,6 @@ def _ksplit(K):
     return 0
 
 
-def _torch_expr(x, weight, bias, alpha, beta, act, residual):
-    y = F.linear(x, weight * alpha, None if bias is None else bias * beta)
-    if act == 'gelu':
-        y = F.gelu(y)
-    elif act == 'lrelu':
-        y = F.leaky_relu(y, 0.2) * math.sqrt(2)
-    return y if residual is None else y + residual
-
-
 def _gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha):
     """alpha * A[I,K] B[K,J] through the strided small-GEMM kernel (split-K form for wide reductions)"""
     if K > MAX_K:
@@ -221,8 +212,11 @@ class _Linear(Function):
             elif _ksplit(R):       # tall reductions (adjust_style: 8192 rows): the split-K form of the same kernel
                 gw, _ = _lib.small_gemm_splitk(N, K, R, _ksplit(R), g, 1, N, x2, x2.stride(0), 1, alpha=alpha)
             else:
-                gw = torch.mm(g.t(), x2 if x2.is_contiguous() else x2.contiguous())
-                gw = gw * alpha if alpha != 1.0 else gw
+                # a row count that does not split evenly: whole 1024-row chunks through the split-K form, the remaining
+                # rows (< 1024) through the single-pass kernel with the first part as its residual (no library GEMM)
+                R1 = (R // MAX_K) * MAX_K
+                gw, _ = _lib.small_gemm_splitk(N, K, R1, R1 // MAX_K, g, 1, N, x2, x2.stride(0), 1, alpha=alpha)
+                gw = _lib.small_gemm(N, K, R - R1, g[R1:], 1, N, x2[R1:], x2.stride(0), 1, residual=gw, alpha=alpha)[0]
         if want_b and gb is None:
             gb = g.sum(0)
             gb = gb * beta if beta != 1.0 else gb

@@ -168,6 +168,24 @@ def packed_weights_cache(cache):
         _STATE.pack_cache = old
 
 
+@contextlib.contextmanager
+def cache_of(ctx):
+    """Backward functions run on the autograd engine's device thread, where the forward thread's `packed_weights_cache()` is
+    not visible (thread-local): a node keeps the cache it was built under (`ctx.pack_cache`, set by `keep_cache`) and re-opens
+    it around its backward, so the layouts packed there - the data-gradient layout of the closed trio in the recorded R1 /
+    path-length backward - are cached like the forward's.  Entries stay validated by version counter and storage address."""
+    c = getattr(ctx, 'pack_cache', None)
+    if c is None or _STATE.pack_cache is not None:
+        yield
+        return
+    with packed_weights_cache(c):
+        yield
+
+
+def keep_cache(ctx):
+    ctx.pack_cache = _STATE.pack_cache
+
+
 def _pack_key(w, pack_kind, wscale):
     return (w.data_ptr(), tuple(w.shape), pack_kind, float(wscale))
 
@@ -182,7 +200,7 @@ def _cacheable(w):
 
 
 def refresh_packed_weights(cache):
-    """Rewrite every stale layout held by `cache` in ONE launch (te_conv_pack_weights_multi_f32).  Called right after an
+    """Re-derive every stale layout held by `cache` in ONE launch (te_conv_pack_weights_multi_f32), into new buffers.  Called right after an
     optimiser step: the layers that use the weights next then hit the cache instead of issuing ~60 small packing launches per
     iteration.  An entry whose parameter is gone / resized is dropped; entries of untouched parameters cost nothing."""
     jobs, fresh = [], []
@@ -196,7 +214,10 @@ def refresh_packed_weights(cache):
         if not (base.data_ptr() == ptr and base.numel() == n and base.is_contiguous() and len(shape) == 4):
             del cache[key]                # a partial view of the parameter (or a resized one): repacked at its next use
             continue
-        jobs.append((wp, base.detach().view(shape), pack_kind, wscale))      # (ModulatedConv2d.weight is [1,Co,Ci,k,k]: same storage)
+        # a FRESH buffer per stale layout: the old one may still be held by an autograd node (ctx.wp_bwd / ctx.packs of a graph
+        # that outlives the optimiser step - retain_graph, a custom step order); rewriting it in place would make that graph
+        # differentiate through the NEW weights without an error
+        jobs.append((torch.empty_like(wp), base.detach().view(shape), pack_kind, wscale))      # (ModulatedConv2d.weight is [1,Co,Ci,k,k]: same storage)
         fresh.append((key, base))
     _lib.conv_pack_multi(jobs)
     for (key, base), job in zip(fresh, jobs):
@@ -361,14 +382,16 @@ class _ConvFwd(Function):
         ctx.save_for_backward(x, w)
         ctx.kind, ctx.wscale = kind, wscale
         ctx.graph = current_graph()
+        keep_cache(ctx)
         return _fwd_raw(x, w, kind, wscale=wscale)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         skip_w = ctx.graph.skip_w or _DEFAULT_GRAPH.skip_w
-        gx = _ConvDgrad.apply(gy, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
-        gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2], ctx.wscale) if (ctx.needs_input_grad[1] and not skip_w) else None
+        with cache_of(ctx):
+            gx = _ConvDgrad.apply(gy, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+            gw = _ConvWgrad.apply(gy, x, ctx.kind, w.shape[2], ctx.wscale) if (ctx.needs_input_grad[1] and not skip_w) else None
         return gx, gw, None, None
 
 
@@ -377,13 +400,15 @@ class _ConvDgrad(Function):
     def forward(ctx, gy, w, kind, wscale):
         ctx.save_for_backward(gy, w)
         ctx.kind, ctx.wscale = kind, wscale
+        keep_cache(ctx)
         return _dgrad_raw(gy, w, kind, wscale=wscale)
 
     @staticmethod
     def backward(ctx, ggx):
         gy, w = ctx.saved_tensors
-        g_gy = _ConvFwd.apply(ggx, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
-        g_w = _ConvWgrad.apply(gy, ggx, ctx.kind, w.shape[2], ctx.wscale) if ctx.needs_input_grad[1] else None
+        with cache_of(ctx):
+            g_gy = _ConvFwd.apply(ggx, w, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+            g_w = _ConvWgrad.apply(gy, ggx, ctx.kind, w.shape[2], ctx.wscale) if ctx.needs_input_grad[1] else None
         return g_gy, g_w, None, None
 
 
@@ -392,13 +417,15 @@ class _ConvWgrad(Function):
     def forward(ctx, gy, x, kind, ksize, wscale):
         ctx.save_for_backward(gy, x)
         ctx.kind, ctx.wscale = kind, wscale
+        keep_cache(ctx)
         return _wgrad_plain(gy, x, kind, ksize, wscale)
 
     @staticmethod
     def backward(ctx, ggw):
         gy, x = ctx.saved_tensors
-        g_gy = _ConvFwd.apply(x, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
-        g_x = _ConvDgrad.apply(gy, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[1] else None
+        with cache_of(ctx):
+            g_gy = _ConvFwd.apply(x, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[0] else None
+            g_x = _ConvDgrad.apply(gy, ggw, ctx.kind, ctx.wscale) if ctx.needs_input_grad[1] else None
         return g_gy, g_x, None, None, None
 
 
@@ -428,6 +455,7 @@ class _ModConvFused(Function):
         # demod_eps != None: osc is the demodulation coefficient of (w, isc), computed here (te_demod_fwd_f32) and
         # differentiated here (its dW / d style are accumulated into the convolution's own in the backward)
         ctx.demod = None
+        keep_cache(ctx)
         if demod_eps is not None:
             w3 = w.reshape(w.shape[0], w.shape[1], -1)
             osc, wsq = _lib.demod_fwd(w3, isc, wscale, demod_eps)
@@ -460,6 +488,11 @@ class _ModConvFused(Function):
 
     @staticmethod
     def backward(ctx, g):
+        with cache_of(ctx):
+            return _ModConvFused._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, w, isc, osc, bias, out = ctx.saved_tensors
         act, kind, wscale = ctx.act, ctx.kind, ctx.wscale
         need = ctx.needs_input_grad

@@ -25,7 +25,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, packed, packed2
+from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, cache_of, keep_cache, packed, packed2
 from .upfirdn2d import _geometry, flipped_taps, upfirdn2d
 
 _SQRT2 = math.sqrt(2.0)
@@ -47,6 +47,7 @@ class _ResBlock(Function):
     def forward(ctx, x, w1, b1, w2, b2, ws, k_main, k_skip, s1, s2, ss, pad_main, pad_skip, gain, w0, b0, s0):
         x = x.contiguous()
         need = ctx.needs_input_grad
+        keep_cache(ctx)
         # Optional from-RGB stem in front (the discriminator's ConvLayer(3, C, 1), :815, + its first ResBlock as one node):
         # x is the image, the block's input is lrelu(conv1x1(x, w0) + b0) * sqrt(2).  The stem's activation gradient then
         # rides in the epilogue of conv1's data gradient (te_conv_res_f32's mask stage) instead of a pass of its own.
@@ -94,6 +95,11 @@ class _ResBlock(Function):
 
     @staticmethod
     def backward(ctx, g):
+        with cache_of(ctx):
+            return _ResBlock._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs, img, w0, b0 = ctx.saved_tensors
         s1, s2, ss, pad_main, pad_skip, gain, pm, ps, s0, need_x = ctx.cfg
         need = ctx.needs_input_grad

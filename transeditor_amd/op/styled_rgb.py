@@ -18,7 +18,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .modconv import _DEFAULT_GRAPH, _composite, _dgrad_raw, _fwd_raw, _wgrad_raw
+from .modconv import _DEFAULT_GRAPH, _composite, _dgrad_raw, _fwd_raw, _wgrad_raw, cache_of, keep_cache
 
 _SQRT2 = 2 ** 0.5
 
@@ -35,6 +35,7 @@ class _ModConvRGB(Function):
     def forward(ctx, x, w, s, bias, wr, sr, br, wscale, eps, wscale_r):
         w3 = w.reshape(w.shape[0], w.shape[1], -1)
         d, wsq = _lib.demod_fwd(w3, s, wscale, eps)
+        keep_cache(ctx)
         if ctx.needs_input_grad[0]:
             a, wp_bwd = _fwd_raw(x, w, '3x3', s, d, bias, 3, wscale, with_bwd_pack=True)
         else:
@@ -48,6 +49,11 @@ class _ModConvRGB(Function):
 
     @staticmethod
     def backward(ctx, ga, grgb):
+        with cache_of(ctx):
+            return _ModConvRGB._backward(ctx, ga, grgb)
+
+    @staticmethod
+    def _backward(ctx, ga, grgb):
         x, w, s, bias, wr, sr, br, d, wsq, a = ctx.saved_tensors
         wscale, eps, wscale_r = ctx.cfg
         need = ctx.needs_input_grad

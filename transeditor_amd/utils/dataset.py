@@ -52,6 +52,14 @@ class MultiResolutionDataset(Dataset):
         self._env = None if self._path is not None else path       # an opened environment (.begin(write=False) -> txn.get(key))
         with self.env.begin(write=False) as txn:
             self.length = int(txn.get('length'.encode('utf-8')).decode('utf-8'))
+        if self._path is not None:
+            # the handle that read `length` must not survive into fork-started workers (a child would hold the inherited
+            # environment AND open a second one on the same path - both unsupported by LMDB): every process, this one
+            # included, opens lazily on its first __getitem__
+            close = getattr(self._env, 'close', None)
+            if close is not None:
+                close()
+            self._env, self._pid = None, None
         self.resolution = resolution
         self.transform = transform
 
