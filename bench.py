@@ -17,7 +17,9 @@ Objects in the JSON beside the driver contract:
   roofline      dominant kernel class = the fp32-MFMA implicit-GEMM convolutions (forward / data-gradient /
                 weight-gradient of every 3x3 kind, G and D): ALGORITHMIC FLOPs of those launches in the timed region /
                 their summed duration, measured live with HIP events on the launch stream; `whole_step_frac` prices
-                the SAME algorithmic FLOPs against the whole wall-clock step.
+                the SAME algorithmic FLOPs against the whole wall-clock step.  `traffic`, `mfma_util_pct`, `mhz` and
+                `counters` come from rocprofv3 --pmc passes spawned by THIS run after the timed region (N = 1;
+                `traffic_source` "live", or "static" = the committed summary if the passes could not run).
   substeps      HIP-event time of each sub-step (D / R1 / G / path) and the cadence-weighted ms per iteration.
   sub_benchmarks  (N = 1) configs[1] generator fwd+bwd at batch 16 and configs[4] FFHQ-1024 generator fwd+bwd at
                 batch 4, each with its own value and roofline.
@@ -59,6 +61,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-sub', action='store_true', help='skip the sub-benchmarks (configs[1], configs[4])')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the live rocprofv3 --pmc passes (roofline.traffic falls back to '
+                                                          'the committed summary, labelled static)')
     return ap.parse_args()
 
 
@@ -128,9 +132,9 @@ class KernelTimer:
         gflop = sum(ks[k]['gflop'] for k in conv_keys)
         tms = sum(ks[k]['total_ms'] for k in conv_keys)
         ach = gflop / tms if tms else 0.0                            # GFLOP / ms == TFLOP/s
-        traffic, note = _pmc_traffic()
+        traffic, note = _pmc_traffic()                               # (static; attach_counters() replaces it with this run's counters)
         return {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': note,
+                'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
                 'kernel': 'conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2, all 3x3 kinds)',
                 'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
                 'algorithmic_gflop_per_step': gflop / steps,
@@ -139,9 +143,91 @@ class KernelTimer:
                 'per_kernel': ks}
 
 
+PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32'),
+              ('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'))
+PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'conv_mfma_kernel<0', 'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
+               'convT2_256to128_at128_b16': 'conv_mfma_kernel<1', 'convS2_128to256_at128_b16': 'conv_mfma_kernel<2',
+               'wgradT2_256x128_at128_b16': 'wgrad_mfma_kernel<1'}
+
+
+def live_counters(timeout_s=150):
+    """Hardware counters collected in THIS run (outside the timed region): three `rocprofv3 --kernel-trace --pmc` passes (MFMA
+    busy cycles, FETCH_SIZE, WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes) over
+    tools/kernel_once.py, which launches every hot kernel at its FFHQ-256 / batch-16 top shape; parsed by
+    tools/pmc_summary.py (FETCH_SIZE doubled: the gfx950 correction).  Returns (per-kernel dict | None, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None, 'rocprofv3 not found'
+    out = tempfile.mkdtemp(prefix='te_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp', REP='2')
+    t0 = time.perf_counter()
+    try:
+        for name, counters in PMC_PASSES:
+            cmd = [prof, '--kernel-trace', '--pmc', *counters.split(), '-d', out, '-o', name, '--output-format', 'csv', '--',
+                   sys.executable, os.path.join(ROOT, 'tools', 'kernel_once.py')]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0 or not os.path.exists(os.path.join(out, name + '_counter_collection.csv')):
+                return None, f'rocprofv3 pass {name} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}'
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import pmc_summary
+        summ = pmc_summary.summarise(out, need_lds=False)
+    except Exception as e:                                          # a missing counter, a timeout: the static file is the fallback
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return summ, f'{len(PMC_PASSES)} rocprofv3 --pmc passes in {time.perf_counter() - t0:.0f} s'
+
+
+def attach_counters(roof, live=True):
+    """fill roofline.traffic / mfma_util_pct / mhz (+ `counters` for the top shapes of every MFMA kernel family) from counters
+    collected in this run; the committed PMC summary only as a labelled fallback"""
+    summ, note = live_counters() if live else (None, 'skipped (--no-pmc)')
+    if summ is None:
+        roof['traffic'], roof['traffic_note'] = _pmc_traffic()
+        roof['traffic_source'] = 'static'
+        roof['live_counters_error'] = note
+        return roof
+    ctr = {}
+    for label, prefix in PMC_KERNELS.items():
+        v = next((val for k, val in summ.items() if k.startswith(prefix)), None)
+        if v is None:
+            continue
+        hbm = (v['hbm_read_mb'] + v['hbm_write_mb']) * 1e6
+        ctr[label] = {'kernel': next(k for k in summ if k.startswith(prefix)), 'us_under_counters': v['us'], 'mhz': v['mhz'],
+                      'mfma_util_pct': v['mfma_util_pct'], 'tflops_under_counters': v['tflops'],
+                      'hbm_read_bytes': v['hbm_read_mb'] * 1e6, 'hbm_write_bytes': v['hbm_write_mb'] * 1e6,
+                      'algorithmic_bytes': v['algorithmic_mb'] * 1e6 if v['algorithmic_mb'] else None,
+                      'traffic_over_algorithmic': hbm / (v['algorithmic_mb'] * 1e6) if v['algorithmic_mb'] else None,
+                      'hbm_GBps': v['gbs']}
+    hbm_tail = {}
+    for k, v in summ.items():
+        if any(t in k for t in ('blur44', 'fir_tile', 'bias_act', 'rgb_', 'wgrad_reduce')) and v['algorithmic_mb']:
+            hbm_tail[k[:60]] = {'us': v['us'], 'algorithmic_TBps': v['algorithmic_mb'] / v['us'],        # MB / us == TB/s
+                                'frac_of_hbm_peak': v['algorithmic_mb'] / v['us'] / (PEAK_HBM_GBS / 1e3),
+                                'traffic_over_algorithmic': (v['hbm_read_mb'] + v['hbm_write_mb']) / v['algorithmic_mb']}
+    top = ctr.get('conv3x3_fwd_128to128_at256_b16')
+    if top is None:
+        roof['traffic'], roof['traffic_note'] = _pmc_traffic()
+        roof['traffic_source'] = 'static'
+        roof['live_counters_error'] = 'top-shape kernel missing from the counter CSVs'
+        return roof
+    roof['traffic'] = top['hbm_read_bytes'] + top['hbm_write_bytes']
+    roof['traffic_source'] = 'live'
+    roof['mfma_util_pct'], roof['mhz'] = top['mfma_util_pct'], top['mhz']
+    roof['traffic_note'] = (f'LIVE: {note} over tools/kernel_once.py inside this bench run (outside the timed region); per launch of '
+                            f'the dominant kernel at its top shape (3x3 128->128 @256x256, batch 16): FETCH_SIZE x2 (gfx950 '
+                            f'correction) + WRITE_SIZE vs {top["algorithmic_bytes"] / 1e6:.0f} MB algorithmic')
+    roof['counters'] = ctr
+    roof['hbm_bound_kernels'] = hbm_tail
+    return roof
+
+
 def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_round.sh +
-    tools/pmc_summary.py; counters cannot be collected from inside this process).  Latest round's summary wins."""
+    """FALLBACK (labelled static): HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (tools/pmc_round.sh + tools/pmc_summary.py), used only when live_counters() cannot run.  Latest round's summary wins."""
     try:
         prof = os.path.join(ROOT, 'profiles')
         cands = sorted(f for f in os.listdir(prof) if f.endswith('_pmc_summary.json'))
@@ -495,6 +581,83 @@ def isolated_allreduce(sync, dev, reps=5):
     return out
 
 
+class Watchdog:
+    """A communication step that hangs (rendezvous, the first RCCL collective: ring set-up over xGMI, IPC handles) must not eat
+    the driver's whole time limit without a trace: if `arm(what, seconds)` is not followed by `disarm()` in time, every rank
+    says so on stderr, rank 0 prints ONE JSON line with `comm.error` (so the failure can be judged from the record), and the
+    process exits with code 3.  The timer runs on its own thread (blocking HIP / RCCL calls release the GIL)."""
+
+    def __init__(self, base, rank, info):
+        self.base, self.rank, self.info, self.timer = base, rank, info, None
+
+    def arm(self, what, seconds):
+        import threading
+        self.disarm()
+        self.timer = threading.Timer(seconds, self._fire, args=(what, seconds))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self, what, seconds):
+        msg = f'{what} did not complete within {seconds:.0f} s on rank {self.rank}'
+        print(f'bench.py watchdog: {msg}', file=sys.stderr, flush=True)
+        if self.rank == 0:
+            print(json.dumps(dict(self.base, value=None, ms_per_step=None, comm=dict(self.info, error=msg))), flush=True)
+        os._exit(3)
+
+
+def comm_preflight(args, backend, world, rank, local_rank, dev):
+    """init_process_group + ONE tiny all-reduce under a watchdog, before any model is built; returns what identifies the
+    communication set-up (library version, device of every rank) for the `comm` object."""
+    import torch.distributed as dist
+    info = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world_size': world,
+            'env': {k: os.environ.get(k) for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'NCCL_DEBUG', 'NCCL_SOCKET_IFNAME', 'MASTER_ADDR',
+                                                    'MASTER_PORT', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES')}}
+    try:
+        info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:
+        info['rccl_version'] = f'unavailable ({type(e).__name__})'
+    base = {'metric': METRIC, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+    dog = Watchdog(base, rank, info)
+    limit = float(os.environ.get('TE_BENCH_COMM_TIMEOUT', '60'))
+    try:
+        dog.arm('init_process_group (env:// rendezvous)', 3 * limit)
+        dist.init_process_group(backend, init_method='env://')
+        dog.arm(f'the first all-reduce over {info["backend"]}', limit)
+        t0 = time.perf_counter()
+        probe = torch.full((1024,), float(rank + 1), device=dev)
+        dist.all_reduce(probe)
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+        info['preflight_allreduce_s'] = time.perf_counter() - t0
+        want = world * (world + 1) / 2
+        if abs(float(probe[0].item()) - want) > 1e-3:
+            raise RuntimeError(f'preflight all-reduce returned {float(probe[0].item())}, expected {want}')
+        dog.arm('the device-id exchange', limit)
+        props = torch.cuda.get_device_properties(dev) if dev.type == 'cuda' else None
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': torch.cuda.current_device() if props else 'cpu',
+                'name': props.name if props else 'cpu', 'pci_bus_id': getattr(props, 'pci_bus_id', None), 'host': os.uname().nodename}
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        info['ranks'] = allv
+        # from here on only a coarse limit for the whole run (a rank that dies or diverges mid-run leaves the others waiting
+        # in a collective): the record then says where instead of the driver's limit killing a silent job
+        dog.arm('the benchmark run after a successful preflight', float(os.environ.get('TE_BENCH_RUN_TIMEOUT', '1500')))
+    except Exception as e:                                          # an error (not a hang): same record, then stop
+        dog.disarm()
+        msg = f'{type(e).__name__}: {e}'
+        print(f'bench.py: communication preflight failed on rank {rank}: {msg}', file=sys.stderr, flush=True)
+        if rank == 0:
+            print(json.dumps(dict(base, value=None, ms_per_step=None, comm=dict(info, error=msg[:2000]))), flush=True)
+        os._exit(3)
+    return info, dog
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -509,11 +672,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     backend = None
+    comm_info = watchdog = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = 'gloo' if share else 'nccl'                       # "nccl" == RCCL on ROCm
-        dist.init_process_group(backend, init_method='env://')
+        comm_info, watchdog = comm_preflight(args, backend, world, rank, local_rank, dev)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     size = args.size
@@ -539,10 +703,14 @@ def main():
                                'per_gpu_images_per_sec': B * args.steps / elapsed})
             if roof:
                 out['roofline'] = roof
+                if world == 1:
+                    torch.cuda.synchronize()
+                    attach_counters(roof, live=not args.no_pmc)
             if world == 1 and not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline_generator(size)
             print(json.dumps(out), flush=True)
         if world > 1:
+            watchdog.disarm()
             torch.distributed.destroy_process_group()
         return
 
@@ -618,7 +786,7 @@ def main():
             ts.iteration(1 + i, reals[i % 4])
         fence(world)
         withcomm = max_over_ranks(time.perf_counter() - t0, world, dev) / k2
-        out['comm'] = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world_size': dist.get_world_size(),
+        out['comm'] = {**comm_info, 'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world_size': dist.get_world_size(),
                        'bytes_allreduced_per_iteration_per_gpu': per_iter_bytes,
                        'g_bytes_per_exchange': ts.g_sync.bytes_per_call(), 'd_bytes_per_exchange': ts.d_sync.bytes_per_call(),
                        'buckets_g': len(ts.g_sync.buckets), 'buckets_d': len(ts.d_sync.buckets),
@@ -644,18 +812,22 @@ def main():
                 'config': 'BASELINE configs[4]: FFHQ-1024 generator fwd+bwd, batch 4, 2 warm-up + 6 timed steps',
                 'value': 4 * 6 / el, 'unit': 'images/sec', 'ms_per_step': 1e3 * el / 6, 'roofline': _slim(roof)}
         out['sub_benchmarks'] = sub
+    if world == 1 and rank == 0 and 'roofline' in out:
+        torch.cuda.synchronize()
+        attach_counters(out['roofline'], live=not args.no_pmc)       # counters of THIS run, outside the timed region
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_train(size)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        watchdog.disarm()
         torch.distributed.destroy_process_group()
 
 
 def _slim(roof):
     if roof is None:
         return None
-    return {k: v for k, v in roof.items() if k not in ('traffic_note', 'kernel')}
+    return {k: v for k, v in roof.items() if k not in ('traffic_note', 'kernel', 'traffic', 'traffic_source')}
 
 
 if __name__ == '__main__':

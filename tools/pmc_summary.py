@@ -48,14 +48,17 @@ def load(path):
     return agg, dur
 
 
-def main(src='gpurun_out/pmc', tag='profiles/r03'):
+def summarise(src, need_lds=True):
+    """per-kernel dict from the counter CSVs under `src` (mfma / fetch / write passes; the LDS pass is optional)"""
+    import os
     mf, dur = load(f'{src}/mfma_counter_collection.csv')
     fe, _ = load(f'{src}/fetch_counter_collection.csv')
     wr, _ = load(f'{src}/write_counter_collection.csv')
-    ld, _ = load(f'{src}/lds_counter_collection.csv')
+    have_lds = os.path.exists(f'{src}/lds_counter_collection.csv')
+    if need_lds and not have_lds:
+        raise FileNotFoundError(f'{src}/lds_counter_collection.csv')
+    ld = load(f'{src}/lds_counter_collection.csv')[0] if have_lds else {}
     out = {}
-    lines = [f'{"kernel":42s} {"us":>8s} {"MHz":>6s} {"MFMA%":>6s} {"TF/s":>6s} {"HBM rd MB":>10s} {"wr MB":>8s} {"alg MB":>8s} '
-             f'{"GB/s":>7s} {"LDSconf%":>8s}']
     for k in mf:
         last = lambda d, c: (d[k][c][-1] if k in d and c in d[k] else float('nan'))
         us = sorted(dur[k])[len(dur[k]) // 2]
@@ -67,11 +70,22 @@ def main(src='gpurun_out/pmc', tag='profiles/r03'):
         wrm = last(wr, 'WRITE_SIZE') * 1024 / 1e6
         alg = next((v for p, v in ALG.items() if k.startswith(p)), None)
         tf = alg['flops'] / us / 1e6 if alg and alg['flops'] else 0.0
-        conf = 100.0 * last(ld, 'SQ_LDS_BANK_CONFLICT') / max(last(ld, 'SQ_LDS_IDX_ACTIVE'), 1.0)
+        conf = (100.0 * last(ld, 'SQ_LDS_BANK_CONFLICT') / max(last(ld, 'SQ_LDS_IDX_ACTIVE'), 1.0)) if have_lds else None
         out[k] = dict(us=us, mhz=mhz, mfma_util_pct=util, tflops=tf, hbm_read_mb=rd, hbm_write_mb=wrm,
                       algorithmic_mb=(alg['bytes'] / 1e6 if alg else None), gbs=(rd + wrm) / us * 1e3, lds_conflict_pct=conf)
-        lines.append(f'{k[:42]:42s} {us:8.1f} {mhz:6.0f} {util:6.1f} {tf:6.1f} {rd:10.1f} {wrm:8.1f} '
-                     f'{(alg["bytes"] / 1e6 if alg else float("nan")):8.1f} {(rd + wrm) / us * 1e3:7.0f} {conf:8.1f}')
+    return out
+
+
+def main(src='gpurun_out/pmc', tag='profiles/r04'):
+    out = summarise(src, need_lds=False)
+    lines = [f'{"kernel":42s} {"us":>8s} {"MHz":>6s} {"MFMA%":>6s} {"TF/s":>6s} {"HBM rd MB":>10s} {"wr MB":>8s} {"alg MB":>8s} '
+             f'{"GB/s":>7s} {"LDSconf%":>8s}']
+    for k, v in out.items():
+        alg = v['algorithmic_mb']
+        conf = v['lds_conflict_pct']
+        lines.append(f'{k[:42]:42s} {v["us"]:8.1f} {v["mhz"]:6.0f} {v["mfma_util_pct"]:6.1f} {v["tflops"]:6.1f} {v["hbm_read_mb"]:10.1f} '
+                     f'{v["hbm_write_mb"]:8.1f} {(alg if alg is not None else float("nan")):8.1f} {v["gbs"]:7.0f} '
+                     f'{(conf if conf is not None else float("nan")):8.1f}')
     open(tag + '_pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
     json.dump(out, open(tag + '_pmc_summary.json', 'w'), indent=1)
     print('\n'.join(lines))
