@@ -21,16 +21,15 @@
  * (plain kernels, same semantics).  Every other entry point is fp32 only: the Python wrappers raise on any other dtype
  * instead of silently casting (tests/test_gpu_generator.py::test_non_contiguous_and_wrong_dtype_inputs).
  *
- * Run-to-run reproducibility.  Forward results are bit-reproducible.  Fixed-order (bit-reproducible) reductions: the split-K
- * convolution WITH a workspace (te_conv_ws_f32 / te_conv_res_f32), te_small_gemm_splitk_f32, the per-(sample, chunk)
- * correlation slabs of te_wgrad_f32 / te_rgb_wgrad_f32, the per-tile bias-gradient partials of te_blur_actgrad_f32 /
- * te_blur_gradact_f32, te_chan_dot_f32, the layer / pixel norm and minibatch-stddev kernels.  NOT fixed-order (hardware fp32
- * atomic adds, library built with -munsafe-fp-atomics; same values up to summation order, i.e. relative differences of
- * ~1e-7 per element between runs): te_conv_f32 on a split problem WITHOUT a workspace (hipMemsetAsync + atomics),
- * te_bias_act_bwd_f32's bias gradient (one atomic per block and channel), te_wgrad_reduce_f32's style / demodulation
- * gradients (one atomic per tile and (sample, channel)) and its weight gradient when the slab chunks of narrow layers are
- * split over blockIdx.z, te_demod_bwd_f32 in accumulate mode.  Training gradients are therefore reproducible to ~1e-6
- * relative, not bit-wise; tests compare those paths with tolerances, never for bit equality.
+ * Run-to-run reproducibility.  EVERY result of this library is bit-reproducible from run to run (same inputs, same
+ * library, same device): there is no atomic add on any path.  Reductions that span thread blocks go through per-block
+ * partials in a caller-owned workspace and a fixed-order second pass: the split-K convolution (te_conv_ws_f32 /
+ * te_conv_res_f32; te_conv_f32, which has no workspace argument, does not split), te_small_gemm_splitk_f32, the
+ * per-(sample, chunk) correlation slabs of te_wgrad_f32 / te_rgb_wgrad_f32, the bias gradient of te_bias_act_bwd_f32 /
+ * te_bias_act_bwd_rgb_f32 (workspace: te_bias_act_bwd_ws_floats), the per-tile bias-gradient partials of te_blur_actgrad_f32 /
+ * te_blur_gradact_f32, all three outputs of te_wgrad_reduce_f32 (workspace: te_wgrad_reduce_ws_floats), te_chan_dot_f32, the
+ * layer / pixel norm and minibatch-stddev kernels.  The library is built WITHOUT -munsafe-fp-atomics.
+ * (tests/test_gpu_determinism.py runs the 256-px generator and discriminator backward twice and compares bit for bit.)
  */
 #ifndef TE_HIP_H
 #define TE_HIP_H
@@ -41,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TE_ABI_VERSION 2
+#define TE_ABI_VERSION 3
 
 #define TE_ERR_NULL -1      /* required pointer is NULL              */
 #define TE_ERR_SHAPE -2     /* non-positive / inconsistent dimension */
@@ -78,18 +77,20 @@ int te_bias_act_f64(double* out, const double* x, const double* b, const double*
 /* Backward of the fused lrelu in ONE pass — replaces FusedLeakyReLUFunctionBackward.forward,
  * utils/op/fused_act.py:18-38 (kernel call + grad_input.sum(dim)):
  *   gi[n,c,i] = g[n,c,i] * (ref[n,c,i] > 0 ? 1 : alpha) * scale ;  gb[c] = sum_{n,i} gi[n,c,i]
- * Layout [outer][C][inner].  gb (may be NULL) must be zero-filled by the caller (partial sums
- * are combined with atomics).  */
-int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const float* ref, float alpha, float scale,
+ * Layout [outer][C][inner].  gb (may be NULL) is WRITTEN (no zero fill needed).  The streaming form combines per-block partial
+ * sums through the caller's workspace `ws` of te_bias_act_bwd_ws_floats(outer, C, inner) floats (0: none needed, ws may be
+ * NULL) and a fixed-order second pass: bit-reproducible, no atomics.  */
+int64_t te_bias_act_bwd_ws_floats(int64_t outer, int64_t C, int64_t inner);
+int te_bias_act_bwd_f32(float* gi, float* gb, float* ws, const float* g, const float* ref, float alpha, float scale,
                         int64_t outer, int64_t C, int64_t inner, te_stream_t stream);
 /* te_bias_act_bwd_f32 with the data gradient of a ToRGB layer (1x1 modulated convolution to 3 channels, ToRGB.forward,
  * model_spatial_query.py:416-425) folded in — te_rgb_dgrad_f32, the gradient-accumulation add and the activation gradient
  * in one pass over the activation-sized tensors:
- *     gi = ( g + wscale * srgb[n,c] * sum_o wrgb[o,c] * grgb[n,o,:] ) * (ref > 0 ? 1 : alpha) * scale ,   gb[c] += sum gi
+ *     gi = ( g + wscale * srgb[n,c] * sum_o wrgb[o,c] * grgb[n,o,:] ) * (ref > 0 ? 1 : alpha) * scale ,   gb[c] = sum gi
  * g [outer,C,inner] may be NULL (nothing but ToRGB consumes the activation), grgb [outer,3,inner], wrgb [3,C], srgb [outer,C] or
- * NULL; gb zero-filled by the caller or NULL.  te_bias_act_bwd_rgb_supported: inner % 4 == 0 and inner >= 1024. */
+ * NULL; gb written or NULL (needs ws, same size as above).  te_bias_act_bwd_rgb_supported: inner % 4 == 0 and inner >= 1024. */
 int te_bias_act_bwd_rgb_supported(int64_t outer, int64_t C, int64_t inner);
-int te_bias_act_bwd_rgb_f32(float* gi, float* gb, const float* g, const float* ref, const float* grgb, const float* wrgb,
+int te_bias_act_bwd_rgb_f32(float* gi, float* gb, float* ws, const float* g, const float* ref, const float* grgb, const float* wrgb,
                             const float* srgb, float wscale, float alpha, float scale, int64_t outer, int64_t C, int64_t inner,
                             te_stream_t stream);
 
@@ -162,7 +163,7 @@ int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, 
  * te_conv_splitk_count returns the number of splits S of a problem (1 = no split).  te_conv_ws_f32 is te_conv_f32 with
  * a caller-owned workspace ws[S][B][M][Ho][Wo] (ignored / may be NULL when S == 1): each split writes its own slab and a
  * second kernel sums them in a fixed order (DETERMINISTIC, no atomics, no memset).  te_conv_f32 itself (no workspace)
- * combines the splits with atomic adds into a zero-filled `out`: same values up to summation order. */
+ * never splits (same result up to summation order, slower on 4x4 ... 16x16 images). */
 int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
@@ -198,8 +199,11 @@ int te_wgrad_group_f32(float* slabs, const float* g, const float* x, int kind, i
  *   gw[co,ci,t]  = wscale * sum_{b,s} osc[b,co]*isc[b,ci] * slab          (gw   may be NULL)
  *   gisc[b,ci]   = sum_{co,t,s} wscale*w[co,ci,t] * osc[b,co] * slab      (gisc may be NULL)
  *   gosc[b,co]   = sum_{ci,t,s} wscale*w[co,ci,t] * isc[b,ci] * slab      (gosc may be NULL)
- * isc / osc NULL = all ones.  gisc/gosc must be zero-filled by the caller. */
-int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const float* slabs, const float* w,
+ * isc / osc NULL = all ones.  All three outputs are WRITTEN.  Shares of different thread blocks (channel tiles, slab chunks,
+ * samples) meet through the caller's workspace `ws` of te_wgrad_reduce_ws_floats(...) floats and a fixed-order second pass:
+ * bit-reproducible, no atomics, no memset. */
+int64_t te_wgrad_reduce_ws_floats(int B, int S, int Co, int Ci, int taps, int want_w, int want_isc, int want_osc);
+int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, float* ws, const float* slabs, const float* w,
                         float wscale, const float* isc, const float* osc, int B, int S, int Co, int Ci,
                         int taps, te_stream_t stream);
 

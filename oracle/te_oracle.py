@@ -40,12 +40,21 @@ def channel_table(channel_multiplier=2):
 
 # --------------------------------------------------------------------------- ops
 
+# Test hook: a callable that receives the output of EVERY leaky-ReLU the oracle evaluates, in execution order
+# (tests/pinning.py records the slope signs the fp64 oracle took and pins the HIP path's activation gradients to them, so that
+# gradient parity can be asserted without the slope flips of pre-activations that sit within round-off of the kink).
+ACT_TAP = None
+
+
 def fused_leaky_relu(x, bias, negative_slope=0.2, scale=SQRT2):
     """utils/op/fused_act.py:50-56 + fused_bias_act_kernel.cu:26-47 (act=3, grad=0):
     y = lrelu(x + b[channel]) * scale, channel = dim 1."""
     if bias is not None:
         x = x + bias.reshape(1, -1, *([1] * (x.ndim - 2)))
-    return torch.where(x > 0, x, x * negative_slope) * scale
+    y = torch.where(x > 0, x, x * negative_slope) * scale
+    if ACT_TAP is not None:
+        ACT_TAP(y)
+    return y
 
 
 def fir_kernel(taps, gain=1.0):
@@ -257,7 +266,7 @@ def conv_layer(P, pre, x, k, downsample=False, bias=True, activate=True):
         if bias:
             y = fused_leaky_relu(y, P[f'{pre}.{ci + 1}.bias'])
         else:
-            y = F.leaky_relu(y, 0.2) * SQRT2                                 # :229-238
+            y = fused_leaky_relu(y, None)                                    # ScaledLeakyReLU, :229-238
     return y
 
 

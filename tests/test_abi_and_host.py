@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(libpath):
     assert not missing, missing
     lib.te_arch.restype = ctypes.c_char_p
     assert lib.te_arch() == b'gfx950'
-    assert lib.te_version() == 2
+    assert lib.te_version() == 3
 
 
 def test_binding_table_matches_header(libpath):
@@ -35,7 +35,7 @@ def test_binding_table_matches_header(libpath):
     header = open(os.path.join(ROOT, 'include', 'te_hip.h')).read()
     declared = set(re.findall(r'\b(te_[a-z0-9_]+)\s*\(', header))
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().te_version() == 2
+    assert _lib.lib().te_version() == 3
 
 
 def test_argument_validation_returns_error_codes(libpath):

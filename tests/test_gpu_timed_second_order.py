@@ -27,6 +27,7 @@ from transeditor_amd import synth
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 TOL = 1e-3
+PIN_SO_TOL = 5e-4      # second-order gradient parity with the leaky-ReLU slopes pinned (tests/pinning.py): element-wise L2
 
 
 @pytest.fixture(autouse=True)
@@ -62,7 +63,10 @@ def test_path_length_step_256_batch2_vs_oracle():
         P[k] = v.clone().requires_grad_(True) if _trainable(k, v) else v
         if _trainable(k, v):
             names.append(k)
-    img_r, lat_r, _ = O.generator_forward(P, z, p, size)
+    from pinning import pinned, record_oracle
+    with record_oracle() as bank:
+        img_r, lat_r, _ = O.generator_forward(P, z, p, size)
+    bank.extend_stacked(16, dim=1)
     pen_r, mean_r, len_r = O.g_path_regularize(img_r, lat_r, 0.0, noise / math.sqrt(size * size))
     gr = torch.autograd.grad(2.0 * 4 * pen_r + 0 * img_r[0, 0, 0, 0], [P[k] for k in names], allow_unused=True)
     ref = dict(zip(names, gr))
@@ -92,6 +96,26 @@ def test_path_length_step_256_batch2_vs_oracle():
     assert not bad, bad[:8]
     # the penalty does not reach ToRGB of the last layer's bias-free parts differently from the reference: same unused set
     assert all(n.endswith('noise.weight') for n in unused), unused
+    # PINNED variant (tests/pinning.py): slopes taken from the oracle's forward, so the double backward differentiates the same
+    # piecewise-linear function on both sides: path lengths 1e-4, every parameter gradient element-wise (L2) at 5e-4
+    with pinned(bank) as st:
+        with second_order():
+            img, lat, _ = G(z.to(DEV), p.to(DEV), return_latents=True)
+        pen, mean, lengths = g_path_regularize(img, lat, 0.0, noise.to(DEV))
+        gs = torch.autograd.grad(2.0 * 4 * pen + 0 * img[0, 0, 0, 0], list(G.parameters()), allow_unused=True)
+    assert not st['unmatched'], st['unmatched']
+    assert rel_err(lengths, len_r) < 1e-4, (lengths, len_r)
+    errs = {}
+    for (n, _), got in zip(G.named_parameters(), gs):
+        want = ref[n]
+        if got is None or n.endswith('k_transform.bias') or float(want.double().norm()) <= 1e-7 * top:
+            continue
+        errs[n] = rel_l2(got, want)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'path step 256 px pinned: {st["flips"]} of {st["elements"]} slopes pinned; lengths {rel_err(lengths, len_r):.2e}; '
+          f'worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+    bad = [(k, v) for k, v in errs.items() if v > PIN_SO_TOL]
+    assert not bad, bad[:8]
 
 
 def test_path_length_step_256_batch8_is_sum_of_batch2_steps():
@@ -115,7 +139,9 @@ def test_path_length_step_256_batch8_is_sum_of_batch2_steps():
         loss = (lengths - c).pow(2).sum()
         return lengths.detach(), torch.autograd.grad(loss, params, allow_unused=True)
 
-    len8, g8 = run(slice(0, B))
+    from pinning import capture, pinned
+    with capture() as bank8:
+        len8, g8 = run(slice(0, B))
     acc, lens = None, []
     for k in range(4):
         l2, g2 = run(slice(2 * k, 2 * k + 2))
@@ -134,6 +160,26 @@ def test_path_length_step_256_batch8_is_sum_of_batch2_steps():
         # test_gpu_timed_shapes.py): the 5e-3 bar of the second-order tests on the norm, 1e-2 element-wise (L2)
         if e > 5 * TOL or rel_l2(a, b) > 10 * TOL:
             bad.append((n, e, rel_l2(a, b)))
+    assert not bad, bad[:8]
+    # PINNED variant: the batch-2 steps take the slopes of the batch-8 step
+    acc, lens, flips = None, [], 0
+    for k in range(4):
+        with pinned(bank8.batch_slice(slice(2 * k, 2 * k + 2), B)) as st:
+            l2, g2 = run(slice(2 * k, 2 * k + 2))
+        assert not st['unmatched'], st['unmatched']
+        flips += st['flips']
+        lens.append(l2)
+        acc = [None if t is None else t.double() for t in g2] if acc is None else \
+              [None if a is None else a + t.double() for a, t in zip(acc, g2)]
+    assert rel_err(len8, torch.cat(lens)) < 1e-4
+    errs = {}
+    for n, a, b in zip(names, g8, acc):
+        if a is None or n.endswith('k_transform.bias') or float(b.norm()) < 1e-7 * top:
+            continue
+        errs[n] = rel_l2(a, b)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'batch-8 path linearity pinned: {flips} slopes pinned; worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+    bad = [(k, v) for k, v in errs.items() if v > PIN_SO_TOL]
     assert not bad, bad[:8]
 
 

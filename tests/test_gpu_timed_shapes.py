@@ -45,8 +45,18 @@ def _build(size, seed):
     return g.to(DEV), sd
 
 
-def _oracle_grads(sd, z, p, w, size, dtype=torch.float32, params=True):
-    """CPU oracle forward + backward: image, dz, dp and {parameter name: gradient}"""
+PIN_TOL = 1e-4          # first-order gradient parity with the leaky-ReLU slopes pinned (tests/pinning.py): element-wise L2
+
+
+def _oracle_grads(sd, z, p, w, size, dtype=torch.float32, params=True, bank=None):
+    """CPU oracle forward + backward: image, dz, dp and {parameter name: gradient}; `bank` (a list) receives the SignBank of
+    the slope signs the oracle took"""
+    if bank is not None:
+        from pinning import record_oracle
+        with record_oracle() as b:
+            out = _oracle_grads(sd, z, p, w, size, dtype, params)
+        bank.append(b.extend_stacked(16, dim=1))
+        return out
     P, names = {}, []
     for k, v in sd.items():
         train = v.is_floating_point() and 'noises' not in k and 'kernel' not in k and not k.startswith('token')
@@ -75,7 +85,8 @@ def _check_against_oracle(G, sd, z, p, w, size, n_unused):
     # leaky-ReLU kink flips its slope; 14 layers deep that moves single entries by parts in 1e3 — measured in round 1,
     # profiles/r01_latent_gradient_conditioning.txt).  So they are judged against the fp64 oracle: the HIP path must be as
     # close to the truth as the fp32 CPU oracle (= the reference's arithmetic) is, up to a factor 3, or within 1e-3.
-    _, gz64, gp64, g64 = _oracle_grads(sd, z, p, w, size, torch.float64, params=True)
+    bank = []
+    _, gz64, gp64, g64 = _oracle_grads(sd, z, p, w, size, torch.float64, params=True, bank=bank)
     for name, got, r32, r64 in (('dz', grads[0], ref_gz, gz64), ('dp', grads[1], ref_gp, gp64)):
         e_hip, e_cpu = rel_err(got, r64), rel_err(r32, r64)
         print(f'{size}px {name}: hip vs fp64 {e_hip:.2e}, cpu-fp32 vs fp64 {e_cpu:.2e}, hip vs cpu-fp32 L2 {rel_l2(got, r32):.2e}')
@@ -105,6 +116,31 @@ def _check_against_oracle(G, sd, z, p, w, size, n_unused):
                 bad.append((n, e_norm, e_l2, e_hip64, e_cpu64))
     assert not bad, bad[:8]
     assert len(unused) == n_unused and all(n.endswith('noise.weight') for n in unused)
+    _check_pinned(G, z, p, w, size, bank[0], gz64, gp64, g64)
+
+
+def _check_pinned(G, z, p, w, size, bank, gz64, gp64, g64):
+    """The same backward with every leaky-ReLU slope pinned to the sign the fp64 oracle took (tests/pinning.py): no flips
+    are left, so dz, dp and EVERY parameter gradient are compared element-wise (relative L2) at 1e-4 - a 0.3 % error in one
+    bias- or style-gradient reduction, which the un-pinned bars above would let through, fails here."""
+    from pinning import pinned
+    zd, pd = z.to(DEV).requires_grad_(True), p.to(DEV).requires_grad_(True)
+    names = [n for n, _ in G.named_parameters()]
+    with pinned(bank) as st:
+        img = G(zd, pd)[0]
+        grads = torch.autograd.grad((img * w.to(DEV)).sum() / img.numel(), [zd, pd] + list(G.parameters()), allow_unused=True)
+    assert not st['unmatched'], st['unmatched']
+    top = max(float(v.double().norm()) for v in g64.values() if v is not None)
+    errs = {'dz': rel_l2(grads[0], gz64), 'dp': rel_l2(grads[1], gp64)}
+    for n, got in zip(names, grads[2:]):
+        if got is None or n.endswith('k_transform.bias') or float(g64[n].double().norm()) <= 1e-9 * top:
+            continue
+        errs[n] = rel_l2(got, g64[n])
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'{size}px pinned: {st["activations"]} activations, {st["flips"]} of {st["elements"]} slopes pinned; '
+          f'dz {errs["dz"]:.2e} dp {errs["dp"]:.2e}; worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+    bad = [(k, v) for k, v in errs.items() if v > PIN_TOL]
+    assert not bad, bad[:8]
 
 
 def test_generator256_fwd_bwd_batch2_vs_oracle():
@@ -131,7 +167,9 @@ def test_generator256_batch16_backward_is_sum_of_batch2_backwards():
         img = G(zd, pd)[0]
         return torch.autograd.grad((img * w[sl]).sum() / (3 * 256 * 256), [zd, pd] + params, allow_unused=True)
 
-    g16 = grads(slice(0, 16))
+    from pinning import capture, pinned
+    with capture() as bank16:                        # the slope signs the batch-16 pass took (for the pinned variant below)
+        g16 = grads(slice(0, 16))
     acc, gz, gp = None, [], []
     for k in range(8):
         g2 = grads(slice(2 * k, 2 * k + 2))
@@ -156,6 +194,28 @@ def test_generator256_batch16_backward_is_sum_of_batch2_backwards():
         e = rel_l2(a, b)
         if e > (2 * TOL if n.endswith('conv.weight') else 4 * TOL):
             bad.append((n, e))
+    assert not bad, bad[:8]
+    # PINNED variant: the eight batch-2 passes take the slopes of the batch-16 pass, so what is left is the arithmetic of the
+    # different tile / split choices alone: every gradient element-wise (L2) at 1e-4
+    acc, gz, gp, flips = None, [], [], 0
+    for k in range(8):
+        with pinned(bank16.batch_slice(slice(2 * k, 2 * k + 2), 16)) as st:
+            g2 = grads(slice(2 * k, 2 * k + 2))
+        assert not st['unmatched'], st['unmatched']
+        flips += st['flips']
+        gz.append(g2[0])
+        gp.append(g2[1])
+        acc = [None if t is None else t.double() for t in g2[2:]] if acc is None else \
+              [None if a is None else a + t.double() for a, t in zip(acc, g2[2:])]
+    errs = {'dz': rel_l2(g16[0], torch.cat(gz)), 'dp': rel_l2(g16[1], torch.cat(gp))}
+    for n, a, b in zip(names, g16[2:], acc):
+        if a is None or n.endswith('k_transform.bias') or float(b.norm()) < 1e-9 * top:
+            continue
+        errs[n] = rel_l2(a, b)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'batch-16 linearity pinned: {flips} slopes pinned; dz {errs["dz"]:.2e} dp {errs["dp"]:.2e}; '
+          f'worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+    bad = [(k, v) for k, v in errs.items() if v > PIN_TOL]
     assert not bad, bad[:8]
 
 

@@ -1,0 +1,183 @@
+"""`TrainStep.iteration` AT THE METRIC'S CONFIGURATION - 256 px, batch 16, joint discriminator pass of 32, grouped weight
+gradient, from-RGB stem inside the first ResBlock node, FusedAdam, EMA (BASELINE configs[2]; train_spatial_query.py:166-294) -
+against the CPU oracle.
+
+The oracle cannot afford batch 16 at 256 px inside a test tier, so the batch is built so that batch 16 EQUALS batch 4:
+sample b of the 16 is sample b // 4 of a batch of four.  The minibatch-stddev sets of a batch of 16 are {m, m+4, m+8, m+12}
+(model_spatial_query.py:844-852), i.e. every set holds the four distinct samples once - exactly the statistic of the batch
+of four; the losses are batch means, so every loss and every parameter gradient of the batch-16 sub-step equals the
+batch-4 one.  (All 16 samples still go through the production tilings; sample independence at batch 16 with distinct
+samples is covered by the linearity tests of test_gpu_timed_shapes.py.)  Learning rate 0 keeps the weights at their
+initial values through the four optimiser steps, so the oracle needs no optimiser.
+
+Compared, with the leaky-ReLU slopes pinned to the ones the oracle took (tests/pinning.py): the discriminator step's losses,
+scores and EVERY discriminator parameter gradient, the generator step's loss and EVERY generator parameter gradient through
+the frozen discriminator - element-wise (relative L2) at 1e-4.  R1 and the path-length step run inside the iteration (their
+own 256-px tests: test_gpu_timed_second_order.py) and must leave finite losses and gradients.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import te_oracle as O
+from transeditor_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+SIZE, B, B4 = 256, 16, 4
+PIN_TOL = 1e-4
+
+
+@pytest.fixture(autouse=True)
+def _cpu_threads():
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(old, 48))
+    yield
+    torch.set_num_threads(old)
+
+
+class ReplicatedSampler:
+    """latents of the D and G steps: batch 16 = four samples, each four times (b -> b // 4); the path step gets its own draws"""
+
+    def __init__(self, zd, zg, zpath, pl_noise):
+        self.q = [zd, zg, zpath]
+        self.pl = pl_noise
+
+    def latents(self, n):
+        z, p = self.q.pop(0)
+        assert z.shape[0] == n, (z.shape, n)
+        return z.to(DEV), p.to(DEV)
+
+    def randn_like(self, t):
+        return self.pl.to(t)
+
+
+def _leaves(sd):
+    P = {}
+    for k, v in sd.items():
+        v = v.detach().cpu()
+        train = v.is_floating_point() and 'noises' not in k and 'kernel' not in k and not k.startswith('token')
+        P[k] = v.clone().requires_grad_(True) if train else v
+    return P
+
+
+def test_train_iteration_256_b16():
+    from pinning import SignBank, pinned, record_oracle
+    from transeditor_amd.model_spatial_query import Discriminator, Generator
+    from transeditor_amd.train_step import TrainStep, default_args
+    args = default_args(size=SIZE, batch=B, lr=0.0)
+    G = Generator(SIZE, 512, 512, args.token, n_trans=8, pixel_norm_op_dim=1)
+    Dn = Discriminator(SIZE)
+    synth.fill_state_dict(G.state_dict(), 60)
+    synth.fill_state_dict(Dn.state_dict(), 61)
+    Pg, Pd = _leaves(G.state_dict()), _leaves(Dn.state_dict())
+    idx = torch.arange(B) // B4
+    zd4, zg4 = synth.latents(B4, 7001), synth.latents(B4, 7002)
+    real4 = synth.normal((B4, 3, SIZE, SIZE), 'it256.real').clamp(-1, 1)
+    zpath = synth.latents(B // 2, 7003)
+    pl_noise = synth.normal((B // 2, 3, SIZE, SIZE), 'it256.pl')
+    rep = lambda m: m[idx]
+
+    # ---- CPU oracle at batch 4 (the reference's arithmetic), recording the slope signs it takes
+    d_names = [n for n, _ in Dn.named_parameters()]
+    g_names = [n for n, _ in G.named_parameters()]
+    with torch.no_grad(), record_oracle() as bk_gd:
+        fake4 = O.generator_forward(Pg, zd4[0], zd4[1], SIZE)[0]
+    with record_oracle() as bk_df:
+        fake_pred = O.discriminator_forward(Pd, fake4, SIZE)
+    with record_oracle() as bk_dr:
+        real_pred = O.discriminator_forward(Pd, real4, SIZE)
+    d_loss = O.d_logistic_loss(real_pred, fake_pred)
+    ref_d = dict(zip(d_names, torch.autograd.grad(d_loss, [Pd[n] for n in d_names])))
+    ref_scores = (float(d_loss), float(real_pred.mean()), float(fake_pred.mean()))
+    assert len(bk_df.masks) == len(bk_dr.masks)
+    # HIP side of the D step: G forward on 16 = 4 x 4 samples; ONE discriminator pass over cat([fake16, real16])
+    bank_d = bk_gd.extend_stacked(16, dim=1).mapped(rep)
+    joint = SignBank()
+    joint.masks = [torch.cat([rep(f), rep(r)]) for f, r in zip(bk_df.masks, bk_dr.masks)]
+    bank_d = bank_d + joint
+    del bk_gd, bk_df, bk_dr, fake_pred, real_pred, d_loss
+
+    for v in Pd.values():
+        if v.requires_grad:
+            v.requires_grad_(False)
+    with record_oracle() as bk_g:
+        fake4g = O.generator_forward(Pg, zg4[0], zg4[1], SIZE)[0]
+    with record_oracle() as bk_gdisc:
+        g_loss = O.g_nonsaturating_loss(O.discriminator_forward(Pd, fake4g, SIZE))
+    g_leaves = [Pg[n] for n in g_names]
+    ref_g = dict(zip(g_names, torch.autograd.grad(g_loss, g_leaves, allow_unused=True)))
+    ref_gloss = float(g_loss)
+    bank_g = bk_g.extend_stacked(16, dim=1).mapped(rep) + bk_gdisc.mapped(rep)
+    del bk_g, bk_gdisc, fake4g, g_loss
+
+    # ---- the product's iteration at batch 16
+    sampler = ReplicatedSampler((zd4[0][idx], zd4[1][idx]), (zg4[0][idx], zg4[1][idx]), zpath, pl_noise)
+    ts = TrainStep(args, DEV, G.to(DEV), Dn.to(DEV), sampler)
+    snaps, stats = {}, {}
+
+    def pin_step(name, bank):
+        fn = getattr(ts, name)
+
+        def run(*a, **k):
+            with pinned(bank) as st:
+                out = fn(*a, **k)
+            stats[name] = st
+            return out
+        setattr(ts, name, run)
+
+    def snap_optim(opt, mod, tags):
+        step = opt.step
+
+        def run(*a, **k):
+            snaps[tags.pop(0)] = {n: (None if q.grad is None else q.grad.detach().clone()) for n, q in mod.named_parameters()}
+            return step(*a, **k)
+        opt.step = run
+    pin_step('d_step', bank_d)
+    pin_step('g_step', bank_g)
+    snap_optim(ts.d_optim, ts.discriminator, ['d', 'r1'])
+    snap_optim(ts.g_optim, ts.generator, ['g', 'path'])
+    w0 = float(sum(q.double().abs().sum() for q in ts.generator.parameters()))
+    losses = ts.iteration(0, real4[idx].to(DEV))
+    torch.cuda.synchronize()
+    assert set(snaps) == {'d', 'r1', 'g', 'path'}
+    for name in ('d_step', 'g_step'):
+        assert not stats[name]['unmatched'], (name, stats[name]['unmatched'])
+
+    def close(key, want, tol=1e-4):
+        got = float(losses[key])
+        assert abs(got - want) <= tol * max(abs(want), 1e-3), (key, got, want)
+    close('d', ref_scores[0])
+    close('real_score', ref_scores[1])
+    close('fake_score', ref_scores[2])
+    close('g', ref_gloss)
+
+    def compare(tag, ref):
+        top = max(float(v.double().norm()) for v in ref.values() if v is not None)
+        errs, unused = {}, []
+        for n, got in snaps[tag].items():
+            want = ref[n]
+            if got is None:
+                unused.append(n)
+                assert want is None or float(want.abs().max()) == 0.0, (tag, n)
+                continue
+            if n.endswith('k_transform.bias') or float(want.double().norm()) <= 1e-9 * top:
+                continue
+            errs[n] = rel_l2(got, want)
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+        st = stats[tag + '_step']
+        print(f'iteration 256/b16 {tag} step, pinned ({st["flips"]} of {st["elements"]} slopes): {len(errs)} parameter gradients, '
+              f'worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+        bad = [(k, v) for k, v in errs.items() if v > PIN_TOL]
+        assert not bad, (tag, bad[:8])
+        return unused
+    assert compare('d', ref_d) == []
+    unused = compare('g', ref_g)
+    assert len(unused) == 13 and all(n.endswith('noise.weight') for n in unused)
+    # R1 and the path-length step ran inside the iteration: finite losses, complete gradients
+    for k in ('r1', 'path', 'path_length'):
+        assert torch.isfinite(losses[k]).all(), k
+    assert all(v is not None and torch.isfinite(v).all() for v in snaps['r1'].values())
+    assert all(v is None or torch.isfinite(v).all() for v in snaps['path'].values())
+    w1 = float(sum(q.double().abs().sum() for q in ts.generator.parameters()))
+    assert abs(w1 - w0) <= 1e-10 * w0                                          # lr = 0: weights untouched

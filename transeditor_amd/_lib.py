@@ -24,9 +24,10 @@ _SIGNATURES = {
     'te_bias_act_f32': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_f16': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_f64': (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _L, _L, _L, _P]),
-    'te_bias_act_bwd_f32': (C.c_int, [_P, _P, _P, _P, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_bwd_ws_floats': (C.c_int64, [_L, _L, _L]),
+    'te_bias_act_bwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _L, _L, _L, _P]),
     'te_bias_act_bwd_rgb_supported': (C.c_int, [_L, _L, _L]),
-    'te_bias_act_bwd_rgb_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _P]),
+    'te_bias_act_bwd_rgb_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _P]),
     'te_upfirdn2d_f32': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                    _P, _L, _I, _F, _F, _P]),
     'te_upfirdn2d_f16': (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -43,7 +44,8 @@ _SIGNATURES = {
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_group_plan': (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P]),
     'te_wgrad_group_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'te_wgrad_reduce_ws_floats': (C.c_int64, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    'te_wgrad_reduce_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     'te_rgb_supported': (C.c_int, [_I, _I, _I]),
     'te_rgb_fwd_f32': (C.c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     'te_rgb_dgrad_f32': (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
@@ -138,30 +140,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Small zero-initialised accumulators (bias gradients, style / demodulation gradients: the targets of the kernels' atomic
-# or partial-sum reductions) come out of a pre-zeroed 1 MiB block instead of one fill launch each: ~110 -> ~3 fill kernels per
-# training iteration.  A slot is handed out ONCE (it becomes somebody's gradient and dies with it; the block's memory goes
-# back to the caching allocator when its last slot dies).  Not used while a hipGraph is being captured: a replay would find
-# the slots dirty.
-import threading
-
-_ZPOOL = threading.local()
-_ZBLOCK, _ZMAX = 1 << 18, 1 << 15          # floats per block; largest request served from the pool
-
-
-def zeros(n, device):
-    """1-D fp32 tensor of n zeros (16-byte aligned)"""
-    if n > _ZMAX or n <= 0 or torch.cuda.is_current_stream_capturing():
-        return torch.zeros(n, device=device, dtype=torch.float32)
-    st = _ZPOOL.__dict__
-    blk, off, sid = st.get('blk'), st.get('off', 0), torch.cuda.current_stream().cuda_stream
-    n4 = (n + 3) & ~3
-    if blk is None or blk.device != device or off + n4 > _ZBLOCK or st.get('sid') != sid:
-        blk, off = torch.zeros(_ZBLOCK, device=device, dtype=torch.float32), 0
-    st['blk'], st['off'], st['sid'] = blk, off + n4, sid
-    return blk[off:off + n]
-
-
 # --------------------------------------------------------------------------------------------- K1
 _OTHER = {torch.float16: 'f16', torch.float64: 'f64'}       # K1 / K2 also exist in the reference's other two dispatch types
 
@@ -197,6 +175,16 @@ def bias_act(x, b, ref, act, grad, alpha, scale):
     return out
 
 
+def _bias_grad_buffers(want_bias, outer, Cn, inner, device):
+    """(gb, workspace): the bias gradient is WRITTEN by a fixed-order second pass over per-block partials (no atomics, so no
+    zero fill and bit-reproducible); it owns its storage (it becomes a parameter's .grad)."""
+    if not want_bias:
+        return None, None
+    n = lib().te_bias_act_bwd_ws_floats(outer, Cn, inner)
+    return (torch.empty(Cn, device=device, dtype=torch.float32),
+            torch.empty(n, device=device, dtype=torch.float32) if n > 0 else None)
+
+
 def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
     g = g.contiguous()
     if g.dtype in _OTHER:       # the reference's two steps (fused_act.py:18-38): the kernel in grad mode, then the bias sum
@@ -207,8 +195,8 @@ def bias_act_bwd(g, ref, alpha, scale, want_bias=True):
     inner = 1
     for d in g.shape[2:]:
         inner *= d
-    gb = zeros(Cn, g.device) if want_bias else None
-    _check(lib().te_bias_act_bwd_f32(_ptr(gi), _ptr(gb), _ptr(g), _ptr(ref), alpha, scale, g.shape[0], Cn, inner,
+    gb, ws = _bias_grad_buffers(want_bias, g.shape[0], Cn, inner, g.device)
+    _check(lib().te_bias_act_bwd_f32(_ptr(gi), _ptr(gb), _ptr(ws), _ptr(g), _ptr(ref), alpha, scale, g.shape[0], Cn, inner,
                                      _stream()), 'te_bias_act_bwd_f32')
     return gi, gb
 
@@ -229,8 +217,8 @@ def bias_act_bwd_rgb(g, ref, grgb, wrgb, srgb, wscale, alpha, scale, want_bias=T
     inner = 1
     for d in ref.shape[2:]:
         inner *= d
-    gb = zeros(Cn, ref.device) if want_bias else None
-    _check(lib().te_bias_act_bwd_rgb_f32(_ptr(gi), _ptr(gb), _ptr(g), _ptr(ref), _ptr(grgb), _ptr(wrgb.contiguous()),
+    gb, ws = _bias_grad_buffers(want_bias, ref.shape[0], Cn, inner, ref.device)
+    _check(lib().te_bias_act_bwd_rgb_f32(_ptr(gi), _ptr(gb), _ptr(ws), _ptr(g), _ptr(ref), _ptr(grgb), _ptr(wrgb.contiguous()),
                                          _ptr(srgb.contiguous()) if srgb is not None else None, wscale, alpha, scale,
                                          ref.shape[0], Cn, inner, _stream()), 'te_bias_act_bwd_rgb_f32')
     return gi, gb
@@ -392,16 +380,15 @@ def wgrad_slabs(g, x, kind, H, W, group=False):
 def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc=False, want_osc=False):
     B, S, Co, Ci, taps = slabs.shape
     dev, dt = slabs.device, slabs.dtype
+    # all three outputs are WRITTEN (shares of different blocks meet in the workspace, summed in a fixed order: no atomics)
     gw = torch.empty(Co, Ci, taps, device=dev, dtype=dt) if want_w else None
-    gisc = gosc = None
-    if want_isc and want_osc:           # one slot for both accumulators
-        z = zeros(B * (Ci + Co), dev)
-        gisc, gosc = z[:B * Ci].view(B, Ci), z[B * Ci:].view(B, Co)
-    elif want_isc:
-        gisc = zeros(B * Ci, dev).view(B, Ci)
-    elif want_osc:
-        gosc = zeros(B * Co, dev).view(B, Co)
-    _check(lib().te_wgrad_reduce_f32(_ptr(gw), _ptr(gisc), _ptr(gosc), _ptr(slabs), _ptr(w.contiguous()), wscale,
+    gisc = torch.empty(B, Ci, device=dev, dtype=dt) if want_isc else None
+    gosc = torch.empty(B, Co, device=dev, dtype=dt) if want_osc else None
+    n = lib().te_wgrad_reduce_ws_floats(B, S, Co, Ci, taps, int(want_w), int(want_isc), int(want_osc))
+    if n < 0:
+        raise RuntimeError(f'te_wgrad_reduce_ws_floats failed ({n})')
+    ws = torch.empty(n, device=dev, dtype=dt) if n > 0 else None
+    _check(lib().te_wgrad_reduce_f32(_ptr(gw), _ptr(gisc), _ptr(gosc), _ptr(ws), _ptr(slabs), _ptr(w.contiguous()), wscale,
                                      _ptr(isc), _ptr(osc), B, S, Co, Ci, taps, _stream()), 'te_wgrad_reduce_f32')
     return gw, gisc, gosc
 

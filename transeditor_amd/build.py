@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libte_hip.so')
 SOURCES = ['te_common.hip', 'bias_act.hip', 'upfirdn2d.hip', 'conv.hip', 'wgrad.hip', 'attention.hip', 'rgb.hip', 'linear.hip', 'style.hip', 'layernorm.hip', 'optim.hip', 'stddev.hip', 'chanscale.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-pass-failed', '-munsafe-fp-atomics']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-pass-failed']
 
 
 def _hipcc():

@@ -1,7 +1,8 @@
 // K1: fused bias + leaky-ReLU family for gfx950 (wave64).
 //   te_bias_act_f32      forward / grad / grad-grad in one kernel family (HBM streaming, 16 B per lane)
 //   te_bias_act_bwd_f32  gi = g * slope(ref) * scale and the per-channel bias gradient in the same pass
-//                        (wave64 shuffle reduction -> LDS across the 4 waves -> one atomic per block)
+//                        (wave64 shuffle reduction -> LDS across the 4 waves -> one partial per block in the caller's
+//                        workspace -> fixed-order second pass: bit-reproducible, no atomics)
 // Semantics follow the reference op (fused_bias_act_kernel.cu:26-47); the channel index of flat
 // element i is (i / step_b) % size_b with integer arithmetic.
 #include "te_common.h"
@@ -72,7 +73,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* lds4) {
 
 // [outer][C][inner], inner % 4 == 0: grid (chunks, C, outer); each block streams CH float4-vectors of one row
 constexpr int kBwdVecPerThread = 4;
-__global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restrict__ gi, float* __restrict__ gb,
+__global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restrict__ gi, float* __restrict__ part,
                                                                 const float4* __restrict__ g, const float4* __restrict__ ref,
                                                                 float alpha, float scale, uint32_t C, uint32_t inner4) {
     __shared__ float lds4[4];
@@ -94,10 +95,20 @@ __global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restri
             acc += (o.x + o.y) + (o.z + o.w);
         }
     }
-    if (gb) {
+    if (part) {
         const float tot = block_sum_256(acc, lds4);
-        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+        if (threadIdx.x == 0) part[((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x] = tot;
     }
+}
+
+// second pass of the row kernels: gb[c] = sum of the channel's per-block partials, in a FIXED order (lane-strided partial
+// sums, then the wave's shuffle tree): the bias gradient is bit-identical from run to run
+__global__ __launch_bounds__(64) void bias_parts_sum_kernel(float* __restrict__ gb, const float* __restrict__ part, uint32_t parts) {
+    const float* p = part + (size_t)blockIdx.x * parts;
+    float acc = 0.f;
+    for (uint32_t j = threadIdx.x; j < parts; j += 64) acc += p[j];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) gb[blockIdx.x] = acc;
 }
 
 // The same pass with the data gradient of a ToRGB layer folded in (generator, model_spatial_query.py:416-425: the activation
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_rows_kernel(float4* __restri
 // i.e. te_rgb_dgrad_f32 + the framework's gradient-accumulation add + te_bias_act_bwd_f32 in one read of g / ref and one
 // write of gi (12 instead of 28 bytes per element; the 3-channel grgb rows are re-read by every channel from L2).  g may be
 // NULL (the last layer's activation feeds ToRGB only).
-__global__ __launch_bounds__(256) void bias_act_bwd_rgb_rows_kernel(float4* __restrict__ gi, float* __restrict__ gb,
+__global__ __launch_bounds__(256) void bias_act_bwd_rgb_rows_kernel(float4* __restrict__ gi, float* __restrict__ part,
                                                                     const float4* __restrict__ g, const float4* __restrict__ ref,
                                                                     const float4* __restrict__ grgb, const float* __restrict__ wrgb,
                                                                     const float* __restrict__ srgb, float wscale, float alpha,
@@ -139,13 +150,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_rgb_rows_kernel(float4* __re
             acc += (o.x + o.y) + (o.z + o.w);
         }
     }
-    if (gb) {
+    if (part) {
         const float tot = block_sum_256(acc, lds4);
-        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+        if (threadIdx.x == 0) part[((size_t)c * gridDim.z + n) * gridDim.x + blockIdx.x] = tot;
     }
 }
 
-// generic layout: one block per channel, loops over (n, i)
+// generic layout: one block per channel, loops over (n, i): the block owns the channel's sum (plain store)
 __global__ __launch_bounds__(256) void bias_act_bwd_chan_kernel(float* __restrict__ gi, float* __restrict__ gb,
                                                                 const float* __restrict__ g, const float* __restrict__ ref,
                                                                 float alpha, float scale, int64_t outer, int64_t C,
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_chan_kernel(float* __restric
     }
     if (gb) {
         const float tot = block_sum_256(acc, lds4);
-        if (threadIdx.x == 0) atomicAdd(gb + c, tot);
+        if (threadIdx.x == 0) gb[c] = tot;
     }
 }
 
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_2d_kernel(float* __restrict_
         gi[idx] = o;
         acc += o;
     }
-    if (gb) atomicAdd(gb + c, acc);
+    if (gb) gb[c] = acc;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -266,7 +277,16 @@ extern "C" int te_bias_act_f32(float* out, const float* x, const float* b, const
     return te::launch_status("te_bias_act_f32");
 }
 
-extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const float* ref, float alpha, float scale,
+static bool bwd_rows_path(int64_t outer, int64_t C, int64_t inner) {
+    return inner % 4 == 0 && inner >= 1024 && C <= 65535 && outer <= 65535;
+}
+
+extern "C" int64_t te_bias_act_bwd_ws_floats(int64_t outer, int64_t C, int64_t inner) {
+    if (outer <= 0 || C <= 0 || inner <= 0 || !bwd_rows_path(outer, C, inner)) return 0;
+    return C * outer * te::cdiv(inner / 4, 256 * kBwdVecPerThread);
+}
+
+extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, float* ws, const float* g, const float* ref, float alpha, float scale,
                                    int64_t outer, int64_t C, int64_t inner, te_stream_t stream_) {
     TE_REQUIRE(gi && g && ref, TE_ERR_NULL, "te_bias_act_bwd_f32: gi/g/ref is NULL");
     TE_REQUIRE(outer >= 0 && C > 0 && inner > 0, TE_ERR_SHAPE, "te_bias_act_bwd_f32: bad dims");
@@ -274,12 +294,12 @@ extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const f
     hipStream_t stream = (hipStream_t)stream_;
     if (inner == 1) {
         bias_act_bwd_2d_kernel<<<(int)te::cdiv(C, 256), 256, 0, stream>>>(gi, gb, g, ref, alpha, scale, outer, C);
-    } else if (inner % 4 == 0 && inner >= 1024 && aligned16(gi) && aligned16(g) && aligned16(ref) && C <= 65535 &&
-               outer <= 65535) {
+    } else if (bwd_rows_path(outer, C, inner) && aligned16(gi) && aligned16(g) && aligned16(ref) && (!gb || ws)) {
         const uint32_t inner4 = (uint32_t)(inner / 4);
         dim3 grid((unsigned)te::cdiv(inner4, 256 * kBwdVecPerThread), (unsigned)C, (unsigned)outer);
-        bias_act_bwd_rows_kernel<<<grid, 256, 0, stream>>>((float4*)gi, gb, (const float4*)g, (const float4*)ref, alpha,
+        bias_act_bwd_rows_kernel<<<grid, 256, 0, stream>>>((float4*)gi, gb ? ws : nullptr, (const float4*)g, (const float4*)ref, alpha,
                                                            scale, (uint32_t)C, inner4);
+        if (gb) bias_parts_sum_kernel<<<(int)C, 64, 0, stream>>>(gb, ws, (uint32_t)(grid.x * grid.z));
     } else {
         bias_act_bwd_chan_kernel<<<(int)C, 256, 0, stream>>>(gi, gb, g, ref, alpha, scale, outer, C, inner);
     }
@@ -287,21 +307,23 @@ extern "C" int te_bias_act_bwd_f32(float* gi, float* gb, const float* g, const f
 }
 
 extern "C" int te_bias_act_bwd_rgb_supported(int64_t outer, int64_t C, int64_t inner) {
-    return (outer > 0 && C > 0 && inner % 4 == 0 && inner >= 1024 && C <= 65535 && outer <= 65535) ? 1 : 0;
+    return (outer > 0 && C > 0 && bwd_rows_path(outer, C, inner)) ? 1 : 0;
 }
 
-extern "C" int te_bias_act_bwd_rgb_f32(float* gi, float* gb, const float* g, const float* ref, const float* grgb, const float* wrgb,
-                                       const float* srgb, float wscale, float alpha, float scale, int64_t outer, int64_t C,
-                                       int64_t inner, te_stream_t stream_) {
+extern "C" int te_bias_act_bwd_rgb_f32(float* gi, float* gb, float* ws, const float* g, const float* ref, const float* grgb,
+                                       const float* wrgb, const float* srgb, float wscale, float alpha, float scale, int64_t outer,
+                                       int64_t C, int64_t inner, te_stream_t stream_) {
     TE_REQUIRE(gi && ref && grgb && wrgb, TE_ERR_NULL, "te_bias_act_bwd_rgb_f32: gi/ref/grgb/wrgb is NULL");
+    TE_REQUIRE(!gb || ws, TE_ERR_NULL, "te_bias_act_bwd_rgb_f32: the bias gradient needs the workspace (te_bias_act_bwd_ws_floats)");
     TE_REQUIRE(te_bias_act_bwd_rgb_supported(outer, C, inner), TE_ERR_UNSUPPORTED,
                "te_bias_act_bwd_rgb_f32: needs inner %% 4 == 0 and inner >= 1024 (use te_rgb_dgrad_f32 + te_bias_act_bwd_f32)");
     TE_REQUIRE(aligned16(gi) && (!g || aligned16(g)) && aligned16(ref) && aligned16(grgb), TE_ERR_UNSUPPORTED,
                "te_bias_act_bwd_rgb_f32: 16-byte aligned tensors required");
     const uint32_t inner4 = (uint32_t)(inner / 4);
     dim3 grid((unsigned)te::cdiv(inner4, 256 * kBwdVecPerThread), (unsigned)C, (unsigned)outer);
-    bias_act_bwd_rgb_rows_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>((float4*)gi, gb, (const float4*)g, (const float4*)ref,
-                                                                       (const float4*)grgb, wrgb, srgb, wscale, alpha, scale,
-                                                                       (uint32_t)C, inner4);
+    hipStream_t stream = (hipStream_t)stream_;
+    bias_act_bwd_rgb_rows_kernel<<<grid, 256, 0, stream>>>((float4*)gi, gb ? ws : nullptr, (const float4*)g, (const float4*)ref,
+                                                          (const float4*)grgb, wrgb, srgb, wscale, alpha, scale, (uint32_t)C, inner4);
+    if (gb) bias_parts_sum_kernel<<<(int)C, 64, 0, stream>>>(gb, ws, (uint32_t)(grid.x * grid.z));
     return te::launch_status("te_bias_act_bwd_rgb_f32");
 }

@@ -673,25 +673,25 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
                 }
                 continue;
             }
-            // Split launches (small images): raw partial sums; scale / bias / activation happen in conv_finalize_kernel.  With a
-            // workspace every split writes its own slab (plain stores, summed in fixed order: deterministic); without one the
-            // splits meet in `out` through atomics.  Same addressing as above: one offset per tile, uniform row strides.
+            // Split launches (small images): raw partial sums; scale / bias / activation happen in conv_finalize_kernel.  Every
+            // split writes its own slab of the workspace (plain stores, summed in fixed order: deterministic; a launch without a
+            // workspace is never split).  Same addressing as above: one offset per tile, uniform row strides.
             {
                 const size_t off0 = ((size_t)bc * p.M + mbase) * oplane + (size_t)(IS_T2 ? 2 * ci : ci) * p.Wo + (IS_T2 ? 2 * cj : cj);
-                float* b0 = p.ws ? p.ws + (size_t)blockIdx.z * p.B * p.M * oplane + off0 : p.out + off0;
+                float* b0 = p.ws + (size_t)blockIdx.z * p.B * p.M * oplane + off0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dm = (r & 3) + 8 * (r >> 2);
                     if (!(cell_ok && mbase + dm < p.M)) continue;
                     float* d = b0 + (size_t)dm * oplane;
                     if (!IS_T2) {
-                        if (p.ws) d[0] = acc[mb][nb][r]; else atomicAdd(d, acc[mb][nb][r]);
+                        d[0] = acc[mb][nb][r];
                     } else {
 #pragma unroll
                         for (int ph = 0; ph < 4; ++ph) {
                             if (2 * ci + (ph >> 1) < p.Ho && 2 * cj + (ph & 1) < p.Wo) {
                                 float* e = d + ((ph >> 1) ? p.Wo : 0) + (ph & 1);
-                                if (p.ws) e[0] = acc[mb][nb * 4 + ph][r]; else atomicAdd(e, acc[mb][nb * 4 + ph][r]);
+                                e[0] = acc[mb][nb * 4 + ph][r];
                             }
                         }
                     }
@@ -1103,14 +1103,11 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
     const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
     const int tc = pl.tc;
     a.ksplit = pl.ksplit; a.kchunk = pl.kchunk;
-    if (a.ksplit == 1) a.ws = nullptr;
-    TE_REQUIRE(!((res || mask_ref) && a.ksplit > 1 && !a.ws), TE_ERR_NULL,
-               "te_conv_res_f32: a split launch with a residual / mask epilogue needs the workspace");
-    if (a.ksplit > 1 && !a.ws) {       // no workspace: the splits accumulate into `out` with atomics (order not fixed)
-        const size_t bytes = sizeof(float) * (size_t)B * M * (kind == TE_CONV_T2 ? (size_t)(2 * H + 1) * (2 * W + 1) : (size_t)H * W);
-        hipError_t e = hipMemsetAsync(out, 0, bytes, s);
-        if (e != hipSuccess) return te::fail((int)e, "te_conv_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+    if (a.ksplit > 1 && !a.ws) {       // no workspace (te_conv_f32): the channel loop is not split - slower on 4x4 ... 16x16 images,
+        a.ksplit = 1;                  // but no atomics anywhere: every result of this library is bit-reproducible
+        a.kchunk = a.Kp;
     }
+    if (a.ksplit == 1) a.ws = nullptr;
     int rc = 0;
     switch (kind) {
         case TE_CONV_3X3: {

@@ -516,8 +516,8 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_w_kernel(float* __restr
         if (isc) v *= isc[(size_t)b * Ci + ci];
         acc += v;
     }
-    if (nchunk > 1) atomicAdd(gw + e, acc * wscale);
-    else gw[e] = acc * wscale;
+    // nchunk > 1: `gw` is the workspace [nchunk][E]; sum_parts_kernel adds the chunks in a fixed order
+    gw[(size_t)blockIdx.y * E + e] = acc * wscale;
 }
 
 // 16 bytes per lane: requires E % 4 == 0 and 16-byte aligned slabs
@@ -549,12 +549,8 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_w4_kernel(float* __rest
         }
         acc.x += v.x * sc[0]; acc.y += v.y * sc[1]; acc.z += v.z * sc[2]; acc.w += v.w * sc[3];
     }
-    if (nchunk > 1) {
-        atomicAdd(gw + e, acc.x * wscale); atomicAdd(gw + e + 1, acc.y * wscale);
-        atomicAdd(gw + e + 2, acc.z * wscale); atomicAdd(gw + e + 3, acc.w * wscale);
-    } else {
-        *reinterpret_cast<float4*>(gw + e) = make_float4(acc.x * wscale, acc.y * wscale, acc.z * wscale, acc.w * wscale);
-    }
+    *reinterpret_cast<float4*>(gw + (size_t)blockIdx.y * E + e) =
+        make_float4(acc.x * wscale, acc.y * wscale, acc.z * wscale, acc.w * wscale);
 }
 
 template <int NT>
@@ -567,6 +563,10 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t slab_sz = (size_t)Co * Ci * NT;
     const float* sb = slabs + (size_t)b * S * slab_sz;
+    float osum = 0.f;                                      // thread j < COB: d osc of channel cob + j, summed over the passes
+    // d isc: this block's share goes to its own row of `gisc` ([gridDim.y][B][Ci] when there are several channel blocks: the
+    // fixed-order second pass adds the rows; the final tensor itself when there is one)
+    float* gi_row = gisc ? gisc + (size_t)blockIdx.y * B * Ci : nullptr;
     for (int c0 = 0; c0 < Ci; c0 += RTHREADS) {            // usually one pass (Ci <= 256) or two (512)
         const int ci = c0 + threadIdx.x;
         const bool live = ci < Ci;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
             }
             posc[j] = live ? is * dot : 0.f;
         }
-        if (gisc && live) atomicAdd(gisc + (size_t)b * Ci + ci, pisc);
+        if (gi_row && live) gi_row[(size_t)b * Ci + ci] = pisc;
         if (gosc) {
 #pragma unroll
             for (int j = 0; j < COB; ++j) {
@@ -604,16 +604,16 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_sc_kernel(float* __rest
                 if (lane == 0) red[wid][j] = v;
             }
             __syncthreads();
-            if (threadIdx.x < COB && cob + threadIdx.x < Co)
-                atomicAdd(gosc + (size_t)b * Co + cob + threadIdx.x,
-                          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+            if (threadIdx.x < COB)
+                osum += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
             __syncthreads();
         }
     }
+    if (gosc && threadIdx.x < COB && cob + threadIdx.x < Co) gosc[(size_t)b * Co + cob + threadIdx.x] = osum;      // the block owns these
 }
 
 // taps == 1 with <= 4 output channels (ToRGB): block (ci chunk, b); a thread owns one input channel of one sample, sums
-// its slabs, writes gisc[b,ci] directly (it sees every output channel) and adds its share of gw.
+// its slabs, writes its gisc[b,ci] (it sees every output channel) and its share of gw as parts for the second pass.
 __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_few_kernel(float* __restrict__ gw, float* __restrict__ gisc,
                                                                     const float* __restrict__ slabs, const float* __restrict__ w,
                                                                     float wscale, const float* __restrict__ isc, int B, int S,
@@ -632,17 +632,17 @@ __global__ __launch_bounds__(RTHREADS) void wgrad_reduce_few_kernel(float* __res
     }
     const float is = isc ? isc[(size_t)b * Ci + ci] : 1.f;
     float gi = 0.f;
+    // gw: every (chunk, sample) block writes its own part [gridDim.z * B][Co * Ci]; gisc: [gridDim.z][B * Ci] (the final tensor
+    // when there is one chunk).  The fixed-order second pass adds the parts.
+    float* gwp = gw ? gw + ((size_t)blockIdx.z * B + b) * E : nullptr;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         if (o < Co) {
             gi += u[o] * w[(size_t)o * Ci + ci];
-            if (gw) atomicAdd(gw + (size_t)o * Ci + ci, u[o] * is * wscale);
+            if (gwp) gwp[(size_t)o * Ci + ci] = u[o] * is * wscale;
         }
     }
-    if (gisc) {
-        if (gridDim.z > 1) atomicAdd(gisc + (size_t)b * Ci + ci, gi * wscale);     // gisc is zero-filled by the caller
-        else gisc[(size_t)b * Ci + ci] = gi * wscale;
-    }
+    if (gisc) gisc[((size_t)blockIdx.z * B + b) * Ci + ci] = gi * wscale;
 }
 
 // One pass over the slabs for all three gradients (3x3 kinds, Co % 16 == 0, Ci % 32 == 0).  A block of 2 waves owns a
@@ -677,7 +677,7 @@ __device__ __forceinline__ void fused_consume(const FusedCtx& c, int b, const f3
         po += __shfl_xor(po, 1, 64);
         po += __shfl_xor(po, 2, 64);
         po += __shfl_xor(po, 4, 64);
-        if (c.l8 == 0) atomicAdd(c.gosc + (size_t)b * c.Co + c.co, po);
+        if (c.l8 == 0) c.gosc[(size_t)b * c.Co + c.co] = po;             // this block's part (c.gosc points at its row)
     }
     if (c.gisc) {
         float* rb = red + (b & 1) * 64;
@@ -690,7 +690,7 @@ __device__ __forceinline__ void fused_consume(const FusedCtx& c, int b, const f3
             if (c.lane < 8) rb[c.wid * 32 + c.l8 * 4 + k] = v;
         }
         __syncthreads();                   // one barrier per sample: the buffer alternates with b
-        if (c.tid < 32) atomicAdd(c.gisc + (size_t)b * c.Ci + c.cib + c.tid, rb[c.tid] + rb[32 + c.tid]);
+        if (c.tid < 32) c.gisc[(size_t)b * c.Ci + c.cib + c.tid] = rb[c.tid] + rb[32 + c.tid];      // this block's part
     }
 }
 
@@ -700,11 +700,16 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
                                                                       const float* __restrict__ isc, const float* __restrict__ osc,
                                                                       int B, int S, int Co, int Ci) {
     // blockIdx.z splits the slab chunks of every sample (narrow layers: a 32 x 32 weight has 2 tiles but hundreds of
-    // chunks); all three outputs are linear in the slab sums, so the parts combine with atomics (outputs zero-filled)
+    // chunks); all three outputs are linear in the slab sums.  NO atomics: d osc of a (sample, channel) gets a share from
+    // every ci block and chunk, d isc from every co block and chunk, dW (when chunked) from every chunk - each block writes
+    // its share to its own row of the workspace (gosc: [gridDim.z * gridDim.x][B][Co], gisc: [gridDim.z * gridDim.y][B][Ci],
+    // gw: [gridDim.z][E]) and sum_parts_kernel adds the rows in a fixed order: bit-reproducible gradients.
     const int s0 = (int)((int64_t)S * blockIdx.z / gridDim.z), s1 = (int)((int64_t)S * (blockIdx.z + 1) / gridDim.z);
     __shared__ float red[2 * 64];
     FusedCtx c;
-    c.gisc = gisc; c.gosc = gosc; c.isc = isc; c.osc = osc; c.Co = Co; c.Ci = Ci;
+    c.gisc = gisc ? gisc + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * B * Ci : nullptr;
+    c.gosc = gosc ? gosc + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * B * Co : nullptr;
+    c.isc = isc; c.osc = osc; c.Co = Co; c.Ci = Ci;
     c.tid = threadIdx.x; c.l8 = c.tid & 7; c.lane = c.tid & 63; c.wid = c.tid >> 6;
     c.co = blockIdx.y * FROWS + (c.tid >> 3); c.cib = blockIdx.x * 32; c.ci0 = c.cib + c.l8 * 4;
     const size_t E = (size_t)Co * Ci * 9;
@@ -748,17 +753,45 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
         fused_consume(c, b, u0, wv, acc, red);
     }
     if (gw) {
+        float* gwz = gw + (size_t)blockIdx.z * E;           // (one chunk: the final tensor itself)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const f32x4 v = acc[i] * wscale;
-            if (gridDim.z > 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) atomicAdd(gw + off + 4 * i + q, v[q]);
-            } else {
-                *reinterpret_cast<f32x4*>(gw + off + 4 * i) = v;
-            }
-        }
+        for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(gwz + off + 4 * i) = acc[i] * wscale;
     }
+}
+
+// Fixed-order second pass of the reducers: out[i] = sum_p parts[p][i], p ascending; up to three outputs per launch.
+struct SumJob { float* out; const float* parts; int nparts; int64_t n; };
+struct SumJobs { SumJob j[3]; };
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(SumJobs jobs) {
+    const SumJob J = jobs.j[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (int64_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int p = 0; p < J.nparts; ++p) a += J.parts[(size_t)p * J.n + i];
+        J.out[i] = a;
+    }
+}
+
+inline void launch_sum_parts(const SumJob* jobs, int n, hipStream_t s) {
+    if (!n) return;
+    SumJobs t{};
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) { t.j[i] = jobs[i]; mx = std::max(mx, jobs[i].n); }
+    sum_parts_kernel<<<dim3((unsigned)std::min<int64_t>(te::cdiv(mx, 256), 4 * te::kNumCU), (unsigned)n), 256, 0, s>>>(t);
+}
+
+// chunk counts of the reducer paths (shared by te_wgrad_reduce_ws_floats and the launch)
+inline bool reduce_fused_ok(int Co, int Ci, int taps) { return taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && Co / FROWS <= 65535; }
+inline int reduce_fused_nz(int S, int Co, int Ci) {
+    const int tiles = (Ci / 32) * (Co / FROWS);
+    return (tiles < te::kNumCU / 4 && S >= 8) ? (int)std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, tiles)) : 1;
+}
+inline int reduce_few_nz(int B, int S, int Ci) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, (int64_t)te::cdiv(Ci, RTHREADS) * B)));
+}
+inline int reduce_w_nchunk(int B, int S, int64_t E, bool vec) {
+    const int64_t blocks = te::cdiv(vec ? E / 4 : E, RTHREADS);
+    return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * S, te::cdiv(2 * te::kNumCU, blocks)));
 }
 
 }  // namespace
@@ -843,54 +876,86 @@ static int wgrad_launch(float* slabs, const float* g, const float* x, int kind, 
     return te::launch_status("te_wgrad_f32");
 }
 
-extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, const float* slabs, const float* w, float wscale,
+// floats of workspace te_wgrad_reduce_f32 needs for this problem (an upper bound over the alignment-dependent paths)
+extern "C" int64_t te_wgrad_reduce_ws_floats(int B, int S, int Co, int Ci, int taps, int want_w, int want_isc, int want_osc) {
+    if (B <= 0 || S <= 0 || Co <= 0 || Ci <= 0 || (taps != 1 && taps != 9)) return TE_ERR_SHAPE;
+    const int64_t E = (int64_t)Co * Ci * taps;
+    int64_t n = 0;
+    if (reduce_fused_ok(Co, Ci, taps)) {
+        const int nz = reduce_fused_nz(S, Co, Ci);
+        if (want_osc) n += (int64_t)nz * (Ci / 32) * B * Co;
+        if (want_isc) n += (int64_t)nz * (Co / FROWS) * B * Ci;
+        if (want_w && nz > 1) n += (int64_t)nz * E;
+    }
+    int64_t m = 0;                                         // the generic path (also the fall-back of a misaligned fused problem)
+    if (want_w) m += (int64_t)std::max(reduce_w_nchunk(B, S, E, false), reduce_w_nchunk(B, S, E, E % 4 == 0)) * E;
+    if (want_isc) m += (int64_t)te::cdiv(Co, COB) * B * Ci;
+    int64_t f = 0;                                         // ToRGB path
+    if (taps == 1 && Co <= 4) {
+        const int nzf = reduce_few_nz(B, S, Ci);
+        if (want_w) f += (int64_t)nzf * B * E;
+        if (want_isc && nzf > 1) f += (int64_t)nzf * B * Ci;
+    }
+    return std::max(n, std::max(m, f));
+}
+
+extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, float* ws, const float* slabs, const float* w, float wscale,
                                    const float* isc, const float* osc, int B, int S, int Co, int Ci, int taps,
                                    te_stream_t stream_) {
     TE_REQUIRE(slabs && w, TE_ERR_NULL, "te_wgrad_reduce_f32: NULL pointer");
     TE_REQUIRE(B > 0 && S > 0 && Co > 0 && Ci > 0 && (taps == 1 || taps == 9), TE_ERR_SHAPE, "te_wgrad_reduce_f32: bad dims");
+    TE_REQUIRE(ws || te_wgrad_reduce_ws_floats(B, S, Co, Ci, taps, gw != nullptr, gisc != nullptr, gosc != nullptr) == 0, TE_ERR_NULL,
+               "te_wgrad_reduce_f32: this problem needs the workspace (te_wgrad_reduce_ws_floats)");
     hipStream_t s = (hipStream_t)stream_;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gw);
-    if (taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && (al & 15) == 0 && Co / FROWS <= 65535) {      // single-pass path
-        const int tiles = (Ci / 32) * (Co / FROWS);
-        int nz = 1;
-        if (tiles < te::kNumCU / 4 && S >= 8) nz = (int)std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, tiles));
-        if (gw && nz > 1) {
-            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * Ci * 9, s);
-            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-        }
-        dim3 grid((unsigned)(Ci / 32), (unsigned)(Co / FROWS), (unsigned)nz);
-        wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(gw, gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+    const int64_t E = (int64_t)Co * Ci * taps;
+    SumJob jobs[3];
+    int nj = 0;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gw) |
+                         reinterpret_cast<uintptr_t>(ws);
+    if (reduce_fused_ok(Co, Ci, taps) && (al & 15) == 0) {                                          // single-pass path
+        const int nz = reduce_fused_nz(S, Co, Ci), nX = Ci / 32, nY = Co / FROWS;
+        float* p = ws;
+        float* po = nullptr; float* pi = nullptr; float* pw = gw;
+        if (gosc) { po = p; p += (size_t)nz * nX * B * Co; jobs[nj++] = SumJob{gosc, po, nz * nX, (int64_t)B * Co}; }
+        if (gisc) { pi = p; p += (size_t)nz * nY * B * Ci; jobs[nj++] = SumJob{gisc, pi, nz * nY, (int64_t)B * Ci}; }
+        if (gw && nz > 1) { pw = p; p += (size_t)nz * E; jobs[nj++] = SumJob{gw, pw, nz, E}; }
+        dim3 grid((unsigned)nX, (unsigned)nY, (unsigned)nz);
+        wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(pw, pi, po, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        launch_sum_parts(jobs, nj, s);
         return te::launch_status("te_wgrad_reduce_f32");
     }
     if (taps == 1 && Co <= 4 && !gosc && !osc) {                                                   // ToRGB
-        if (gw) {
-            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Co * Ci, s);
-            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-        }
         // few, long per-thread streams when the image is large (S up to a few hundred): split them over blockIdx.z
-        const int nzf = (int)std::max<int64_t>(1, std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, (int64_t)te::cdiv(Ci, RTHREADS) * B)));
+        const int nzf = reduce_few_nz(B, S, Ci);
+        float* p = ws;
+        float* pw = nullptr; float* pi = gisc;
+        if (gw) { pw = p; p += (size_t)nzf * B * E; jobs[nj++] = SumJob{gw, pw, nzf * B, E}; }
+        if (gisc && nzf > 1) { pi = p; p += (size_t)nzf * B * Ci; jobs[nj++] = SumJob{gisc, pi, nzf, (int64_t)B * Ci}; }
         dim3 grid((unsigned)te::cdiv(Ci, RTHREADS), (unsigned)B, (unsigned)nzf);
-        wgrad_reduce_few_kernel<<<grid, RTHREADS, 0, s>>>(gw, gisc, slabs, w, wscale, isc, B, S, Co, Ci);
+        wgrad_reduce_few_kernel<<<grid, RTHREADS, 0, s>>>(pw, pi, slabs, w, wscale, isc, B, S, Co, Ci);
+        launch_sum_parts(jobs, nj, s);
         return te::launch_status("te_wgrad_reduce_f32");
     }
+    float* p = ws;
     if (gw) {
-        const int64_t E = (int64_t)Co * Ci * taps;
-        const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(gw)) & 15) == 0;
+        const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(gw) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
         const int64_t blocks = te::cdiv(vec ? E / 4 : E, RTHREADS);
-        int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * S, te::cdiv(2 * te::kNumCU, blocks)));
-        if (nchunk > 1) {
-            hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * E, s);
-            if (e != hipSuccess) return te::fail((int)e, "te_wgrad_reduce_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-        }
-        if (vec) wgrad_reduce_w4_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S,
+        const int nchunk = reduce_w_nchunk(B, S, E, vec);
+        float* pw = gw;
+        if (nchunk > 1) { pw = p; p += (size_t)nchunk * E; jobs[nj++] = SumJob{gw, pw, nchunk, E}; }
+        if (vec) wgrad_reduce_w4_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(pw, slabs, wscale, isc, osc, B, S,
                                                                                                     Co, Ci, taps, nchunk);
-        else wgrad_reduce_w_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(gw, slabs, wscale, isc, osc, B, S, Co,
+        else wgrad_reduce_w_kernel<<<dim3((unsigned)blocks, (unsigned)nchunk), RTHREADS, 0, s>>>(pw, slabs, wscale, isc, osc, B, S, Co,
                                                                                                Ci, taps, nchunk);
     }
     if (gisc || gosc) {
-        dim3 grid((unsigned)B, (unsigned)te::cdiv(Co, COB));
-        if (taps == 9) wgrad_reduce_sc_kernel<9><<<grid, RTHREADS, 0, s>>>(gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
-        else wgrad_reduce_sc_kernel<1><<<grid, RTHREADS, 0, s>>>(gisc, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        const int nY = (int)te::cdiv(Co, COB);
+        float* pi = gisc;
+        if (gisc && nY > 1) { pi = p; p += (size_t)nY * B * Ci; jobs[nj++] = SumJob{gisc, pi, nY, (int64_t)B * Ci}; }
+        dim3 grid((unsigned)B, (unsigned)nY);
+        if (taps == 9) wgrad_reduce_sc_kernel<9><<<grid, RTHREADS, 0, s>>>(pi, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        else wgrad_reduce_sc_kernel<1><<<grid, RTHREADS, 0, s>>>(pi, gosc, slabs, w, wscale, isc, osc, B, S, Co, Ci);
     }
+    launch_sum_parts(jobs, nj, s);
     return te::launch_status("te_wgrad_reduce_f32");
 }
