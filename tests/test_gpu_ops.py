@@ -436,6 +436,7 @@ LINEAR_CASES = [   # rows-shape, K, N, act, residual, bias
     ((32,), 8192, 512, 'lrelu', False, True),      # discriminator final_linear[0] (:831-834): split-K form, 8 chunks
     ((5,), 2304, 40, None, False, True),           # split-K with a ragged tile (3 chunks of 768)
     ((16, 512), 16, 14, None, False, True),        # adjust_style at batch 16: dW reduces over 8192 rows (split-K form)
+    ((2055,), 24, 20, None, False, True),          # dW over a row count that does not split evenly: 2 chunks of 1024 + a 7-row tail
 ]
 
 
