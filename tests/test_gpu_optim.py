@@ -146,13 +146,19 @@ def test_refresh_packed_weights_equals_single_packs():
         packed(views[2], _lib.PACK_SWAP, 1.5)
         assert len(cache) == 9 and refresh_packed_weights(cache) == 0          # nothing stale yet
         held = {k: v[1] for k, v in cache.items()}
+        before = {k: v.clone() for k, v in held.items()}
         with torch.no_grad():
             for p in ps[:3]:
                 p.add_(torch.randn_like(p))                                    # an optimiser step (bumps the version counters)
         assert refresh_packed_weights(cache) == 7                              # ps[3]'s two layouts are not touched
+        touched = {p.data_ptr() for p in ps[:3]}
         for key, (ver, wp, base) in cache.items():
-            assert wp is held[key] and ver == base._version                    # rewritten in place, entry current again
+            assert ver == base._version                                        # entry current again
+            # a stale layout is re-derived into a NEW buffer (the old one may still be held by an autograd node, ADVICE
+            # round 3) and the old buffer keeps the old weights; an untouched parameter keeps its buffer
+            assert (wp is not held[key]) == (base.data_ptr() in touched), key
+            assert torch.equal(held[key], before[key]), key
             want = _lib.conv_pack(base.detach().view(key[1]), key[2], key[3])
             assert torch.equal(wp, want), key
         hits = packed(views[0], _lib.PACK_FWD, 0.37)
-        assert hits is held[(views[0].data_ptr(), tuple(views[0].shape), _lib.PACK_FWD, 0.37)]
+        assert hits is cache[(views[0].data_ptr(), tuple(views[0].shape), _lib.PACK_FWD, 0.37)][1]

@@ -32,9 +32,15 @@ def _gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha):
     """alpha * A[I,K] B[K,J] through the strided small-GEMM kernel (split-K form for wide reductions)"""
     if K > MAX_K:
         S = _ksplit(K)
-        if not S:
-            raise RuntimeError(f'te_hip: reduction of {K} does not split into chunks of <= {MAX_K} that are multiples of 8')
-        return _lib.small_gemm_splitk(I, J, K, S, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
+        if S:
+            return _lib.small_gemm_splitk(I, J, K, S, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
+        # a reduction that does not split evenly: whole 1024-wide chunks through the split-K form, the tail (< 1024) through the
+        # single-pass kernel with the first part as its residual
+        K1 = (K // MAX_K) * MAX_K
+        c = _lib.small_gemm_splitk(I, J, K1, K1 // MAX_K, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
+        at = a.as_strided((1,), (1,), a.storage_offset() + K1 * sak)          # (operands are addressed from their first element)
+        bt = b.as_strided((1,), (1,), b.storage_offset() + K1 * sbk)
+        return _lib.small_gemm(I, J, K - K1, at, sai, sak, bt, sbk, sbj, residual=c, alpha=alpha)[0]
     return _lib.small_gemm(I, J, K, a, sai, sak, b, sbk, sbj, alpha=alpha)[0]
 
 
