@@ -134,16 +134,41 @@ def emulated_conv_ops(monkeypatch):
         return {'3x3': (B, w.shape[1], H, W), '1x1': (B, w.shape[1], H, W), 'up': (B, w.shape[1], (H - 1) // 2, (W - 1) // 2),
                 'down': (B, w.shape[1], 2 * H + 1, 2 * W + 1)}[kind]
 
+    ch = lambda t, sc: t if sc is None else t * sc[:, :, None, None]
+
     def fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0, with_bwd_pack=False):
-        assert isc is None and osc is None and bias is None and not act and not with_bwd_pack
-        return _conv_ref(x, w * wscale, kind)
+        """te_conv_f32's contract: osc * conv(isc * x, wscale w) (style scale at staging, demodulation in the epilogue)"""
+        assert bias is None and not act and not with_bwd_pack
+        return ch(_conv_ref(ch(x, isc), w * wscale, kind), osc)
 
     def dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
-        assert isc is None and osc is None
+        """isc scales the channels of g (shaped like the convolution's output), osc the channels of the result"""
         with torch.enable_grad():
             x0 = torch.zeros(in_shape(g, w, kind), dtype=g.dtype, requires_grad=True)
-            gx, = torch.autograd.grad(_conv_ref(x0, w.detach() * wscale, kind), x0, g.detach())
-        return gx
+            gx, = torch.autograd.grad(_conv_ref(x0, w.detach() * wscale, kind), x0, ch(g.detach(), isc))
+        return ch(gx, osc)
+
+    def wgrad_raw(g, x, kind, group=False):
+        """per-sample correlation slabs [B, 1, Co, Ci, taps] of the UNMODULATED tensors"""
+        assert kind != 'down'
+        ks = 1 if kind == '1x1' else 3
+        out = []
+        for b in range(g.shape[0]):
+            with torch.enable_grad():
+                w0 = torch.zeros(g.shape[1], x.shape[1], ks, ks, dtype=g.dtype, requires_grad=True)
+                gw, = torch.autograd.grad(_conv_ref(x[b:b + 1].detach(), w0, kind), w0, g[b:b + 1].detach())
+            out.append(gw.reshape(g.shape[1], x.shape[1], ks * ks))
+        return torch.stack(out).unsqueeze(1)
+
+    def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc=False, want_osc=False):
+        """te_wgrad_reduce_f32's dW: wscale * sum_{b,s} osc[b,co] isc[b,ci] slab"""
+        assert want_w and not want_isc and not want_osc
+        sl = slabs.sum(1)
+        if isc is not None:
+            sl = sl * isc[:, None, :, None]
+        if osc is not None:
+            sl = sl * osc[:, :, None, None]
+        return wscale * sl.sum(0), None, None
 
     def wgrad_plain(gy, x, kind, ksize, wscale):
         with torch.enable_grad():
@@ -165,6 +190,9 @@ def emulated_conv_ops(monkeypatch):
     monkeypatch.setattr(modconv, '_fwd_raw', fwd_raw)
     monkeypatch.setattr(modconv, '_dgrad_raw', dgrad_raw)
     monkeypatch.setattr(modconv, '_wgrad_plain', wgrad_plain)
+    monkeypatch.setattr(modconv, '_wgrad_raw', wgrad_raw)
+    monkeypatch.setattr(_lib, 'wgrad_reduce', wgrad_reduce)
+    monkeypatch.setattr(_lib, 'rgb_supported', lambda M, K, HW: False)
     monkeypatch.setattr(_lib, 'chan_scale', lambda x, s: x * s.reshape(*s.shape, *([1] * (x.dim() - 2))))
     monkeypatch.setattr(_lib, 'chan_dot', lambda a, b: (a * b).flatten(2).sum(2))
     monkeypatch.setattr(_lib, 'bias_act', bias_act)
@@ -188,12 +216,52 @@ def test_conv_trio_algebra(emulated_conv_ops, kind):
         assert torch.allclose(a, b, rtol=1e-10, atol=1e-12), name
 
 
+@pytest.mark.parametrize('kind,demod', [('3x3', True), ('up', True), ('1x1', False), ('1x1', True)])
+def test_closed_modulated_conv_family_algebra(emulated_conv_ops, monkeypatch, kind, demod):
+    """the five-linear family of the modulated convolution (op/modconv.py::_MCFwd / _MCDgrad / _MCWgrad: style scale and
+    demodulation INSIDE the convolution calls, the scale gradients as channel dots divided by the scale) against the broadcast
+    expression: value, all four first gradients (recorded), and the gradient of a scalar of THOSE w.r.t. every input - which walks
+    every backward branch of the three Functions (ModulatedConv2d.forward, model_spatial_query.py:296-337; ToRGB without
+    demodulation :416-425)"""
+    monkeypatch.setattr(modconv, '_closed_ok', lambda x: True)
+    torch.manual_seed(6)
+    B, Ci, Co = 2, 3, 4
+    ks = 1 if kind == '1x1' else 3
+    x = torch.randn(B, Ci, 4, 5, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, ks, ks, dtype=torch.float64, requires_grad=True)
+    s = (1 + 0.3 * torch.randn(B, Ci, dtype=torch.float64)).requires_grad_(True)
+    d = (1 + 0.3 * torch.randn(B, Co, dtype=torch.float64)).requires_grad_(True) if demod else None
+    ins = (x, w, s) + ((d,) if demod else ())
+
+    def plain(x, w, s, d=None):
+        y = _conv_ref(x * s[:, :, None, None], w * 0.21, kind)
+        return y if d is None else y * d[:, :, None, None]
+
+    def ours(x, w, s, d=None):
+        return modconv.modconv_closed(x, w, s, d, kind, 0.21)
+    gy = torch.randn_like(plain(*ins))
+    want = _second_order(plain, ins, gy)
+    got = _second_order(ours, ins, gy)
+    names = ['y'] + [f'g{i}' for i in range(len(ins))] + [f'G{i}' for i in range(len(ins))]
+    for name, a, b in zip(names, got, want):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-11), name
+    # an exactly-zero style scale does not poison the scale gradient (the division sees the smallest normal number instead)
+    s0 = s.detach().clone()
+    s0[0, 1] = 0.0
+    s0.requires_grad_(True)
+    y = ours(x, w, s0, d) if demod else ours(x, w, s0)
+    gs, = torch.autograd.grad(y, s0, gy)
+    assert torch.isfinite(gs).all()
+
+
 @pytest.mark.parametrize('kind,act', [('3x3', True), ('up', False), ('down', True), ('1x1', 1.0)])
-def test_modulated_conv_composite_algebra(emulated_conv_ops, kind, act):
+@pytest.mark.parametrize('closed', [False, True])
+def test_modulated_conv_composite_algebra(emulated_conv_ops, monkeypatch, kind, act, closed):
     """the any-order composite of the modulated convolution (style scale -> trio -> demodulation scale -> bias + leaky ReLU,
     op/modconv.py::_composite) against the broadcast expression, through a path-length-style probe: gradients w.r.t. the input
     and the style with create_graph, then the gradient of their squares w.r.t. EVERY input (model_spatial_query.py:296-337 +
     train_spatial_query.py:92-105)"""
+    monkeypatch.setattr(modconv, '_closed_ok', lambda x: closed)      # both routes of _composite: closed family / chan_scale + trio
     torch.manual_seed(4)
     B, Ci, Co = 2, 3, 4
     ks = 1 if kind == '1x1' else 3

@@ -434,9 +434,128 @@ def conv_core(x, w, kind='3x3', wscale=1.0):
     return _ConvFwd.apply(x, w, kind, float(wscale))
 
 
+# The MODULATED convolution y = d (.) conv(s (.) x, wscale w) as a family closed under differentiation.  It is one
+# five-linear form  P(gy, x, w, s, d) = sum gy[b,co,p (+) t] x[b,ci,p] w[co,ci,t] s[b,ci] d[b,co]  seen from its five
+# arguments: y = dP/dgy, the data gradient dP/dx, the weight gradient dP/dw, and the two scale gradients
+#     dP/ds[b,ci] = sum_p x * (dP/dx) / s ,      dP/dd[b,co] = sum_p gy * (dP/dgy) / d
+# (the sums are te_chan_dot_f32 passes, the divisions [B,C]-sized).  The derivative of dP/da with respect to b, contracted with
+# a cotangent c, is dP/db with a := c - so the three Functions below name each other in their backwards and anything built on
+# them differentiates to any order.  Unlike the chan_scale -> conv_core -> chan_scale composite of rounds 2-3, the style scale
+# and the demodulation ride INSIDE the convolution kernels (staging / epilogue, the arguments the fused first-order path has
+# always used): per layer and order, three activation-sized elementwise passes and their autograd accumulations disappear
+# (path-length step: 161 chan_scale launches and ~5 ms per step).
+def _nonzero(s):
+    """the scale gradients divide by the scale: an exact zero (measure zero, but representable) becomes the smallest normal number"""
+    return torch.where(s == 0, torch.full_like(s, 1.2e-38), s)
+
+
+def _rgb_ok(w, d, x_like, kind):
+    return (kind == '1x1' and d is None and w.shape[0] == 3
+            and _lib.rgb_supported(3, w.shape[1], x_like.shape[2] * x_like.shape[3]))
+
+
+def _chan_dot(a, b):
+    from .chanscale import _ChanDot
+    return _ChanDot.apply(a.contiguous(), b.contiguous())
+
+
+class _MCFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, s, d, kind, wscale):
+        ctx.kind, ctx.wscale = kind, wscale
+        ctx.graph = current_graph()
+        keep_cache(ctx)
+        if _rgb_ok(w, d, x, kind):          # ToRGB: HBM-bound streaming kernel
+            y = _lib.rgb_fwd(x, w.reshape(3, w.shape[1]), s.contiguous(), None, wscale)
+        else:
+            y = _fwd_raw(x, w, kind, s.contiguous(), None if d is None else d.contiguous(), None, 0, wscale)
+        ctx.save_for_backward(x, w, s, d, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, d, y = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        skip_w = ctx.graph.skip_w or _DEFAULT_GRAPH.skip_w
+        with cache_of(ctx):
+            gx = _MCDgrad.apply(gy, w, s, d, ctx.kind, ctx.wscale) if (need[0] or need[2]) else None
+            gw = _MCWgrad.apply(gy, x, s, d, ctx.kind, w.shape[2], ctx.wscale) if (need[1] and not skip_w) else None
+        gs = _chan_dot(gx, x) / s if need[2] else None
+        gd = _chan_dot(gy, y) / d if (d is not None and need[3]) else None
+        return (gx if need[0] else None), gw, gs, gd, None, None
+
+
+class _MCDgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w, s, d, kind, wscale):       # s (.) dgrad(d (.) gy, wscale w), shaped like the convolution's input
+        ctx.kind, ctx.wscale = kind, wscale
+        keep_cache(ctx)
+        if _rgb_ok(w, d, gy, kind):
+            gx = _lib.rgb_dgrad(gy, w.reshape(3, w.shape[1]), s.contiguous(), w.shape[1], wscale)
+        else:
+            gx = _dgrad_raw(gy, w, kind, isc=None if d is None else d.contiguous(), osc=s.contiguous(), wscale=wscale)
+        ctx.save_for_backward(gy, w, s, d, gx)
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w, s, d, gx = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        with cache_of(ctx):
+            y2 = _MCFwd.apply(ggx, w, s, d, ctx.kind, ctx.wscale) if (need[0] or (d is not None and need[3])) else None
+            gw = _MCWgrad.apply(gy, ggx, s, d, ctx.kind, w.shape[2], ctx.wscale) if need[1] else None
+        gs = _chan_dot(ggx, gx) / s if need[2] else None
+        gd = _chan_dot(gy, y2) / d if (d is not None and need[3]) else None
+        return (y2 if need[0] else None), gw, gs, gd, None, None
+
+
+class _MCWgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, x, s, d, kind, ksize, wscale):    # wscale * sum_b d_b s_b (correlation slab of sample b)  [Co,Ci,k,k]
+        ctx.kind, ctx.wscale = kind, wscale
+        keep_cache(ctx)
+        ctx.save_for_backward(gy, x, s, d)
+        Co, Ci = gy.shape[1], x.shape[1]
+        gyc, xc = gy.contiguous(), x.contiguous()
+        if kind == '1x1' and d is None and Co == 3 and _lib.rgb_supported(3, Ci, x.shape[2] * x.shape[3]):
+            slabs = _lib.rgb_wgrad_slabs(gyc, xc)
+        else:
+            slabs = _wgrad_raw(gyc, xc, kind)
+        gw, _, _ = _lib.wgrad_reduce(slabs, slabs[0, 0], wscale, s.contiguous(), None if d is None else d.contiguous(), want_w=True)
+        return gw.reshape(Co, Ci, ksize, ksize)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x, s, d = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        with cache_of(ctx):
+            y2 = _MCFwd.apply(x, ggw, s, d, ctx.kind, ctx.wscale) if (need[0] or (d is not None and need[3])) else None
+            gx = _MCDgrad.apply(gy, ggw, s, d, ctx.kind, ctx.wscale) if (need[1] or need[2]) else None
+        gs = _chan_dot(gx, x) / s if need[2] else None
+        gd = _chan_dot(gy, y2) / d if (d is not None and need[3]) else None
+        return (y2 if need[0] else None), (gx if need[1] else None), gs, gd, None, None, None
+
+
+def _closed_ok(x):
+    return x.is_cuda and x.dtype == torch.float32
+
+
+USE_CLOSED_MODCONV = True      # False: the chan_scale -> conv_core -> chan_scale composite of rounds 2-3 (A/B measurements)
+
+
+def modconv_closed(x, w, isc, osc, kind='3x3', wscale=1.0):
+    """osc (.) conv(isc (.) x, wscale * w), differentiable to any order with the scales inside the convolution kernels"""
+    return _MCFwd.apply(x, w, _nonzero(isc), osc, kind, float(wscale))
+
+
 def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
     """The same function as the fused kernel, built from any-order differentiable pieces (the equalised-lr constant rides
     in the weight packing of the trio: no `w * wscale` pass, no scaling pass for its gradient)."""
+    if USE_CLOSED_MODCONV and isc is not None and kind in ('3x3', 'up', '1x1') and _closed_ok(x):
+        y = modconv_closed(x, w, isc, osc, kind, wscale)
+        if act:
+            return fused_leaky_relu(y, bias, 0.2, _act_gain(act))
+        return y if bias is None else y + bias[None, :, None, None]
     if isc is not None:
         x = chan_scale(x, isc)
     y = conv_core(x, w, kind, wscale)
