@@ -334,7 +334,10 @@ def test_modulated_conv2d_module_golden(golden, name):
     for got, key in zip(g2, ('pl_gx', 'pl_gw', 'pl_gmw', 'pl_gmb')):
         want = g[f'{name}.{key}']
         if float(want.abs().max()) == 0:
-            assert got is None or float(got.abs().max()) < 1e-6
+            # analytically zero (without demodulation y is linear in the style scale, so |dy/ds|^2 does not depend on it): the closed
+            # family forms the scale gradient as a channel dot divided by the scale, whose s-derivative is two terms of size
+            # ~2 pl / s that cancel to round-off
+            assert got is None or float(got.abs().max()) < 1e-6 * max(1.0, float(pl))
         else:
             assert rel_err(got, want) < 5e-4, key
 
