@@ -24,9 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int QCH = 64;         // channels of the shifted operand per block (2 waves)
 // NWP waves along the plain operand's channels (4 -> 512 threads, 128 x 64 tile; 2 -> 256 threads, 64 x 64 tile)
 constexpr unsigned OOB = 0x80000000u;   // buffer offset beyond num_records: the load returns 0
-#ifndef TE_WGRAD_XCD        // build knob for A/B measurements: 0 = chunk-major ids, as the 3-D grid had them
-#define TE_WGRAD_XCD 1
-#endif
 
 struct WgArgs {
     float* slabs;
@@ -45,7 +42,6 @@ struct WgArgs {
     unsigned magic_q8, magic_q2;   // ceil(2^32 / (QH*8)), ceil(2^32 / (QH*2))
     unsigned magic_q16, magic_q1;  // ceil(2^32 / (QH*16)), ceil(2^32 / QH)   (transposed kind: 65-wide rows = 16 x 16 B + 1)
     int vec;                       // 16-byte staging path: TW == 32 and W % 32 == 0 (rows of both operands 16 B aligned)
-    int nchunks, ny, nyz;          // grid decomposition: (sample group, chunk) ids, channel blocks along co, channel blocks in all
 };
 
 template <int KIND> struct WK;
@@ -90,21 +86,11 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const int l31 = lane & 31, half = lane >> 5;
     const int wp = wid >> 1, wq = wid & 1;          // wave -> (plain channel block, shifted channel block)
 
-    // ---- block -> ((sample group, chunk), channel block).  1-D grid; consecutive workgroup ids go round-robin over the 8 XCDs
-    // (each with its own L2), so the j-th block of XCD x takes chunk (j / nyz) * 8 + x and channel block j % nyz: the
-    // channel blocks of a chunk - which all read the same cells of both operands - run on ONE XCD back to back and meet in
-    // its L2 (with the plain 3-D grid they were a whole grid row apart: every operand tile came from HBM once per channel block)
-#if TE_WGRAD_XCD
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int chunk_id = (jx / p.nyz) * 8 + xcd, yz = jx % p.nyz;
-    if (chunk_id >= p.nchunks) return;                  // (grid padded to a multiple of 8 chunks; block-uniform)
-#else
-    const int chunk_id = blockIdx.x % p.nchunks, yz = blockIdx.x / p.nchunks;
-#endif
-    const int by = yz % p.ny, bz = yz / p.ny;
-    const int s_chunk = chunk_id % p.S, bgrp = chunk_id / p.S, b = bgrp * p.NB;     // b: first sample of the group
+    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;     // b: first sample of the group
     // rows of the result = co (A operand = g), cols = ci (B operand = x)
-    const int co0 = by * (GSHIFT ? QCH : PCH), ci0 = bz * (GSHIFT ? PCH : QCH);
+    // (an XCD-aware 1-D block order that runs the channel blocks of a chunk back to back on one XCD was measured in round 4:
+    // same time, same FETCH_SIZE - profiles/experiments/r04_wgrad_xcd_ab.log - and dropped)
+    const int co0 = blockIdx.y * (GSHIFT ? QCH : PCH), ci0 = blockIdx.z * (GSHIFT ? PCH : QCH);
 
     const float* gP = p.g + (size_t)b * p.Co * p.Hg * p.Wg;
     const float* xP = p.x + (size_t)b * p.Ci * p.Hx * p.Wx;
@@ -391,7 +377,7 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     }
 #ifdef TE_CONV_PROF
     {
-        const int lin = blockIdx.x;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if (lane == 0 && lin * (NTHREADS / 64) + wid < 8192) {
             unsigned long long* d = te_wgrad_prof_buf + ((size_t)lin * (NTHREADS / 64) + wid) * 8;
             for (int i = 0; i < 6; ++i) d[i] = pc[i];
@@ -478,18 +464,15 @@ bool fill_geometry(WgArgs& a) {
 inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 
 template <int KIND, int NWP>
-void launch_wgrad_t(WgArgs a, hipStream_t s) {
+void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
     size_t lds = ((KIND == TE_CONV_1X1 || NWP == 2) ? 1 : 2) * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);   // 8-wave 3x3 / T2: two operand images
     if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);
-    a.nchunks = a.B / a.NB * a.S;
-    a.ny = (int)te::cdiv(a.Co, GSHIFT ? QCH : PCH);
-    a.nyz = a.ny * (int)te::cdiv(a.Ci, GSHIFT ? PCH : QCH);
-    const int64_t nblocks = (TE_WGRAD_XCD ? (int64_t)te::cdiv(a.nchunks, 8) * 8 : (int64_t)a.nchunks) * a.nyz;
-    wgrad_mfma_kernel<KIND, NWP><<<dim3((unsigned)nblocks), NWP * 128, lds, s>>>(a);
+    dim3 grid((unsigned)(a.B / a.NB * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
+    wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);
 }
 
 template <int KIND>
@@ -878,7 +861,8 @@ static int wgrad_launch(float* slabs, const float* g, const float* x, int kind, 
                         te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && H > 0 && W > 0 && S > 0, TE_ERR_SHAPE, "te_wgrad_f32: bad dims");
-    TE_REQUIRE(((int64_t)B * S + 8) * te::cdiv(Co, 64) * te::cdiv(Ci, 64) <= 0x7FFFFFFF, TE_ERR_SHAPE, "te_wgrad_f32: grid too large");
+    TE_REQUIRE((int64_t)B * S <= 0x7FFFFFFF && te::cdiv(Co, QCH) <= 65535 && te::cdiv(Ci, QCH) <= 65535, TE_ERR_SHAPE,
+               "te_wgrad_f32: grid too large");
     WgArgs a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB;
     a.Hx = H; a.Wx = W;
