@@ -73,6 +73,27 @@ def accumulate(model1, model2, decay=0.999):                                 # :
     MultiTensorEMA(model1, model2).update(decay)
 
 
+def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_optim=None, d_optim=None, device=None):
+    """The reference's restore (train_spatial_query.py:475-492; test_spatial_query.py:285 for a 'g_ema'-only file) on any set of
+    modules / optimisers: `ckpt` is a path or a loaded dictionary in the layout :361-371 writes.  -> the start iteration parsed
+    from the file name ('790000.pt' -> 790000), or None."""
+    import os
+    start = None
+    if isinstance(ckpt, (str, bytes, os.PathLike)):
+        try:
+            start = int(os.path.splitext(os.path.basename(ckpt))[0])
+        except ValueError:
+            pass
+        ckpt = torch.load(ckpt, map_location=device)
+    g_ema.load_state_dict(ckpt['g_ema'])
+    if 'g' in ckpt and generator is not None:
+        generator.load_state_dict(ckpt['g'])
+        discriminator.load_state_dict(ckpt['d'])
+        g_optim.load_state_dict(ckpt['g_optim'])
+        d_optim.load_state_dict(ckpt['d_optim'])
+    return start
+
+
 class RandomSampler:
     """Random draws of one iteration; tests substitute a deterministic one."""
 
@@ -244,21 +265,7 @@ class TrainStep:
     def load_checkpoint(self, ckpt):
         """`ckpt`: a path or an already loaded dictionary.  Returns the start iteration parsed from the file name (:481-484),
         or None.  A published inference checkpoint that only holds 'g_ema' loads into the EMA generator alone."""
-        import os
-        start = None
-        if isinstance(ckpt, (str, bytes, os.PathLike)):
-            try:
-                start = int(os.path.splitext(os.path.basename(ckpt))[0])
-            except ValueError:
-                pass
-            ckpt = torch.load(ckpt, map_location=self.device)
-        self.g_ema.load_state_dict(ckpt['g_ema'])
-        if 'g' in ckpt:
-            self.generator.load_state_dict(ckpt['g'])
-            self.discriminator.load_state_dict(ckpt['d'])
-            self.g_optim.load_state_dict(ckpt['g_optim'])
-            self.d_optim.load_state_dict(ckpt['d_optim'])
-        return start
+        return load_checkpoint_into(ckpt, self.g_ema, self.generator, self.discriminator, self.g_optim, self.d_optim, self.device)
 
     def iteration(self, i, real_img):
         """One iteration `i` of the reference loop on a batch of real images already on the device."""
