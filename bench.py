@@ -616,13 +616,20 @@ def comm_preflight(args, backend, world, rank, local_rank, dev):
     import torch.distributed as dist
     info = {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'world_size': world,
             'env': {k: os.environ.get(k) for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'NCCL_DEBUG', 'NCCL_SOCKET_IFNAME', 'MASTER_ADDR',
-                                                    'MASTER_PORT', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES')}}
+                                                    'MASTER_PORT', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'OMP_NUM_THREADS')}}
     try:
         info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
     except Exception as e:
         info['rccl_version'] = f'unavailable ({type(e).__name__})'
     base = {'metric': METRIC, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+    banner = None
+    if backend == 'nccl':
+        # RCCL's own start-up banner (library build, HIP / ROCm versions) is evidence worth keeping, but with NCCL_DEBUG set it goes
+        # to STDOUT, where rank 0 must print exactly one JSON line: send it to a per-process file and quote it in `comm`
+        os.environ.setdefault('NCCL_DEBUG', 'VERSION')
+        banner = f'/tmp/te_rccl_banner.{os.getpid()}.log'
+        os.environ['NCCL_DEBUG_FILE'] = banner
     dog = Watchdog(base, rank, info)
     limit = float(os.environ.get('TE_BENCH_COMM_TIMEOUT', '60'))
     try:
@@ -645,6 +652,8 @@ def comm_preflight(args, backend, world, rank, local_rank, dev):
         allv = [None] * world
         dist.all_gather_object(allv, mine)
         info['ranks'] = allv
+        if banner and os.path.exists(banner):
+            info['rccl_banner'] = open(banner).read()[:600]
         # from here on only a coarse limit for the whole run (a rank that dies or diverges mid-run leaves the others waiting
         # in a collective): the record then says where instead of the driver's limit killing a silent job
         dog.arm('the benchmark run after a successful preflight', float(os.environ.get('TE_BENCH_RUN_TIMEOUT', '1500')))
@@ -673,7 +682,14 @@ def main():
     dev = torch.device('cuda', local_rank)
     backend = None
     comm_info = watchdog = None
-    if world > 1:
+    # TE_BENCH_FORCE_DIST=1 (rehearsal on a 1-GPU box, never set by the driver): run the multi-rank code path - RCCL process
+    # group, preflight, hook-driven bucketed exchange, `comm` object - with a world of ONE rank
+    dist_on = world > 1 or os.environ.get('TE_BENCH_FORCE_DIST') == '1'
+    if os.environ.get('TE_BENCH_FORCE_DIST') == '1':
+        os.environ['TE_GRADSYNC_FORCE'] = '1'
+        for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', '29577'), ('RANK', '0'), ('WORLD_SIZE', '1')):
+            os.environ.setdefault(k, v)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = 'gloo' if share else 'nccl'                       # "nccl" == RCCL on ROCm
@@ -709,7 +725,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline_generator(size)
             print(json.dumps(out), flush=True)
-        if world > 1:
+        if dist_on:
             watchdog.disarm()
             torch.distributed.destroy_process_group()
         return
@@ -725,7 +741,7 @@ def main():
 
     for i in range(args.warmup):                                   # iteration 0 fires both lazy regularisers
         ts.iteration(i, reals[i % 4])
-    if world > 1:
+    if dist_on:
         # GradSync learns the used-parameter mask of every call kind during its first two calls (a tiny MAX all-reduce with a
         # host read-back); make sure no kind is still learning inside the timed window
         for _ in range(2):
@@ -761,7 +777,7 @@ def main():
     if cw:
         out['substeps']['cadence_weighted_images_per_sec_per_gpu'] = 1e3 * B / cw
 
-    if world > 1:
+    if dist_on:
         # ---- comm evidence, outside the timed region
         import torch.distributed as dist
         ts.g_step()                                                # leaves averaged G grads in place
@@ -819,7 +835,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline_train(size)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         watchdog.disarm()
         torch.distributed.destroy_process_group()
 
