@@ -623,13 +623,14 @@ def comm_preflight(args, backend, world, rank, local_rank, dev):
         info['rccl_version'] = f'unavailable ({type(e).__name__})'
     base = {'metric': METRIC, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
-    banner = None
     if backend == 'nccl':
-        # RCCL's own start-up banner (library build, HIP / ROCm versions) is evidence worth keeping, but with NCCL_DEBUG set it goes
-        # to STDOUT, where rank 0 must print exactly one JSON line: send it to a per-process file and quote it in `comm`
-        os.environ.setdefault('NCCL_DEBUG', 'VERSION')
-        banner = f'/tmp/te_rccl_banner.{os.getpid()}.log'
-        os.environ['NCCL_DEBUG_FILE'] = banner
+        # With NCCL_DEBUG=VERSION (exported on the GPU boxes) RCCL printf()s a five-line banner to STDOUT from every rank - measured
+        # in the round-4 rehearsal (profiles/r04_bench_rccl_world1_before_fix.txt): it came out AFTER the JSON line, at exit, and
+        # NCCL_DEBUG_FILE does not redirect it.  The driver wants ONE JSON line on stdout, so the banner is switched off here (the
+        # original setting is recorded in `comm.env`; the library version comes from torch.cuda.nccl.version()).
+        info['env']['NCCL_DEBUG_as_found'] = os.environ.get('NCCL_DEBUG')
+        os.environ['NCCL_DEBUG'] = os.environ.get('TE_BENCH_NCCL_DEBUG', 'WARN')
+        os.environ.setdefault('NCCL_DEBUG_FILE', f'/tmp/te_rccl_debug.{os.getpid()}.log')      # (warnings, if any, off stdout too)
     dog = Watchdog(base, rank, info)
     limit = float(os.environ.get('TE_BENCH_COMM_TIMEOUT', '60'))
     try:
@@ -652,8 +653,7 @@ def comm_preflight(args, backend, world, rank, local_rank, dev):
         allv = [None] * world
         dist.all_gather_object(allv, mine)
         info['ranks'] = allv
-        if banner and os.path.exists(banner):
-            info['rccl_banner'] = open(banner).read()[:600]
+        info['hip_version'] = getattr(torch.version, 'hip', None)
         # from here on only a coarse limit for the whole run (a rank that dies or diverges mid-run leaves the others waiting
         # in a collective): the record then says where instead of the driver's limit killing a silent job
         dog.arm('the benchmark run after a successful preflight', float(os.environ.get('TE_BENCH_RUN_TIMEOUT', '1500')))
@@ -724,7 +724,7 @@ def main():
                     attach_counters(roof, live=not args.no_pmc)
             if world == 1 and not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline_generator(size)
-            print(json.dumps(out), flush=True)
+        final_line(out if rank == 0 else None, rank, world, dist_on)
         if dist_on:
             watchdog.disarm()
             torch.distributed.destroy_process_group()
@@ -833,11 +833,25 @@ def main():
         attach_counters(out['roofline'], live=not args.no_pmc)       # counters of THIS run, outside the timed region
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_train(size)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    final_line(out, rank, world, dist_on)
     if dist_on:
         watchdog.disarm()
         torch.distributed.destroy_process_group()
+
+
+def final_line(out, rank, world, dist_on):
+    """rank 0's ONE JSON line, as the LAST thing any rank writes to stdout: whatever native libraries left in the C stdio
+    buffers of the ranks is flushed first, then a barrier, then the line"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist_on and world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def _slim(roof):
