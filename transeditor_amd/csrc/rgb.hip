@@ -86,64 +86,88 @@ __global__ __launch_bounds__(256) void rgb_dgrad_kernel(float* __restrict__ gx, 
     }
 }
 
-// one block per (sample, pixel chunk); x tile [K][TP] staged in LDS (row stride TP+1: conflict-free column reads),
-// thread k accumulates its 3 dot products over the chunk's pixels
+// one block per (sample, pixel chunk); x tile [K][TPX] staged in LDS (row stride TPX + 1: conflict-free column reads).
+// Round 4: the tile width scales with the channel count (K * TPX ~ 8192 elements: 32 pixels at 256+ channels, 256 at 32) and
+// ALL 256 threads multiply: 256 / K2 threads share a channel (K2 = K rounded up to a power of two), each takes every
+// (256 / K2)-th pixel of the tile, and their partial dot products meet through LDS in a fixed order at the end.  Before, thread k
+// owned channel k alone: at the 32 / 64-channel layers of the FFHQ-1024 tail 1/8 - 1/4 of the block computed, behind a barrier
+// pair every 32 pixels (1.9 TB/s at 32 channels @1024^2; 3.9 at 128 channels @256^2).
 // SUM: a 4th slab row holds sum_p x[b,k,p] (the bias gradient of the from-RGB stem comes out of the same pass over x)
-constexpr int TP = 32;
+inline int rgb_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+inline int rgb_tile_px(int K) { return std::max(32, std::min(256, 8192 / rgb_pow2(K))); }
+
 template <bool SUM>
 __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slabs, const float* __restrict__ g,
-                                                        const float* __restrict__ x, int K, int HW, int S) {
+                                                        const float* __restrict__ x, int K, int HW, int S, int TPX, int lgTPX, int K2) {
     constexpr int NROW = SUM ? NOUT + 1 : NOUT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xl = smem;                      // [K][TP + 1]
-    float* gl = smem + K * (TP + 1);       // [NOUT][TP]
+    float* xl = smem;                      // [K][TPX + 1]
+    float* gl = smem + K * (TPX + 1);      // [NOUT][TPX]
     const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    const int ntile = (HW + TP - 1) / TP;
+    const int ntile = (HW + TPX - 1) / TPX;
     const int t0 = (int)((int64_t)ntile * c / S), t1 = (int)((int64_t)ntile * (c + 1) / S);
     const float* xb = x + (size_t)b * K * HW;
     const float* gb = g + (size_t)b * NOUT * HW;
+    // compute-phase geometry: K2 <= 256: `parts` threads per channel; K2 == 512: every thread owns two channels
+    const int parts = K2 >= 256 ? 1 : 256 / K2;
+    const int kk = K2 >= 256 ? tid : (tid & (K2 - 1)), part = K2 >= 256 ? 0 : tid / K2;
+    const int nh = K2 > 256 ? 2 : 1;
     float acc[2][NOUT + 1] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int tl = t0; tl < t1; ++tl) {
-        const int p0 = tl * TP;
+        const int p0 = tl * TPX;
         __syncthreads();
-        for (int e0 = 0; e0 < K * TP; e0 += 256 * 8) {        // 8 loads in flight per lane, then the LDS writes
+        for (int e0 = 0; e0 < K * TPX; e0 += 256 * 8) {        // 8 loads in flight per lane, then the LDS writes
             float st[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int e = e0 + tid + 256 * j, k = e / TP, pp = e - k * TP;
-                const bool ok = e < K * TP && p0 + pp < HW;
+                const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
+                const bool ok = e < K * TPX && p0 + pp < HW;
                 const float v = xb[ok ? (size_t)k * HW + p0 + pp : 0];
                 st[j] = ok ? v : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int e = e0 + tid + 256 * j, k = e / TP, pp = e - k * TP;
-                if (e < K * TP) xl[k * (TP + 1) + pp] = st[j];
+                const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
+                if (e < K * TPX) xl[k * (TPX + 1) + pp] = st[j];
             }
         }
-        if (tid < NOUT * TP) {
-            const int o = tid / TP, pp = tid - o * TP;
-            gl[tid] = (p0 + pp < HW) ? gb[(size_t)o * HW + p0 + pp] : 0.f;
+        for (int e = tid; e < NOUT * TPX; e += 256) {
+            const int o = e >> lgTPX, pp = e & (TPX - 1);
+            gl[e] = (p0 + pp < HW) ? gb[(size_t)o * HW + p0 + pp] : 0.f;
         }
         __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = tid + 256 * h;
+        for (int h = 0; h < nh; ++h) {
+            const int k = kk + 256 * h;
             if (k < K) {
-#pragma unroll 8
-                for (int pp = 0; pp < TP; ++pp) {
-                    const float xv = xl[k * (TP + 1) + pp];
+#pragma unroll 4
+                for (int pp = part; pp < TPX; pp += parts) {
+                    const float xv = xl[k * (TPX + 1) + pp];
 #pragma unroll
-                    for (int o = 0; o < NOUT; ++o) acc[h][o] += gl[o * TP + pp] * xv;
+                    for (int o = 0; o < NOUT; ++o) acc[h][o] += gl[o * TPX + pp] * xv;
                     if (SUM) acc[h][NOUT] += xv;
                 }
             }
         }
     }
     float* sl = slabs + ((size_t)b * S + c) * NROW * K;
+    if (parts > 1) {                       // the channel's `parts` partial sums meet in LDS, added in a fixed order
+        __syncthreads();
+        float* red = smem;                 // [parts][NROW][K2]  (<= 256 * NROW floats: fits in the x tile)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int k = tid + 256 * h;
+        for (int o = 0; o < NROW; ++o) red[(part * NROW + o) * K2 + kk] = acc[0][o];
+        __syncthreads();
+        if (part == 0 && kk < K) {
+#pragma unroll
+            for (int o = 0; o < NROW; ++o) {
+                float a = 0.f;
+                for (int q = 0; q < parts; ++q) a += red[(q * NROW + o) * K2 + kk];
+                sl[o * K + kk] = a;
+            }
+        }
+        return;
+    }
+    for (int h = 0; h < nh; ++h) {
+        const int k = kk + 256 * h;
         if (k < K) {
 #pragma unroll
             for (int o = 0; o < NROW; ++o) sl[o * K + k] = acc[h][o];
@@ -187,7 +211,7 @@ extern "C" int te_rgb_expand_f32(float* out, const float* x3, const float* w, co
 
 extern "C" int te_rgb_wgrad_slab_count(int B, int K, int HW) {
     if (B <= 0 || K <= 0 || HW <= 0) return TE_ERR_SHAPE;
-    const int64_t ntile = te::cdiv(HW, TP);
+    const int64_t ntile = te::cdiv(HW, rgb_tile_px(K));
     int64_t S = te::cdiv(4 * te::kNumCU, B);
     return (int)std::max<int64_t>(1, std::min<int64_t>(S, ntile));
 }
@@ -195,21 +219,27 @@ extern "C" int te_rgb_wgrad_slab_count(int B, int K, int HW) {
 extern "C" int te_rgb_wgrad_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_rgb_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_f32: need 0 < K <= 512");
-    const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
+    const int TPX = rgb_tile_px(K), K2 = rgb_pow2(K);
+    int lg = 0;
+    while ((1 << lg) < TPX) ++lg;
+    const size_t lds = sizeof(float) * std::max<size_t>((size_t)K * (TPX + 1) + NOUT * TPX, (size_t)256 * (NOUT + 1));
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel<false>, 96 * 1024);
     dim3 grid((unsigned)S, (unsigned)B);
-    rgb_wgrad_kernel<false><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
+    rgb_wgrad_kernel<false><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S, TPX, lg, K2);
     return te::launch_status("te_rgb_wgrad_f32");
 }
 
 extern "C" int te_rgb_wgrad_sum_f32(float* slabs, const float* g, const float* x, int B, int K, int HW, int S, te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_rgb_wgrad_sum_f32: NULL pointer");
     TE_REQUIRE(B > 0 && K > 0 && K <= KMAX && HW > 0 && S > 0, TE_ERR_UNSUPPORTED, "te_rgb_wgrad_sum_f32: need 0 < K <= 512");
-    const size_t lds = sizeof(float) * ((size_t)K * (TP + 1) + NOUT * TP);
+    const int TPX = rgb_tile_px(K), K2 = rgb_pow2(K);
+    int lg = 0;
+    while ((1 << lg) < TPX) ++lg;
+    const size_t lds = sizeof(float) * std::max<size_t>((size_t)K * (TPX + 1) + NOUT * TPX, (size_t)256 * (NOUT + 1));
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)rgb_wgrad_kernel<true>, 96 * 1024);
     dim3 grid((unsigned)S, (unsigned)B);
-    rgb_wgrad_kernel<true><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S);
+    rgb_wgrad_kernel<true><<<grid, 256, lds, (hipStream_t)stream_>>>(slabs, g, x, K, HW, S, TPX, lg, K2);
     return te::launch_status("te_rgb_wgrad_sum_f32");
 }
