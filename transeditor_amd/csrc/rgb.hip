@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slab
     const int t0 = (int)((int64_t)ntile * c / S), t1 = (int)((int64_t)ntile * (c + 1) / S);
     const float* xb = x + (size_t)b * K * HW;
     const float* gb = g + (size_t)b * NOUT * HW;
+    const bool vec4 = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);      // block-uniform
     // compute-phase geometry: K2 <= 256: `parts` threads per channel; K2 == 512: every thread owns two channels
     const int parts = K2 >= 256 ? 1 : 256 / K2;
     const int kk = K2 >= 256 ? tid : (tid & (K2 - 1)), part = K2 >= 256 ? 0 : tid / K2;
@@ -116,19 +117,40 @@ __global__ __launch_bounds__(256) void rgb_wgrad_kernel(float* __restrict__ slab
     for (int tl = t0; tl < t1; ++tl) {
         const int p0 = tl * TPX;
         __syncthreads();
-        for (int e0 = 0; e0 < K * TPX; e0 += 256 * 8) {        // 8 loads in flight per lane, then the LDS writes
-            float st[8];
+        if (vec4) {        // rows are 16-byte aligned (HW % 4 == 0): 8 float4 loads in flight per lane = a whole 8192-element tile in ONE
+                           // round (the scalar form below needs four rounds, and the kernel is bound by their latency, not by HBM)
+            for (int e0 = 0; e0 < K * TPX; e0 += 256 * 8 * 4) {
+                float4 st[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
-                const bool ok = e < K * TPX && p0 + pp < HW;
-                const float v = xb[ok ? (size_t)k * HW + p0 + pp : 0];
-                st[j] = ok ? v : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 4 * (tid + 256 * j), k = e >> lgTPX, pp = e & (TPX - 1);
+                    const bool ok = e < K * TPX && p0 + pp < HW;
+                    st[j] = ok ? *reinterpret_cast<const float4*>(xb + (size_t)k * HW + p0 + pp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 4 * (tid + 256 * j), k = e >> lgTPX, pp = e & (TPX - 1);
+                    if (e < K * TPX) {
+                        float* d = xl + k * (TPX + 1) + pp;
+                        d[0] = st[j].x; d[1] = st[j].y; d[2] = st[j].z; d[3] = st[j].w;
+                    }
+                }
             }
+        } else {
+            for (int e0 = 0; e0 < K * TPX; e0 += 256 * 8) {        // 8 loads in flight per lane, then the LDS writes
+                float st[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
-                if (e < K * TPX) xl[k * (TPX + 1) + pp] = st[j];
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
+                    const bool ok = e < K * TPX && p0 + pp < HW;
+                    const float v = xb[ok ? (size_t)k * HW + p0 + pp : 0];
+                    st[j] = ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + tid + 256 * j, k = e >> lgTPX, pp = e & (TPX - 1);
+                    if (e < K * TPX) xl[k * (TPX + 1) + pp] = st[j];
+                }
             }
         }
         for (int e = tid; e < NOUT * TPX; e += 256) {
