@@ -40,7 +40,7 @@ def test_pinning_matches_by_sign_and_fixes_flips(monkeypatch):
     assert torch.equal(a > 0, want_sign)                  # signs now the bank's; untouched elements keep their values
     keep = torch.ones_like(ref, dtype=torch.bool)
     keep[0, 0, 0, 0] = keep[1, 3, 2, 1] = False
-    assert float((a - ref * 0.70710678).abs()[keep].max()) < 1e-6 and float(a.abs()[~keep].max()) <= 1e-30
+    assert float((a - ref * 0.70710678).abs()[keep].max()) < 1e-6 and float(a.abs()[~keep].max()) < 2e-30
     assert b.shape == (3, 5) and c is not None and d is not None
     assert _lib.conv.__name__ == '<lambda>'               # the wrappers are gone again
 
