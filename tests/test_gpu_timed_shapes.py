@@ -268,3 +268,55 @@ def test_generator1024_fwd_bwd_batch1_vs_oracle():
     z, p = synth.latents(1, 5252)
     w = synth.normal((1, 3, 1024, 1024), 'ts.w1024')
     _check_against_oracle(G, sd, z, p, w, 1024, n_unused=17)
+
+
+def test_generator1024_batch4_backward_is_sum_of_batch1_backwards():
+    """BASELINE configs[4] AT ITS BATCH (FFHQ-1024, batch 4): the batch-4 backward - the tile / slab-split choices the bench
+    times, 32- and 64-channel tail layers on 512^2 / 1024^2 planes, 1025^2 intermediates - equals the sum of four batch-1
+    backwards (each of which test_generator1024_fwd_bwd_batch1_vs_oracle ties to the oracle), with the batch-1 passes taking the
+    leaky-ReLU slopes of the batch-4 pass (tests/pinning.py): every gradient element-wise (L2) at 1e-4."""
+    from pinning import capture, pinned
+    G, _ = _build(1024, 9)
+    B = 4
+    z, p = synth.latents(B, 5353)
+    w = synth.normal((B, 3, 1024, 1024), 'ts.w1024b4').to(DEV)
+    params = [q for q in G.parameters()]
+    names = [n for n, _ in G.named_parameters()]
+
+    def grads(sl):
+        zd, pd = z[sl].to(DEV).requires_grad_(True), p[sl].to(DEV).requires_grad_(True)
+        img = G(zd, pd)[0]
+        return [img.detach()] + list(torch.autograd.grad((img * w[sl]).sum() / (3 * 1024 * 1024), [zd, pd] + params, allow_unused=True))
+
+    with capture() as bank4:
+        g4 = grads(slice(0, B))
+    assert torch.isfinite(g4[0]).all()
+    acc, imgs, gz, gp, flips = None, [], [], [], 0
+    for k in range(B):
+        with pinned(bank4.batch_slice(slice(k, k + 1), B)) as st:
+            g1 = grads(slice(k, k + 1))
+        assert not st['unmatched'], st['unmatched']
+        flips += st['flips']
+        imgs.append(g1[0])
+        gz.append(g1[1])
+        gp.append(g1[2])
+        acc = [None if t is None else t.double() for t in g1[3:]] if acc is None else \
+              [None if a is None else a + t.double() for a, t in zip(acc, g1[3:])]
+    assert rel_err(g4[0], torch.cat(imgs)) < 1e-5                      # the forward is sample-independent
+    top = max(float(b.norm()) for b in acc if b is not None)
+    errs = {'dz': rel_l2(g4[1], torch.cat(gz)), 'dp': rel_l2(g4[2], torch.cat(gp))}
+    unused = 0
+    for n, a, b in zip(names, g4[3:], acc):
+        assert (a is None) == (b is None), n
+        if a is None:
+            unused += 1
+            continue
+        if n.endswith('k_transform.bias') or float(b.norm()) < 1e-9 * top:
+            continue
+        errs[n] = rel_l2(a, b)
+    assert unused == 17
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f'FFHQ-1024 batch-4 linearity pinned: {flips} slopes pinned; dz {errs["dz"]:.2e} dp {errs["dp"]:.2e}; '
+          f'worst {[(k, float(f"{v:.2e}")) for k, v in worst]}')
+    bad = [(k, v) for k, v in errs.items() if v > PIN_TOL]
+    assert not bad, bad[:8]
