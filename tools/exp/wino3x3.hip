@@ -9,31 +9,43 @@
 //   out[2j] = m0 + m1 + m2                   out[2j+1] = m1 - m2 - m3
 //
 // Block: 256 threads, output tile 128 (M) x 4 rows x 32 columns (= 64 pairs); wave (wm, wr): 64 output channels x rows
-// {2 wr, 2 wr + 1} x 16 pairs x 4 components = 8 accumulator tiles of v_mfma_f32_32x32x2_f32.  8 input channels per stage;
-// the loads of stage s + 1 are issued before the MFMAs of stage s (register prefetch), transformed and written to LDS after them.
+// {2 wr, 2 wr + 1} x 16 pairs x 4 components = 8 accumulator tiles of v_mfma_f32_32x32x2_f32.  WKC input channels per stage;
+// the loads of stage s + 1 are issued before the MFMAs of stage s (register prefetch).  WDB = 0: one LDS image, transformed
+// tile written after the MFMAs (two barriers per stage); WDB = 1: two images, the next tile is written between the two halves of
+// the current stage's MFMAs (one barrier per stage).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifndef WKC
+#define WKC 8
+#endif
+#ifndef WDB
+#define WDB 0
+#endif
+#ifndef WOCC
+#define WOCC 2
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KC = 8, TH = 4, TW = 32, NP = TW / 2, BM = 128;
-constexpr int T_FLOATS = KC * 4 * (TH + 2) * NP;          // 3072
-constexpr int U_FLOATS = 3 * 4 * KC * BM;                 // 12288
-constexpr int N_IN = (KC * (TH + 2) * NP + 255) / 256;    // input items (channel, row, pair) per thread: 3
-constexpr int N_W4 = U_FLOATS / 4 / 256;                  // weight float4 per thread: 12
+constexpr int KC = WKC, TH = 4, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
+constexpr int T_FLOATS = KC * 4 * RS;
+constexpr int U_FLOATS = 3 * 4 * KC * BM;
+constexpr int IMG = T_FLOATS + U_FLOATS;
+constexpr int N_IN = (KC * RS + 255) / 256;               // input items (channel, row, pair) per thread
+constexpr int N_W4 = U_FLOATS / 4 / 256;                  // weight float4 per thread
+constexpr bool IN_EXACT = (KC * RS) % 256 == 0;
 
 struct WinoArgs {
     float* out; const float* in; const float* U; const float* isc;
     int B, K, M, H, W;
 };
 
-__global__ __launch_bounds__(256, 2) void wino3x3_kernel(const WinoArgs p) {
+__global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Tl = smem;                 // [KC][4][TH + 2][NP]
-    float* Ul = smem + T_FLOATS;      // [3][4][KC][BM]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int wm = wid >> 1, wr = wid & 1;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH, mblocks = p.M / BM;
@@ -43,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(const WinoArgs p) {
     const int ty = t % tiles_y; const int b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
     const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
-    const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);
+    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -53,74 +66,98 @@ __global__ __launch_bounds__(256, 2) void wino3x3_kernel(const WinoArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
 
-    // per-thread staging geometry
-    int i_ch[N_IN], i_row[N_IN], i_pair[N_IN];
+    // staging geometry: item e = tid + 256 i -> (channel, row, pair); one element offset and one LDS offset per item
+    int g_off[N_IN], l_off[N_IN];
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
         const int e = tid + 256 * i;
-        i_pair[i] = e % NP; i_row[i] = (e / NP) % (TH + 2); i_ch[i] = e / (NP * (TH + 2));
+        const int pr = e % NP, row = (e / NP) % (TH + 2), ch = e / RS;
+        g_off[i] = (ch * p.H + (y0 - 1 + row)) * p.W + x0 + 2 * pr - 1;
+        l_off[i] = (IN_EXACT || e < KC * RS) ? ch * 4 * RS + row * NP + pr : -1;
     }
+    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * 8 * M
+    const int stage_in = KC * p.H * p.W, stage_w = 3 * 4 * KC * p.M;
     f32x4 rin[N_IN];
+    float rsc[N_IN];
     f32x4 rw[N_W4];
     const int nstage = p.K / KC;
     auto issue = [&](int s) {
+        const float* base = inb + (size_t)s * stage_in;
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
-            const int gy = y0 - 1 + i_row[i], gx = x0 + 2 * i_pair[i] - 1, ch = s * KC + i_ch[i];
-            const float* src = inb + ((size_t)ch * p.H + gy) * p.W + gx;
+            if (!IN_EXACT && l_off[i] < 0) continue;
+            const int e = tid + 256 * i, ch = e / RS;
+            rsc[i] = iscb ? iscb[s * KC + ch] : 1.f;
             if (!edge) {
-                rin[i] = *reinterpret_cast<const f32x4u*>(src);
+                rin[i] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
             } else {
+                const int pr = e % NP, row = (e / NP) % (TH + 2);
+                const int gy = y0 - 1 + row, gx = x0 + 2 * pr - 1;
                 const bool rowok = gy >= 0 && gy < p.H;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rin[i][q] = (rowok && gx + q >= 0 && gx + q < p.W) ? src[q] : 0.f;
+                for (int q = 0; q < 4; ++q) rin[i][q] = (rowok && gx + q >= 0 && gx + q < p.W) ? base[g_off[i] + q] : 0.f;
             }
         }
-        const float* us = p.U + (size_t)s * 3 * 4 * KC * p.M;
+        const float* us = p.U + (size_t)s * stage_w + w_off;
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 5, c4 = idx & 31;       // row = (ky * 4 + c) * KC + k
-            rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)row * p.M + mb * BM + 4 * c4);
-        }
+        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * 8 * p.M);
     };
-    auto commit = [&](int s) {
+    auto commit = [&](float* img) {
+        float* Tl = img;
+        float* Ul = img + T_FLOATS;
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
-            const float sc = p.isc ? p.isc[(size_t)b * p.K + s * KC + i_ch[i]] : 1.f;
+            if (!IN_EXACT && l_off[i] < 0) continue;
+            const float sc = rsc[i];
             const float d0 = rin[i][0] * sc, d1 = rin[i][1] * sc, d2 = rin[i][2] * sc, d3 = rin[i][3] * sc;
-            float* dst = Tl + ((i_ch[i] * 4) * (TH + 2) + i_row[i]) * NP + i_pair[i];
+            float* dst = Tl + l_off[i];
             dst[0] = d0 - d2;
-            dst[(TH + 2) * NP] = d1 + d2;
-            dst[2 * (TH + 2) * NP] = d2 - d1;
-            dst[3 * (TH + 2) * NP] = d1 - d3;
+            dst[RS] = d1 + d2;
+            dst[2 * RS] = d2 - d1;
+            dst[3 * RS] = d1 - d3;
         }
 #pragma unroll
         for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(Ul + 4 * (tid + 256 * i)) = rw[i];
     };
-
-    issue(0);
-    commit(0);
-    __syncthreads();
     const int rr = l31 >> 4, jj = l31 & 15;
-    for (int s = 0; s < nstage; ++s) {
-        if (s + 1 < nstage) issue(s + 1);
+    const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;          // + (2 ks * 4 + c) * RS + ky * NP
+    const int a_off = T_FLOATS + half * BM + wm * 64 + l31;             // + ((ky * 4 + c) * KC + 2 ks) * BM
+    auto mfmas = [&](const float* img, int ks_from, int ks_to) {
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            const int ch = 2 * ks + half;
+        for (int ks = ks_from; ks < ks_to; ++ks) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float bv = Tl[((ch * 4 + c) * (TH + 2) + 2 * wr + rr + ky) * NP + jj];
-                    const float* ua = Ul + ((ky * 4 + c) * KC + ch) * BM + wm * 64 + l31;
+                    const float bv = img[b_off + (2 * ks * 4 + c) * RS + ky * NP];
+                    const float* ua = img + a_off + ((ky * 4 + c) * KC + 2 * ks) * BM;
                     acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[0], bv, acc[0][c], 0, 0, 0);
                     acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[32], bv, acc[1][c], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
-        if (s + 1 < nstage) commit(s + 1);
-        __syncthreads();
+    };
+
+    issue(0);
+    commit(smem);
+    if (WDB && nstage > 1) issue(1);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        if (WDB) {
+            float* cur = smem + (s & 1) * IMG;
+            float* nxt = smem + ((s & 1) ^ 1) * IMG;
+            mfmas(cur, 0, KC / 4);
+            if (s + 1 < nstage) commit(nxt);                 // stage s + 1: loaded while stage s - 1 was multiplied
+            if (s + 2 < nstage) issue(s + 2);
+            mfmas(cur, KC / 4, KC / 2);
+            __syncthreads();
+        } else {
+            if (s + 1 < nstage) issue(s + 1);
+            mfmas(smem, 0, KC / 2);
+            __syncthreads();
+            if (s + 1 < nstage) commit(smem);
+            __syncthreads();
+        }
     }
     // epilogue: output transform, two adjacent columns per accumulator element
     float* ob = p.out + ((size_t)b * p.M + mb * BM + wm * 64) * p.H * p.W;
@@ -142,10 +179,12 @@ extern "C" int wino3x3_f32(float* out, const float* in, const float* U, const fl
                            void* stream) {
     if (K % KC || M % BM || H % TH || W % TW) return -1;
     WinoArgs a{out, in, U, isc, B, K, M, H, W};
-    const size_t lds = sizeof(float) * (T_FLOATS + U_FLOATS);
+    const size_t lds = sizeof(float) * IMG * (WDB ? 2 : 1);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)wino3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)wino3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int64_t blocks = (int64_t)B * (H / TH) * (W / TW) * (M / BM);
     wino3x3_kernel<<<dim3((unsigned)blocks), 256, lds, (hipStream_t)stream>>>(a);
     return (int)hipGetLastError();
 }
+
+extern "C" int wino_kc(void) { return KC; }

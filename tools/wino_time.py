@@ -11,13 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from transeditor_amd import _lib      # noqa: E402
 
-src, so = os.path.join(ROOT, 'tools/exp/wino3x3.hip'), os.path.join(ROOT, 'tools/exp/libwino.so')
-if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) or os.environ.get('WINO_FLAGS'):
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
-                           *os.environ.get('WINO_FLAGS', '').split(), src, '-o', so])
-W = C.CDLL(so)
-W.wino3x3_f32.restype = C.c_int
-W.wino3x3_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+SRC = os.path.join(ROOT, 'tools/exp/wino3x3.hip')
+
+
+def load(kc, db, occ, extra=()):
+    so = os.path.join(ROOT, f'tools/exp/libwino_{kc}_{db}_{occ}{"_" + "".join(extra).replace("-D", "").replace("=", "") if extra else ""}.so')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DWKC={kc}',
+                               f'-DWDB={db}', f'-DWOCC={occ}', *extra, SRC, '-o', so])
+    W = C.CDLL(so)
+    W.wino3x3_f32.restype = C.c_int
+    W.wino3x3_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+    return W
 
 
 def timeit(fn, n=10):
@@ -30,30 +35,35 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n
 
 
-def transform_weights(w):
-    """[M, K, 3, 3] -> U [K/8][3][4][8][M]:  U[ky][c] = G w[.., ky, :],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]"""
+def transform_weights(w, kc):
+    """[M, K, 3, 3] -> U [K/kc][3][4][kc][M]:  U[ky][c] = G w[.., ky, :],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]"""
     M, K = w.shape[:2]
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], device=w.device, dtype=w.dtype)
     u = torch.einsum('cx,mkyx->yckm', G, w)                       # [3][4][K][M]
-    return u.reshape(3, 4, K // 8, 8, M).permute(2, 0, 1, 3, 4).contiguous()
+    return u.reshape(3, 4, K // kc, kc, M).permute(2, 0, 1, 3, 4).contiguous()
 
 
-for B, K, M, H in ((16, 128, 128, 256), (16, 256, 256, 128), (16, 512, 512, 64), (2, 8, 128, 8)):
+VARIANTS = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 0, 2), (4, 1, 2), (8, 1, 1), (4, 0, 2)]
+SHAPES = ((16, 128, 128, 256), (16, 256, 256, 128), (16, 512, 512, 64))
+for B, K, M, H in SHAPES:
     torch.manual_seed(0)
     x = torch.randn(B, K, H, H, device='cuda')
     w = torch.randn(M, K, 3, 3, device='cuda') / (3 * K ** 0.5)
     isc = 1 + 0.1 * torch.randn(B, K, device='cuda')
     wp = _lib.conv_pack(w, _lib.PACK_FWD, 1.0)
     ref = _lib.conv(x, wp, _lib.CONV_3X3, M, H, H, isc, None, None, 0)
-    U = transform_weights(w)
-    out = torch.empty_like(ref)
-    st = torch.cuda.current_stream().cuda_stream
-    run = lambda: W.wino3x3_f32(out.data_ptr(), x.data_ptr(), U.data_ptr(), isc.data_ptr(), B, K, M, H, H, st)
-    rc = run()
-    torch.cuda.synchronize()
-    err = float((out - ref).abs().max() / ref.abs().max())
     flops = 2.0 * 9 * K * M * H * H * B
     t_d = timeit(lambda: _lib.conv(x, wp, _lib.CONV_3X3, M, H, H, isc, None, None, 0))
-    t_w = timeit(run)
-    print(f'B{B} {K}->{M} @{H}: rc {rc} err {err:.2e} | direct {t_d * 1e3:8.1f} us {flops / t_d / 1e9:6.1f} TF/s | winograd {t_w * 1e3:8.1f} us '
-          f'{flops / t_w / 1e9:6.1f} TF/s (algorithmic)', flush=True)
+    print(f'B{B} {K}->{M} @{H}: direct {t_d * 1e3:8.1f} us {flops / t_d / 1e9:6.1f} TF/s', flush=True)
+    st = torch.cuda.current_stream().cuda_stream
+    for kc, db, occ in VARIANTS:
+        W = load(kc, db, occ)
+        U = transform_weights(w, kc)
+        out = torch.empty_like(ref)
+        run = lambda: W.wino3x3_f32(out.data_ptr(), x.data_ptr(), U.data_ptr(), isc.data_ptr(), B, K, M, H, H, st)
+        rc = run()
+        torch.cuda.synchronize()
+        err = float((out - ref).abs().max() / ref.abs().max())
+        t_w = timeit(run)
+        print(f'    winograd KC={kc} DB={db} occ={occ}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
+              f'MFMA-equivalent {flops / t_w / 1e9 / 1.5:6.1f}', flush=True)
