@@ -82,7 +82,8 @@ class KernelTimer:
         from transeditor_amd import _lib
         timer = self
         orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
-        names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1'}
+        names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1',
+                 _lib.CONV_3X3W: 'conv3x3'}        # (the Winograd form of the same convolution: same algorithmic FLOPs)
 
         def conv(x, wp, kind, M, H, W, *a, **k):
             if not timer.enabled:
@@ -145,7 +146,8 @@ class KernelTimer:
 
 PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32'),
               ('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'))
-PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'conv_mfma_kernel<0', 'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
+PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino3x3_kernel', 'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
+               'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
                'convT2_256to128_at128_b16': 'conv_mfma_kernel<1', 'convS2_128to256_at128_b16': 'conv_mfma_kernel<2',
                'wgradT2_256x128_at128_b16': 'wgrad_mfma_kernel<1'}
 
@@ -208,7 +210,7 @@ def attach_counters(roof, live=True):
             hbm_tail[k[:60]] = {'us': v['us'], 'algorithmic_TBps': v['algorithmic_mb'] / v['us'],        # MB / us == TB/s
                                 'frac_of_hbm_peak': v['algorithmic_mb'] / v['us'] / (PEAK_HBM_GBS / 1e3),
                                 'traffic_over_algorithmic': (v['hbm_read_mb'] + v['hbm_write_mb']) / v['algorithmic_mb']}
-    top = ctr.get('conv3x3_fwd_128to128_at256_b16')
+    top = ctr.get('conv3x3_fwd_128to128_at256_b16') or ctr.get('conv3x3_direct_kernel_same_shape')
     if top is None:
         roof['traffic'], roof['traffic_note'] = _pmc_traffic()
         roof['traffic_source'] = 'static'

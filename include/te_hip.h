@@ -133,12 +133,16 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_CONV_T2 1     /* 3x3 transposed, stride 2, pad 0 in [B,K,H,W]       -> out [B,M,2H+1,2W+1]  */
 #define TE_CONV_S2 2     /* 3x3, stride 2, pad 0           in [B,K,2H+1,2W+1] -> out [B,M,H,W]        */
 #define TE_CONV_1X1 3    /* 1x1                            in [B,K,H,W]       -> out [B,M,H,W]        */
+#define TE_CONV_3X3W 4   /* TE_CONV_3X3 through the 1-D Winograd F(2,3) kernel (2/3 of the MFMAs; same result to fp32 round-off).
+                            Shapes: te_conv_wino_supported; weights packed TE_PACK_WFWD / TE_PACK_WDGRAD; never split */
 
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */
 #define TE_PACK_FWD 0    /* M = Co, K = Ci, taps as stored         (forward 3x3 / 1x1 / T2, and S2) */
 #define TE_PACK_DGRAD 1  /* M = Ci, K = Co, taps flipped           (data gradient of 3x3 / 1x1)     */
 #define TE_PACK_SWAP 2   /* M = Ci, K = Co, taps as stored         (S2 as data gradient of T2)       */
+#define TE_PACK_WFWD 3   /* TE_CONV_3X3W forward:       U[K/8][ky][c][8][M], U[ky][c] = G w[.., ky, :]  (12 K M floats)  */
+#define TE_PACK_WDGRAD 4 /* TE_CONV_3X3W data gradient: the same transform of the flipped, transposed taps (M = Ci)     */
 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
@@ -165,6 +169,11 @@ int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, 
  * second kernel sums them in a fixed order (DETERMINISTIC, no atomics, no memset).  te_conv_f32 itself (no workspace)
  * never splits (same result up to summation order, slower on 4x4 ... 16x16 images). */
 int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
+/* 1 if TE_CONV_3X3W covers the problem: K % 8 == 0, M % 128 == 0, H % 4 == 0, W % 32 == 0 (every 3x3 layer of the generator
+ * and discriminator from 32x32 up at the FFHQ-256 channel counts; the narrow tail of FFHQ-1024 and the 513-channel final
+ * convolution stay on TE_CONV_3X3).  Reference: the grouped F.conv2d of ModulatedConv2d.forward, model_spatial_query.py:331-333,
+ * and EqualConv2d.forward :173-181. */
+int te_conv_wino_supported(int B, int K, int M, int H, int W);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 /* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):

@@ -1,0 +1,97 @@
+"""TE_CONV_3X3W: the 1-D Winograd F(2,3) form of the 3x3 / stride 1 / pad 1 convolution (csrc/wino.hip) against fp64 torch and
+against the direct kernel - forward layout and data-gradient layout (flipped, transposed taps), style scale at staging, every
+epilogue stage (demodulation scale, bias, leaky-ReLU with gain sqrt(2) / 1, residual, activation-gradient mask), single-tile
+and multi-tile images, several M blocks, edge tiles on all four sides - and the weight transform of the packing kernel.
+Reference: the grouped F.conv2d of ModulatedConv2d.forward (model_spatial_query.py:331-333), EqualConv2d.forward (:173-181)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from transeditor_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+SHAPES = [(2, 8, 128, 4, 32), (1, 16, 128, 8, 64), (3, 24, 256, 12, 32), (2, 128, 128, 32, 32), (2, 64, 384, 16, 96), (1, 512, 512, 32, 32)]
+
+
+@pytest.mark.parametrize('B,K,M,H,W', SHAPES)
+def test_winograd_forward_and_data_gradient_vs_fp64(B, K, M, H, W):
+    assert _lib.wino_ok(B, K, M, H, W)
+    x = synth.normal((B, K, H, W), f'wino.x.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f'wino.w.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc = (1 + 0.3 * synth.normal((B, K), 'wino.isc')).to(DEV)
+    ws = 0.83
+    want = F.conv2d(x.double() * isc.double()[:, :, None, None], w.double() * ws, padding=1)
+    up = _lib.conv_pack(w, _lib.PACK_WFWD, ws)
+    got = _lib.conv(x, up, _lib.CONV_3X3W, M, H, W, isc)
+    assert rel_err(got, want) < 5e-6
+    direct = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, ws), _lib.CONV_3X3, M, H, W, isc)
+    assert rel_err(got, direct) < 5e-6
+    # data gradient: a convolution from M to K channels with the flipped, transposed taps - only where THAT problem is covered
+    if _lib.wino_ok(B, M, K, H, W):
+        g = synth.normal((B, M, H, W), f'wino.g.{M}.{H}').to(DEV)
+        osc = (1 + 0.3 * synth.normal((B, K), 'wino.osc')).to(DEV)
+        want_g = F.conv_transpose2d(g.double(), w.double() * ws, padding=1) * osc.double()[:, :, None, None]
+        got_g = _lib.conv(g, _lib.conv_pack(w, _lib.PACK_WDGRAD, ws), _lib.CONV_3X3W, K, H, W, None, osc)
+        assert rel_err(got_g, want_g) < 5e-6
+
+
+@pytest.mark.parametrize('act', [0, 3, 4])
+@pytest.mark.parametrize('epi', ['plain', 'res', 'res+mask'])
+def test_winograd_epilogue_stages_equal_the_direct_kernel(act, epi):
+    B, K, M, H, W = 2, 32, 256, 8, 64
+    x = synth.normal((B, K, H, W), 'wino.ex').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 'wino.ew') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 'wino.ei')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'wino.eo')).to(DEV)
+    bias = synth.normal((M,), 'wino.eb').to(DEV)
+    res = synth.normal((B, M, H, W), 'wino.er').to(DEV) if epi != 'plain' else None
+    mref = synth.normal((B, M, H, W), 'wino.em').to(DEV) if epi == 'res+mask' else None
+    a = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_WFWD), _lib.CONV_3X3W, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
+    b = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
+    pre = F.conv2d(x.double() * isc.double()[:, :, None, None], w.double(), padding=1) * osc.double()[:, :, None, None] + bias.double()[None, :, None, None]
+    if act:
+        # a pre-activation within round-off of the kink may take the other slope in the two kernels: compare away from it
+        keep = pre.abs() > 1e-4
+        assert rel_err(a * keep, b * keep) < 5e-6
+    else:
+        assert rel_err(a, b) < 5e-6
+
+
+def test_winograd_layouts_through_the_multi_pack_launch_and_the_module_path():
+    """both Winograd layouts through te_conv_pack_weights_multi_f32 equal the single-layout launch and the transform written out
+    with torch; and the module path really takes the Winograd kernel where it applies (same result as with the switch off)"""
+    from transeditor_amd.op import modconv
+    M, K = 256, 136
+    w = synth.normal((M, K, 3, 3), 'wino.pw').to(DEV)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], device=DEV)
+    u = torch.einsum('cx,mkyx->yckm', G, w * 0.7)                                   # [3][4][K][M]
+    want_f = u.reshape(3, 4, K // 8, 8, M).permute(2, 0, 1, 3, 4).reshape(-1)
+    wd = torch.flip(w, [2, 3]).transpose(0, 1)                                      # [K (as M), M (as K), 3, 3]
+    ud = torch.einsum('cx,mkyx->yckm', G, wd * 0.7)
+    want_d = ud.reshape(3, 4, M // 8, 8, K).permute(2, 0, 1, 3, 4).reshape(-1)
+    assert rel_err(_lib.conv_pack(w, _lib.PACK_WFWD, 0.7), want_f) < 1e-6
+    assert rel_err(_lib.conv_pack(w, _lib.PACK_WDGRAD, 0.7), want_d) < 1e-6
+    a, b = _lib.conv_pack2(w, _lib.PACK_WFWD, _lib.PACK_WDGRAD, 0.7)
+    assert torch.equal(a, _lib.conv_pack(w, _lib.PACK_WFWD, 0.7)) and torch.equal(b, _lib.conv_pack(w, _lib.PACK_WDGRAD, 0.7))
+    # module path: forward + backward of a modulated layer with and without the Winograd form
+    x = synth.normal((2, 128, 32, 32), 'wino.mx').to(DEV).requires_grad_(True)
+    wm = (synth.normal((128, 128, 3, 3), 'wino.mw')).to(DEV).requires_grad_(True)
+    s = (1 + 0.3 * synth.normal((2, 128), 'wino.ms')).to(DEV).requires_grad_(True)
+    bias = synth.normal((128,), 'wino.mb').to(DEV).requires_grad_(True)
+    gy = synth.normal((2, 128, 32, 32), 'wino.mg').to(DEV)
+    outs = []
+    for flag in (True, False):
+        modconv.USE_WINOGRAD = flag
+        try:
+            y = modconv.modconv(x, wm, s, None, bias, True, '3x3', 1 / math.sqrt(128 * 9), demod_eps=1e-8)
+            # (no upstream gradient near the leaky-ReLU kink: the two kernels may legitimately pick different slopes there)
+            gs = torch.autograd.grad(y, (x, wm, s, bias), gy * (y.detach().abs() > 1e-4))
+        finally:
+            modconv.USE_WINOGRAD = True
+        outs.append((y.detach(),) + gs)
+    for name, p, q in zip(('y', 'dx', 'dw', 'ds', 'db'), outs[0], outs[1]):
+        assert rel_err(p, q) < 2e-5, name

@@ -16,9 +16,15 @@ def main():
     x = torch.randn(B, 128, 256, 256, device=DEV)
     w = torch.randn(128, 128, 3, 3, device=DEV) / 34
     isc, osc, bias = torch.rand(B, 128, device=DEV) + 0.5, torch.rand(B, 128, device=DEV) + 0.5, torch.randn(128, device=DEV)
-    wp = _lib.conv_pack(w, _lib.PACK_FWD)
+    from transeditor_amd.op.modconv import fwd_kinds
+    pk, ck = fwd_kinds('3x3', B, w, 256, 256)                                         # the form the model runs (Winograd where it applies)
+    wp = _lib.conv_pack(w, pk)
     for _ in range(REP):
-        y = _lib.conv(x, wp, _lib.CONV_3X3, 128, 256, 256, isc, osc, bias, 3)         # conv3x3 fwd (fused epilogue)
+        y = _lib.conv(x, wp, ck, 128, 256, 256, isc, osc, bias, 3)                    # conv3x3 fwd (fused epilogue)
+    if ck != _lib.CONV_3X3:
+        wpd = _lib.conv_pack(w, _lib.PACK_FWD)
+        for _ in range(REP):
+            _lib.conv(x, wpd, _lib.CONV_3X3, 128, 256, 256, isc, osc, bias, 3)        # the direct kernel at the same shape (small layers run it)
     for _ in range(REP):
         sl = _lib.wgrad_slabs(y, x, _lib.CONV_3X3, 256, 256)                           # wgrad 3x3
     for _ in range(REP):

@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
 _lib = None
 
-CONV_3X3, CONV_T2, CONV_S2, CONV_1X1 = 0, 1, 2, 3
-PACK_FWD, PACK_DGRAD, PACK_SWAP = 0, 1, 2
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W = 0, 1, 2, 3, 4
+PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD = 0, 1, 2, 3, 4
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
@@ -38,6 +38,7 @@ _SIGNATURES = {
     'te_conv_pack_weights_multi_f32': (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P]),
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
+    'te_conv_wino_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -324,6 +325,11 @@ def conv_pack_multi(jobs):
         arr(C.c_float, [float(j[3]) for j in jobs]), arr(C.c_int, [int(j[2]) for j in jobs]),
         arr(C.c_int, [j[1].shape[0] for j in jobs]), arr(C.c_int, [j[1].shape[1] for j in jobs]),
         arr(C.c_int, [j[1].shape[2] for j in jobs]), _stream()), 'te_conv_pack_weights_multi_f32')
+
+
+def wino_ok(B, K, M, H, W):
+    """does TE_CONV_3X3W (1-D Winograd F(2,3): 2/3 of the MFMAs of the direct 3x3 kernel) cover this problem?"""
+    return bool(lib().te_conv_wino_supported(B, K, M, H, W))
 
 
 def conv_out_shape(kind, B, M, H, W):

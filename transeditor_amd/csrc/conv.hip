@@ -749,7 +749,7 @@ constexpr int PT = 32;
 template <int T>
 __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
     constexpr int RL = PT * T + 1, NE = PT * PT * T;
-    const bool fwd = q.kind == TE_PACK_FWD;
+    const bool fwd = q.kind == TE_PACK_FWD || q.kind == TE_PACK_WFWD;
     const int Co = fwd ? q.M : q.K, Ci = fwd ? q.K : q.M;              // real extents of the source along co / ci
     const int CoP = fwd ? q.Mp : q.Kp, CiP = fwd ? q.Kp : q.Mp;        // padded extents of the packed layout (zero filled)
     const int tiles_i = (CiP + PT - 1) / PT, tiles_c = (CoP + PT - 1) / PT;
@@ -763,7 +763,23 @@ __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
             tile[r * RL + j] = v * q.wscale;
         }
         __syncthreads();
-        if (fwd) {                                                     // Wp[(tap * Kp + ci) * Mp + co]: lanes over co
+        if (T == 9 && (q.kind == TE_PACK_WFWD || q.kind == TE_PACK_WDGRAD)) {
+            // Winograd F(2,3) weight transform (wino.hip): U[((k / 8 * 3 + ky) * 4 + c) * 8 + k % 8][m] = sum_kx G[c][kx] w(.., ky, kx),
+            // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; forward: m = co, k = ci; data gradient: m = ci, k = co, taps flipped
+            const bool wf = q.kind == TE_PACK_WFWD;
+            for (int e = threadIdx.x; e < PT * PT * 12; e += 256) {
+                const int lanei = e % PT, x = e / PT, other = x % PT, kc = x / PT;        // kc = ky * 4 + c
+                const int r = wf ? lanei : other, ii = wf ? other : lanei;                // lanes run over m (contiguous in U)
+                const int ky = kc >> 2, c = kc & 3;
+                const int co = c0 + r, ci = i0 + ii;
+                if (co >= Co || ci >= Ci) continue;
+                const float* src = tile + r * RL + ii * T + (wf ? ky * 3 : (2 - ky) * 3);
+                const float g0 = wf ? src[0] : src[2], g1 = src[1], g2 = wf ? src[2] : src[0];
+                const float v = c == 0 ? g0 : (c == 1 ? 0.5f * (g0 + g1 + g2) : (c == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+                const int m = wf ? co : ci, k = wf ? ci : co;
+                q.wp[((size_t)((k >> 3) * 3 + ky) * 4 + c) * 8 * q.Mp + (size_t)(k & 7) * q.Mp + m] = v;
+            }
+        } else if (fwd) {                                              // Wp[(tap * Kp + ci) * Mp + co]: lanes over co
             for (int e = threadIdx.x; e < NE; e += 256) {
                 const int r = e % PT, x = e / PT, ii = x % PT, tap = x / PT;
                 const int co = c0 + r, ci = i0 + ii;
@@ -792,13 +808,19 @@ inline int pow2ceil(int v) { return 1 << ilog2(v); }
 inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 struct PackDims { int K, M, Kp, Mp, ntap; };
+inline bool pack_is_wino(int kind_pack) { return kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_WDGRAD; }
 inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     PackDims d;
     d.ntap = ksize * ksize;
-    d.M = (kind_pack == TE_PACK_FWD) ? Co : Ci;
-    d.K = (kind_pack == TE_PACK_FWD) ? Ci : Co;
-    d.Kp = roundup(d.K, KPAD);
-    d.Mp = roundup(d.M, MPAD);
+    const bool fwd = kind_pack == TE_PACK_FWD || kind_pack == TE_PACK_WFWD;
+    d.M = fwd ? Co : Ci;
+    d.K = fwd ? Ci : Co;
+    if (pack_is_wino(kind_pack)) {          // U[K/8][ky][component][8][M]: no padding (K % 8 == 0, M % 128 == 0 are required)
+        d.Kp = d.K; d.Mp = d.M;
+    } else {
+        d.Kp = roundup(d.K, KPAD);
+        d.Mp = roundup(d.M, MPAD);
+    }
     return d;
 }
 
@@ -969,7 +991,7 @@ extern "C" int te_debug_conv_prof_clear() {
 
 extern "C" int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize) {
     const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
-    return (int64_t)d.ntap * d.Kp * d.Mp;
+    return (int64_t)(pack_is_wino(kind_pack) ? 12 : d.ntap) * d.Kp * d.Mp;
 }
 
 static int pack_launch(const char* what, int n, float* const* wp, const float* const* w, const float* wscale, const int* kind_pack,
@@ -1007,7 +1029,9 @@ static int pack_launch(const char* what, int n, float* const* wp, const float* c
             const int e = base + i;
             TE_REQUIRE(wp[e] && w[e], TE_ERR_NULL, "%s: NULL pointer in job %d", what, e);
             TE_REQUIRE(Co[e] > 0 && Ci[e] > 0 && (ksize[e] == 1 || ksize[e] == 3), TE_ERR_SHAPE, "%s: bad dims in job %d", what, e);
-            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 2, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 4, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(!pack_is_wino(kind_pack[e]) || (ksize[e] == 3 && Co[e] % 8 == 0 && Ci[e] % 8 == 0), TE_ERR_UNSUPPORTED,
+                       "%s: the Winograd layouts need 3x3 taps and channel counts that are multiples of 8 (job %d)", what, e);
             const PackDims d = pack_dims(kind_pack[e], Co[e], Ci[e], ksize[e]);
             P.j[i] = PackJob{wp[e], w[e], wscale[e], kind_pack[e], Ci[e], d.ntap, d.K, d.M, d.Kp, d.Mp};
             biggest = std::max<int64_t>(biggest, te::cdiv(d.Kp, PT) * te::cdiv(d.Mp, PT));
@@ -1070,7 +1094,8 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
 }
 
 extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
-    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 3) return TE_ERR_SHAPE;
+    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 4) return TE_ERR_SHAPE;
+    if (kind == TE_CONV_3X3W) return 1;
     return conv_plan(kind, B, K, M, H, W).ksplit;
 }
 
@@ -1082,8 +1107,9 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
                "te_conv_res_f32: no residual / mask epilogue for the transposed kind");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
-    TE_REQUIRE(kind >= 0 && kind <= 3, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
+    TE_REQUIRE(kind >= 0 && kind <= 4, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     hipStream_t s = (hipStream_t)stream_;
+    if (kind == TE_CONV_3X3W) return te_wino_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);
     ConvArgs a{};
     a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;

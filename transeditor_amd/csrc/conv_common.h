@@ -20,3 +20,8 @@ constexpr int KPAD = 16;    // packed weights Wp[tap][Kp][Mp]: K padded to a mul
 constexpr int MPAD = 128;   // ... M padded to a multiple of 128 (block tiles cover 32, 64 or 128 rows)
 constexpr int NTHREADS = 256;
 
+
+// csrc/wino.hip: the 1-D Winograd F(2,3) form of the 3x3 / stride 1 / pad 1 convolution (kind TE_CONV_3X3W); weights packed
+// TE_PACK_WFWD / TE_PACK_WDGRAD as U[K/8][ky][component][8][M]
+int te_wino_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
+                   const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);

@@ -256,13 +256,13 @@ def packed2(w, kind_a, kind_b, wscale=1.0):
     return packed(w, kind_a, wscale), packed(w, kind_b, wscale)
 
 
-def _frozen_entry(w, kind, wscale, want_wsq):
+def _frozen_entry(w, kind, wscale, want_wsq, pack_kind=_lib.PACK_FWD):
     base = w._base if w._base is not None else w
-    key = (id(base), w.data_ptr(), tuple(w.shape), kind, float(wscale))
+    key = (id(base), w.data_ptr(), tuple(w.shape), kind, float(wscale), pack_kind)
     stamp = (base._version, base.data_ptr())
     ent = _STATE.frozen_cache.get(key)
     if ent is None or ent['stamp'] != stamp:
-        ent = {'stamp': stamp, 'wp': _lib.conv_pack(w, _lib.PACK_FWD, wscale), 'wsq': None, 'keep': base}
+        ent = {'stamp': stamp, 'wp': _lib.conv_pack(w, pack_kind, wscale), 'wsq': None, 'keep': base}
         _STATE.frozen_cache[key] = ent
     if want_wsq and ent['wsq'] is None:
         w3 = w.reshape(w.shape[0], w.shape[1], -1)
@@ -272,13 +272,14 @@ def _frozen_entry(w, kind, wscale, want_wsq):
 
 def _modconv_frozen(x, w, isc, osc, bias, act, kind, wscale, demod_eps):
     """forward only, weights taken from the frozen cache (no autograd node is created)"""
-    ent = _frozen_entry(w, kind, wscale, demod_eps is not None)
+    H, W = _lowres_hw(kind, False, x)
+    pk, ck = fwd_kinds(kind, x.shape[0], w, H, W)
+    ent = _frozen_entry(w, kind, wscale, demod_eps is not None, pk)
     if demod_eps is not None:
         osc = _lib.demod_from_wsq(ent['wsq'], isc, demod_eps)
     if kind == '1x1' and osc is None and not act and _lib.rgb_supported(w.shape[0], w.shape[1], x.shape[2] * x.shape[3]):
         return _lib.rgb_fwd(x, w.reshape(w.shape[0], w.shape[1]), isc, bias, wscale)
-    H, W = _lowres_hw(kind, False, x)
-    return _lib.conv(x, ent['wp'], _KIND[kind], w.shape[0], H, W, isc, osc, bias, _act_code(act))
+    return _lib.conv(x, ent['wp'], ck, w.shape[0], H, W, isc, osc, bias, _act_code(act))
 
 
 _KIND = {'3x3': _lib.CONV_3X3, '1x1': _lib.CONV_1X1, 'up': _lib.CONV_T2, 'down': _lib.CONV_S2}
@@ -317,31 +318,50 @@ def _bwd_pack_kind(kind):
     return _lib.PACK_SWAP if kind in ('up', 'down') else _lib.PACK_DGRAD
 
 
+# 3x3 / stride 1 launches that the 1-D Winograd F(2,3) kernel covers (csrc/wino.hip: >= 32x32 images, K % 8 == 0, M % 128 == 0 - the
+# launches that carry the FLOPs of both networks) use it: same result to fp32 round-off, 2/3 of the MFMAs.  The choice is a pure
+# function of the problem shape, so the forward (which packs the data-gradient layout ahead) and the backward agree on it.
+USE_WINOGRAD = True      # False: the direct kernel everywhere (A/B measurements)
+
+
+def fwd_kinds(kind, B, w, H, W):
+    """(weight pack kind, convolution kind code) of the forward launch; H, W = low-resolution size"""
+    if kind == '3x3' and USE_WINOGRAD and _lib.wino_ok(B, w.shape[1], w.shape[0], H, W):
+        return _lib.PACK_WFWD, _lib.CONV_3X3W
+    return _lib.PACK_FWD, _KIND[kind]
+
+
+def bwd_kinds(kind, B, w, H, W):
+    """the same for the data gradient (a convolution from Co to Ci channels)"""
+    if kind == '3x3' and USE_WINOGRAD and _lib.wino_ok(B, w.shape[0], w.shape[1], H, W):
+        return _lib.PACK_WDGRAD, _lib.CONV_3X3W
+    ck = {'up': _lib.CONV_S2, 'down': _lib.CONV_T2}.get(kind)          # adjoint of the transposed / strided kind
+    return _bwd_pack_kind(kind), (ck if ck is not None else _KIND[kind])
+
+
 def _fwd_raw(x, w, kind, isc=None, osc=None, bias=None, act=0, wscale=1.0, with_bwd_pack=False):
     """with_bwd_pack: also return the data-gradient packing of w (one launch packs both layouts)."""
     H, W = _lowres_hw(kind, False, x)
+    pk, ck = fwd_kinds(kind, x.shape[0], w, H, W)
     if with_bwd_pack:
-        wp, wpb = packed2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
-        return _lib.conv(x, wp, _KIND[kind], w.shape[0], H, W, isc, osc, bias, act), wpb
+        wp, wpb = packed2(w, pk, bwd_kinds(kind, x.shape[0], w, H, W)[0], wscale)
+        return _lib.conv(x, wp, ck, w.shape[0], H, W, isc, osc, bias, act), wpb
     if _STATE.pack_cache is not None and torch.is_grad_enabled() is False:
         # (a no-grad forward inside a training loop: the same weights meet a backward later in the iteration)
-        wp, _ = packed2(w, _lib.PACK_FWD, _bwd_pack_kind(kind), wscale)
+        wp, _ = packed2(w, pk, bwd_kinds(kind, x.shape[0], w, H, W)[0], wscale)
     else:
-        wp = packed(w, _lib.PACK_FWD, wscale)
-    return _lib.conv(x, wp, _KIND[kind], w.shape[0], H, W, isc, osc, bias, act)
+        wp = packed(w, pk, wscale)
+    return _lib.conv(x, wp, ck, w.shape[0], H, W, isc, osc, bias, act)
 
 
 def _dgrad_raw(g, w, kind, isc=None, osc=None, wscale=1.0, wp=None):
     """data gradient: g is shaped like the conv OUTPUT; returns a tensor shaped like the conv input.
     isc scales the channels of g ([B,Co]), osc the channels of the result ([B,Ci]).  wp: w already packed for it."""
     H, W = _lowres_hw(kind, True, g)
+    pk, ck = bwd_kinds(kind, g.shape[0], w, H, W)          # ('up': the strided kind is its adjoint; 'down': the transposed one)
     if wp is None:
-        wp = packed(w, _bwd_pack_kind(kind), wscale)
-    if kind == 'up':       # adjoint of the transposed conv = strided conv
-        return _lib.conv(g, wp, _lib.CONV_S2, w.shape[1], H, W, isc, osc)
-    if kind == 'down':     # adjoint of the strided conv = transposed conv
-        return _lib.conv(g, wp, _lib.CONV_T2, w.shape[1], H, W, isc, osc)
-    return _lib.conv(g, wp, _KIND[kind], w.shape[1], H, W, isc, osc)
+        wp = packed(w, pk, wscale)
+    return _lib.conv(g, wp, ck, w.shape[1], H, W, isc, osc)
 
 
 def _wgrad_raw(g, x, kind, group=False):

@@ -25,7 +25,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, cache_of, keep_cache, packed, packed2
+from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, bwd_kinds, cache_of, fwd_kinds, keep_cache, packed, packed2
 from .upfirdn2d import _geometry, flipped_taps, upfirdn2d
 
 _SQRT2 = math.sqrt(2.0)
@@ -61,11 +61,12 @@ class _ResBlock(Function):
         front = need_x or need[1] or need[2]                  # anything upstream of the blur wants a gradient
         H, W = x.shape[2], x.shape[3]
         # conv1 (+ its data-gradient packing when dx will be asked for)
+        pk1, ck1 = fwd_kinds('3x3', x.shape[0], w1, H, W)       # (the Winograd form where it applies: op/modconv.py)
         if need_x:
-            wp1, wp1b = packed2(w1, _lib.PACK_FWD, _bwd_pack_kind('3x3'), s1)
+            wp1, wp1b = packed2(w1, pk1, bwd_kinds('3x3', x.shape[0], w1, H, W)[0], s1)
         else:
-            wp1, wp1b = packed(w1, _lib.PACK_FWD, s1), None
-        y1 = _lib.conv(x, wp1, _lib.CONV_3X3, w1.shape[0], H, W, None, None, b1, 3)
+            wp1, wp1b = packed(w1, pk1, s1), None
+        y1 = _lib.conv(x, wp1, ck1, w1.shape[0], H, W, None, None, b1, 3)
         pm = (pad_main[0], pad_main[1], pad_main[0], pad_main[1])
         yb = _lib.upfirdn2d_raw(y1, k_main, (1, 1), (1, 1), pm)
         if yb.shape[2] % 2 == 0 or yb.shape[3] % 2 == 0:
@@ -146,8 +147,8 @@ class _ResBlock(Function):
             _, gp_s = _geometry(x.shape[2:], k_skip.shape, (1, 1), (2, 2), ps)
             gx_b = _lib.upfirdn2d_raw(g_xs, flipped_taps(k_skip), (2, 2), (1, 1), gp_s)
             # data gradient of conv1 + the skip branch's gradient in its epilogue (+ the stem's activation gradient)
-            gx = _lib.conv(g1, wp1b, _lib.CONV_3X3, w1.shape[1], x.shape[2], x.shape[3], None, None, None, 0, res=gx_b,
-                           mask_ref=x if ctx.stem else None, mask_gain=_SQRT2)
+            gx = _lib.conv(g1, wp1b, bwd_kinds('3x3', x.shape[0], w1, x.shape[2], x.shape[3])[1], w1.shape[1], x.shape[2], x.shape[3],
+                           None, None, None, 0, res=gx_b, mask_ref=x if ctx.stem else None, mask_gain=_SQRT2)
         if ctx.stem:
             gpre, gx = gx, None                               # gradient w.r.t. the stem's pre-activation
             M = w0.shape[0]
