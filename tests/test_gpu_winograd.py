@@ -47,12 +47,15 @@ def test_winograd_epilogue_stages_equal_the_direct_kernel(act, epi):
     x = synth.normal((B, K, H, W), 'wino.ex').to(DEV)
     w = (synth.normal((M, K, 3, 3), 'wino.ew') / (3 * math.sqrt(K))).to(DEV)
     isc, osc = (1 + 0.3 * synth.normal((B, K), 'wino.ei')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'wino.eo')).to(DEV)
+    if epi != 'plain':          # (the direct kernel has the residual / mask stages for unmodulated launches only: the discriminator's)
+        isc, osc = None, None
     bias = synth.normal((M,), 'wino.eb').to(DEV)
     res = synth.normal((B, M, H, W), 'wino.er').to(DEV) if epi != 'plain' else None
     mref = synth.normal((B, M, H, W), 'wino.em').to(DEV) if epi == 'res+mask' else None
     a = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_WFWD), _lib.CONV_3X3W, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
     b = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
-    pre = F.conv2d(x.double() * isc.double()[:, :, None, None], w.double(), padding=1) * osc.double()[:, :, None, None] + bias.double()[None, :, None, None]
+    one = lambda t, n: t.double() if t is not None else torch.ones(B, n, device=DEV, dtype=torch.float64)
+    pre = F.conv2d(x.double() * one(isc, K)[:, :, None, None], w.double(), padding=1) * one(osc, M)[:, :, None, None] + bias.double()[None, :, None, None]
     if act:
         # a pre-activation within round-off of the kink may take the other slope in the two kernels: compare away from it
         keep = pre.abs() > 1e-4
