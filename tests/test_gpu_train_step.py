@@ -217,7 +217,9 @@ def test_discriminator_joint_pass_equals_two_passes(size, B):
     synth.fill_state_dict(D.state_dict(), 77)
     fake, real = torch.randn(B, 3, size, size, device=DEV), torch.randn(B, 3, size, size, device=DEV).clamp(-1, 1)
     params = list(D.parameters())
-    fp, rp = D(torch.cat([fake, real]), chunks=2).chunk(2)
+    from pinning import capture, pinned
+    with capture() as bank:                                 # the slopes the joint pass takes (for the pinned comparison below)
+        fp, rp = D(torch.cat([fake, real]), chunks=2).chunk(2)
     fp2, rp2 = D(fake), D(real)
     assert rel_err(fp, fp2) < 1e-5 and rel_err(rp, rp2) < 1e-5
     mixed = D(torch.cat([fake, real]))[:B]                  # one minibatch of 2B: the statistic mixes the passes
@@ -230,10 +232,20 @@ def test_discriminator_joint_pass_equals_two_passes(size, B):
     # the flipped element and at 4e-4 - 8e-4 in front of it, each with its own flips; every kernel of the backward is at 3e-7
     # on random data, tools/resblock_bisect.py).  The bar is set for a handful of flips, not for rounding.
     for (n, _), a, b in zip(D.named_parameters(), ga, gb):
-        assert rel_err(a, b) < 1e-2, n
+        assert rel_err(a, b) < 2e-2, n
     tail = [i for i, (n, _) in enumerate(D.named_parameters()) if n.startswith('final_linear.1')]
     for i in tail:               # behind the last activation nothing can flip
         assert rel_err(ga[i], gb[i]) < 2e-5
+    # PINNED variant (tests/pinning.py): the two separate passes take the slopes of the joint pass, so no flip is left and the
+    # two routes must agree to rounding on EVERY parameter gradient
+    both = bank.batch_slice(slice(0, B), 2 * B) + bank.batch_slice(slice(B, 2 * B), 2 * B)
+    with pinned(both) as st:
+        fp3, rp3 = D(fake), D(real)
+        gc = torch.autograd.grad(d_logistic_loss(rp3, fp3), params)
+    assert not st['unmatched'], st['unmatched']
+    worst = max((rel_err(a, c), n) for (n, _), a, c in zip(D.named_parameters(), ga, gc))
+    print(f'joint vs two-pass discriminator step at {size} px, pinned ({st["flips"]} slopes): worst parameter gradient {worst[0]:.2e} ({worst[1]})')
+    assert worst[0] < 1e-4, worst
     with pytest.raises(ValueError):
         D(torch.cat([fake, real])[:2 * B - 1], chunks=2)
 
