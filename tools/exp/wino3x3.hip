@@ -25,29 +25,34 @@
 #ifndef WOCC
 #define WOCC 2
 #endif
+#ifndef WNR          // waves along the rows of the tile: 2 -> 256 threads, 4 rows; 4 -> 512 threads, 8 rows
+#define WNR 2
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int KC = WKC, TH = 4, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
+constexpr int NTHR = 128 * WNR;
+constexpr int KC = WKC, TH = 2 * WNR, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
 constexpr int T_FLOATS = KC * 4 * RS;
 constexpr int U_FLOATS = 3 * 4 * KC * BM;
 constexpr int IMG = T_FLOATS + U_FLOATS;
-constexpr int N_IN = (KC * RS + 255) / 256;               // input items (channel, row, pair) per thread
-constexpr int N_W4 = U_FLOATS / 4 / 256;                  // weight float4 per thread
-constexpr bool IN_EXACT = (KC * RS) % 256 == 0;
+constexpr int N_IN = (KC * RS + NTHR - 1) / NTHR;               // input items (channel, row, pair) per thread
+constexpr int N_W4 = U_FLOATS / 4 / NTHR;                  // weight float4 per thread
+constexpr bool IN_EXACT = (KC * RS) % NTHR == 0;
+static_assert(U_FLOATS % (4 * NTHR) == 0, "weight staging split");
 
 struct WinoArgs {
     float* out; const float* in; const float* U; const float* isc;
     int B, K, M, H, W;
 };
 
-__global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
+__global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wm = wid >> 1, wr = wid & 1;
+    const int wm = wid / WNR, wr = wid % WNR;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH, mblocks = p.M / BM;
     int t = blockIdx.x;
     const int mb = t % mblocks; t /= mblocks;
@@ -70,12 +75,12 @@ __global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
     int g_off[N_IN], l_off[N_IN];
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NTHR * i;
         const int pr = e % NP, row = (e / NP) % (TH + 2), ch = e / RS;
         g_off[i] = (ch * p.H + (y0 - 1 + row)) * p.W + x0 + 2 * pr - 1;
         l_off[i] = (IN_EXACT || e < KC * RS) ? ch * 4 * RS + row * NP + pr : -1;
     }
-    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * 8 * M
+    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * (NTHR / 32) * M
     const int stage_in = KC * p.H * p.W, stage_w = 3 * 4 * KC * p.M;
     f32x4 rin[N_IN];
     float rsc[N_IN];
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
             if (!IN_EXACT && l_off[i] < 0) continue;
-            const int e = tid + 256 * i, ch = e / RS;
+            const int e = tid + NTHR * i, ch = e / RS;
             rsc[i] = iscb ? iscb[s * KC + ch] : 1.f;
             if (!edge) {
                 rin[i] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
         }
         const float* us = p.U + (size_t)s * stage_w + w_off;
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * 8 * p.M);
+        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * (NTHR / 32) * p.M);
     };
     auto commit = [&](float* img) {
         float* Tl = img;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, WOCC) void wino3x3_kernel(const WinoArgs p) {
             dst[3 * RS] = d1 - d3;
         }
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(Ul + 4 * (tid + 256 * i)) = rw[i];
+        for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(Ul + 4 * (tid + NTHR * i)) = rw[i];
     };
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;          // + (2 ks * 4 + c) * RS + ky * NP
@@ -183,7 +188,7 @@ extern "C" int wino3x3_f32(float* out, const float* in, const float* U, const fl
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)wino3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const int64_t blocks = (int64_t)B * (H / TH) * (W / TW) * (M / BM);
-    wino3x3_kernel<<<dim3((unsigned)blocks), 256, lds, (hipStream_t)stream>>>(a);
+    wino3x3_kernel<<<dim3((unsigned)blocks), NTHR, lds, (hipStream_t)stream>>>(a);
     return (int)hipGetLastError();
 }
 

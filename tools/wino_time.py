@@ -14,11 +14,11 @@ from transeditor_amd import _lib      # noqa: E402
 SRC = os.path.join(ROOT, 'tools/exp/wino3x3.hip')
 
 
-def load(kc, db, occ, extra=()):
-    so = os.path.join(ROOT, f'tools/exp/libwino_{kc}_{db}_{occ}{"_" + "".join(extra).replace("-D", "").replace("=", "") if extra else ""}.so')
+def load(kc, db, occ, nr=2, extra=()):
+    so = os.path.join(ROOT, f'tools/exp/libwino_{kc}_{db}_{occ}_{nr}{"_" + "".join(extra).replace("-D", "").replace("=", "") if extra else ""}.so')
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DWKC={kc}',
-                               f'-DWDB={db}', f'-DWOCC={occ}', *extra, SRC, '-o', so])
+                               f'-DWDB={db}', f'-DWOCC={occ}', f'-DWNR={nr}', *extra, SRC, '-o', so])
     W = C.CDLL(so)
     W.wino3x3_f32.restype = C.c_int
     W.wino3x3_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
@@ -43,7 +43,7 @@ def transform_weights(w, kc):
     return u.reshape(3, 4, K // kc, kc, M).permute(2, 0, 1, 3, 4).contiguous()
 
 
-VARIANTS = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 0, 2), (4, 1, 2), (8, 1, 1), (4, 0, 2)]
+VARIANTS = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 0, 2, 2), (8, 1, 1, 4), (8, 0, 1, 4), (4, 1, 2, 4)]
 SHAPES = ((16, 128, 128, 256), (16, 256, 256, 128), (16, 512, 512, 64))
 for B, K, M, H in SHAPES:
     torch.manual_seed(0)
@@ -56,8 +56,8 @@ for B, K, M, H in SHAPES:
     t_d = timeit(lambda: _lib.conv(x, wp, _lib.CONV_3X3, M, H, H, isc, None, None, 0))
     print(f'B{B} {K}->{M} @{H}: direct {t_d * 1e3:8.1f} us {flops / t_d / 1e9:6.1f} TF/s', flush=True)
     st = torch.cuda.current_stream().cuda_stream
-    for kc, db, occ in VARIANTS:
-        W = load(kc, db, occ)
+    for kc, db, occ, nr in VARIANTS:
+        W = load(kc, db, occ, nr)
         U = transform_weights(w, kc)
         out = torch.empty_like(ref)
         run = lambda: W.wino3x3_f32(out.data_ptr(), x.data_ptr(), U.data_ptr(), isc.data_ptr(), B, K, M, H, H, st)
@@ -65,5 +65,5 @@ for B, K, M, H in SHAPES:
         torch.cuda.synchronize()
         err = float((out - ref).abs().max() / ref.abs().max())
         t_w = timeit(run)
-        print(f'    winograd KC={kc} DB={db} occ={occ}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
+        print(f'    winograd KC={kc} DB={db} occ={occ} rows={2 * nr}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
               f'MFMA-equivalent {flops / t_w / 1e9 / 1.5:6.1f}', flush=True)
