@@ -43,6 +43,18 @@ def transform_weights(w, kc):
     return u.reshape(3, 4, K // kc, kc, M).permute(2, 0, 1, 3, 4).contiguous()
 
 
+def load_pp(src='tools/exp/wino_pp.hip', flags=()):
+    so = os.path.join(ROOT, src.replace('.hip', '') + ''.join(flags).replace('-D', '_').replace('=', '') + '.so')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(ROOT, src)):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', *flags, os.path.join(ROOT, src), '-o', so])
+    W = C.CDLL(so)
+    W.wino3x3_f32.restype = C.c_int
+    W.wino3x3_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
+    return W
+
+
+PP = [a for a in sys.argv[1:] if a.startswith('pp')]
+sys.argv = [a for a in sys.argv if not a.startswith('pp')]
 VARIANTS = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(8, 0, 2, 2), (8, 1, 1, 4), (8, 0, 1, 4), (4, 1, 2, 4)]
 SHAPES = ((16, 128, 128, 256), (16, 256, 256, 128), (16, 512, 512, 64))
 for B, K, M, H in SHAPES:
@@ -56,6 +68,17 @@ for B, K, M, H in SHAPES:
     t_d = timeit(lambda: _lib.conv(x, wp, _lib.CONV_3X3, M, H, H, isc, None, None, 0))
     print(f'B{B} {K}->{M} @{H}: direct {t_d * 1e3:8.1f} us {flops / t_d / 1e9:6.1f} TF/s', flush=True)
     st = torch.cuda.current_stream().cuda_stream
+    for spec in PP:
+        W = load_pp(flags=tuple(f'-D{f}' for f in spec.split(':')[1:]))
+        U = transform_weights(w, 8)
+        out = torch.empty_like(ref)
+        run = lambda: W.wino3x3_f32(out.data_ptr(), x.data_ptr(), U.data_ptr(), isc.data_ptr(), B, K, M, H, H, st)
+        rc = run()
+        torch.cuda.synchronize()
+        err = float((out - ref).abs().max() / ref.abs().max())
+        t_w = timeit(run)
+        print(f'    winograd ping-pong {spec}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
+              f'MFMA-equivalent {flops / t_w / 1e9 / 1.5:6.1f}', flush=True)
     for kc, db, occ, nr in VARIANTS:
         W = load(kc, db, occ, nr)
         U = transform_weights(w, kc)
