@@ -110,21 +110,30 @@ __global__ __launch_bounds__(512, 1) void wino3x3_kernel(const WinoArgs p) {
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;
     const int a_off = half * BM + wm * 64 + l31;
+#ifndef WAHEAD
+#define WAHEAD 1          // LDS operand reads this many steps ahead of the MFMAs that consume them (a step = one (ks, ky, c): two MFMAs)
+#endif
     auto mfmas = [&](int s) {
         const float* ul = Ubuf + (s & 1) * U_FLOATS + a_off;
         const float* tl = Tl + b_off;
+        constexpr int NST = (KC / 2) * 12;
+        float a0[WAHEAD + 1], a1[WAHEAD + 1], bb[WAHEAD + 1];
+        auto rd = [&](int st, int slot) {
+            const int ks = st / 12, ky = (st % 12) / 4, c = st % 4;
+            bb[slot] = tl[(2 * ks * 4 + c) * RS + ky * NP];
+            const float* ua = ul + ((ky * 4 + c) * KC + 2 * ks) * BM;
+            a0[slot] = ua[0]; a1[slot] = ua[32];
+        };
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
+        for (int i = 0; i < WAHEAD; ++i) rd(i, i);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float bv = tl[(2 * ks * 4 + c) * RS + ky * NP];
-                    const float* ua = ul + ((ky * 4 + c) * KC + 2 * ks) * BM;
-                    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[0], bv, acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[32], bv, acc[1][c], 0, 0, 0);
-                }
-            }
+        for (int st = 0; st < NST; ++st) {
+            if (st + WAHEAD < NST) rd(st + WAHEAD, (st + WAHEAD) % (WAHEAD + 1));
+            __builtin_amdgcn_sched_barrier(0);           // keep those reads in front of the MFMAs of step st
+            const int c = st % 4, slot = st % (WAHEAD + 1);
+            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[slot], bb[slot], acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[slot], bb[slot], acc[1][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
