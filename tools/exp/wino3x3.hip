@@ -25,8 +25,11 @@
 #ifndef WOCC
 #define WOCC 2
 #endif
-#ifndef WNR          // waves along the rows of the tile: 2 -> 256 threads, 4 rows; 4 -> 512 threads, 8 rows
+#ifndef WNR          // waves along the rows of the tile: 2 -> 4 rows; 4 -> 8 rows
 #define WNR 2
+#endif
+#ifndef WMT          // 32-row M tiles per wave: 2 (128 accumulator registers, 2 waves along M) or 1 (64 registers, 4 waves along M)
+#define WMT 2
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,7 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int NTHR = 128 * WNR;
+constexpr int NMW = 4 / WMT;          // waves along M
+constexpr int NTHR = 64 * NMW * WNR;
 constexpr int KC = WKC, TH = 2 * WNR, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
 constexpr int T_FLOATS = KC * 4 * RS;
 constexpr int U_FLOATS = 3 * 4 * KC * BM;
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
     const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
     const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
 
-    f32x16 acc[2][4];
+    f32x16 acc[WMT][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WMT; ++mt)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
     };
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;          // + (2 ks * 4 + c) * RS + ky * NP
-    const int a_off = T_FLOATS + half * BM + wm * 64 + l31;             // + ((ky * 4 + c) * KC + 2 ks) * BM
+    const int a_off = T_FLOATS + half * BM + wm * (32 * WMT) + l31;             // + ((ky * 4 + c) * KC + 2 ks) * BM
 #ifndef WPIPE
 #define WPIPE 1
 #endif
@@ -138,19 +142,21 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
             const int ks = ks_from + st / 12, ky = (st % 12) / 4, c = st % 4;
             bb = img[b_off + (2 * ks * 4 + c) * RS + ky * NP];
             const float* ua = img + a_off + ((ky * 4 + c) * KC + 2 * ks) * BM;
-            a0 = ua[0]; a1 = ua[32];
+            a0 = ua[0];
+            if (WMT > 1) a1 = ua[32];
         };
-        float a0c, a1c, bc;
+        float a0c, a1c = 0.f, bc;
         rd(0, a0c, a1c, bc);
 #pragma unroll
         for (int st = 0; st < (KC / 2) * 12; ++st) {
             if (st >= n) break;
             float a0n = a0c, a1n = a1c, bn = bc;
+            (void)a1n;
             if (st + 1 < n) rd(st + 1, a0n, a1n, bn);
             __builtin_amdgcn_sched_barrier(0);           // keep the reads of step i + 1 in front of the MFMAs of step i
             const int c = st % 4;
             acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c, bc, acc[0][c], 0, 0, 0);
-            acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c, bc, acc[1][c], 0, 0, 0);
+            if (WMT > 1) acc[WMT - 1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c, bc, acc[WMT - 1][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a0c = a0n; a1c = a1n; bc = bn;
         }
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
                     const float bv = img[b_off + (2 * ks * 4 + c) * RS + ky * NP];
                     const float* ua = img + a_off + ((ky * 4 + c) * KC + 2 * ks) * BM;
                     acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[0], bv, acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[32], bv, acc[1][c], 0, 0, 0);
+                    if (WMT > 1) acc[WMT - 1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[32], bv, acc[WMT - 1][c], 0, 0, 0);
                 }
             }
         }
@@ -193,10 +199,10 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
         }
     }
     // epilogue: output transform, two adjacent columns per accumulator element
-    float* ob = p.out + ((size_t)b * p.M + mb * BM + wm * 64) * p.H * p.W;
+    float* ob = p.out + ((size_t)b * p.M + mb * BM + wm * (32 * WMT)) * p.H * p.W;
     const int oy = y0 + 2 * wr + rr, ox = x0 + 2 * jj;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WMT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;

@@ -14,11 +14,11 @@ from transeditor_amd import _lib      # noqa: E402
 SRC = os.path.join(ROOT, 'tools/exp/wino3x3.hip')
 
 
-def load(kc, db, occ, nr=2, extra=()):
-    so = os.path.join(ROOT, f'tools/exp/libwino_{kc}_{db}_{occ}_{nr}{"_" + "".join(extra).replace("-D", "").replace("=", "") if extra else ""}.so')
+def load(kc, db, occ, nr=2, mt=2, pipe=1, extra=()):
+    so = os.path.join(ROOT, f'tools/exp/libwino_{kc}_{db}_{occ}_{nr}_{mt}_{pipe}{"_" + "".join(extra).replace("-D", "").replace("=", "") if extra else ""}.so')
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(SRC):
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DWKC={kc}',
-                               f'-DWDB={db}', f'-DWOCC={occ}', f'-DWNR={nr}', *extra, SRC, '-o', so])
+                               f'-DWDB={db}', f'-DWOCC={occ}', f'-DWNR={nr}', f'-DWMT={mt}', f'-DWPIPE={pipe}', *extra, SRC, '-o', so])
     W = C.CDLL(so)
     W.wino3x3_f32.restype = C.c_int
     W.wino3x3_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
@@ -79,8 +79,10 @@ for B, K, M, H in SHAPES:
         t_w = timeit(run)
         print(f'    winograd ping-pong {spec}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
               f'MFMA-equivalent {flops / t_w / 1e9 / 1.5:6.1f}', flush=True)
-    for kc, db, occ, nr in VARIANTS:
-        W = load(kc, db, occ, nr)
+    for var in VARIANTS:
+        kc, db, occ, nr = var[:4]
+        mt, pipe = (var[4] if len(var) > 4 else 2), (var[5] if len(var) > 5 else 1)
+        W = load(kc, db, occ, nr, mt, pipe)
         U = transform_weights(w, kc)
         out = torch.empty_like(ref)
         run = lambda: W.wino3x3_f32(out.data_ptr(), x.data_ptr(), U.data_ptr(), isc.data_ptr(), B, K, M, H, H, st)
@@ -88,5 +90,5 @@ for B, K, M, H in SHAPES:
         torch.cuda.synchronize()
         err = float((out - ref).abs().max() / ref.abs().max())
         t_w = timeit(run)
-        print(f'    winograd KC={kc} DB={db} occ={occ} rows={2 * nr}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
+        print(f'    winograd KC={kc} DB={db} occ={occ} rows={2 * nr} Mtiles/wave={mt} pipe={pipe}: rc {rc} err {err:.2e}  {t_w * 1e3:8.1f} us {flops / t_w / 1e9:6.1f} TF/s (algorithmic), '
               f'MFMA-equivalent {flops / t_w / 1e9 / 1.5:6.1f}', flush=True)
