@@ -136,29 +136,27 @@ __global__ __launch_bounds__(NTHR, WOCC) void wino3x3_kernel(const WinoArgs p) {
 #endif
     auto mfmas = [&](const float* img, int ks_from, int ks_to) {
 #if WPIPE
-        // operands of step i + 1 are read from LDS before the MFMAs of step i are issued (a step = one (ks, ky, c) triple: two MFMAs)
+        // operands of step i + WPIPE are read from LDS before the MFMAs of step i are issued (a step = one (ks, ky, c) triple)
         const int n = (ks_to - ks_from) * 12;
-        auto rd = [&](int st, float& a0, float& a1, float& bb) {
+        float a0[WPIPE + 1], a1[WPIPE + 1], bb[WPIPE + 1];
+        auto rd = [&](int st, int slot) {
             const int ks = ks_from + st / 12, ky = (st % 12) / 4, c = st % 4;
-            bb = img[b_off + (2 * ks * 4 + c) * RS + ky * NP];
+            bb[slot] = img[b_off + (2 * ks * 4 + c) * RS + ky * NP];
             const float* ua = img + a_off + ((ky * 4 + c) * KC + 2 * ks) * BM;
-            a0 = ua[0];
-            if (WMT > 1) a1 = ua[32];
+            a0[slot] = ua[0];
+            if (WMT > 1) a1[slot] = ua[32];
         };
-        float a0c, a1c = 0.f, bc;
-        rd(0, a0c, a1c, bc);
+#pragma unroll
+        for (int i = 0; i < WPIPE; ++i) rd(i, i);
 #pragma unroll
         for (int st = 0; st < (KC / 2) * 12; ++st) {
             if (st >= n) break;
-            float a0n = a0c, a1n = a1c, bn = bc;
-            (void)a1n;
-            if (st + 1 < n) rd(st + 1, a0n, a1n, bn);
-            __builtin_amdgcn_sched_barrier(0);           // keep the reads of step i + 1 in front of the MFMAs of step i
-            const int c = st % 4;
-            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c, bc, acc[0][c], 0, 0, 0);
-            if (WMT > 1) acc[WMT - 1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c, bc, acc[WMT - 1][c], 0, 0, 0);
+            if (st + WPIPE < n) rd(st + WPIPE, (st + WPIPE) % (WPIPE + 1));
+            __builtin_amdgcn_sched_barrier(0);           // keep those reads in front of the MFMAs of step st
+            const int c = st % 4, slot = st % (WPIPE + 1);
+            acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[slot], bb[slot], acc[0][c], 0, 0, 0);
+            if (WMT > 1) acc[WMT - 1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[slot], bb[slot], acc[WMT - 1][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a0c = a0n; a1c = a1n; bc = bn;
         }
 #else
 #pragma unroll
