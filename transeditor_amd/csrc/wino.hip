@@ -14,12 +14,16 @@
 // at 128 - 142 TFLOP/s = 86 % MFMA utilisation at the sustained clock with the direct kernel, i.e. at its ceiling; this
 // kernel reaches 145 - 162 "algorithmic" TFLOP/s at 69 % utilisation (profiles/experiments/r04_winograd_ab.log).
 //
-// Block: 256 threads, output tile 128 (M) x 4 rows x 32 columns (= 64 pairs); wave (wm, wr): 64 output channels x rows
-// {2 wr, 2 wr + 1} x 16 pairs x 4 components = 8 accumulator tiles of v_mfma_f32_32x32x2_f32 (128 registers).  8 input channels
-// per stage; the loads of stage s + 1 are issued before the MFMAs of stage s (register prefetch), transformed and written to
-// the single LDS image after them (two barriers per stage; two blocks share a CU).  Block -> (tile, M block) is XCD-aware like
-// the direct kernel's: the M blocks of a tile run on one XCD and share the input tile through its L2.
-// Epilogue = the direct kernel's: out = (act(osc * conv + bias) + res) * slope(mask_ref).
+// Block: 512 threads = 8 waves, output tile 128 (M) x 4 rows x 32 columns (= 64 pairs); wave (wm, wr): 32 output channels x rows
+// {2 wr, 2 wr + 1} x 16 pairs x 4 components = 4 accumulator tiles of v_mfma_f32_32x32x2_f32 (64 registers), so FOUR waves
+// share a SIMD (two blocks per CU): measured, a SIMD needs several waves issuing MFMAs at the same time - one wave alone streams
+// them at ~58 % of the pipe's rate however its operands are prefetched (the ping-pong design of tools/exp/wino_pp.hip: 88 TFLOP/s
+// MFMA-equivalent), two waves with 128 accumulator registers each reach 69 %, four waves with 64 each 75 %
+// (profiles/experiments/r04_winograd_ab.log).  8 input channels per stage; the loads of stage s + 1 are issued before the MFMAs
+// of stage s (register prefetch), transformed and written to the single LDS image after them (two barriers per stage); inside
+// the MFMA loop the LDS operands of step i + 1 are read before the MFMA of step i is issued (sched_barrier-pinned).  Block ->
+// (tile, M block) is XCD-aware like the direct kernel's: the M blocks of a tile run on one XCD and share the input tile through
+// its L2.  Epilogue = the direct kernel's: out = (act(osc * conv + bias) + res) * slope(mask_ref).
 #include "conv_common.h"
 
 namespace {
@@ -27,12 +31,14 @@ namespace {
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int WT = 512;                                   // threads per block (8 waves)
 constexpr int KC = 8, TH = 4, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
 constexpr int T_FLOATS = KC * 4 * RS;                     // transformed input tile  [KC][4][TH + 2][NP]
 constexpr int U_FLOATS = 3 * 4 * KC * BM;                 // transformed weights     [3][4][KC][BM]
-constexpr int N_IN = KC * RS / NTHREADS;                  // input items (channel, row, pair) per thread: 3
-constexpr int N_W4 = U_FLOATS / 4 / NTHREADS;             // weight float4 per thread: 12
-static_assert(KC * RS % NTHREADS == 0 && U_FLOATS % (4 * NTHREADS) == 0, "staging split");
+constexpr int N_ITEMS = KC * RS;                          // input items (channel, row, pair) of a stage: 768
+constexpr int N_IN = (N_ITEMS + WT - 1) / WT;             // ... per thread: 2 (the second one only for the first 256 threads)
+constexpr int N_W4 = U_FLOATS / 4 / WT;                   // weight float4 per thread: 6
+static_assert(U_FLOATS % (4 * WT) == 0, "staging split");
 
 struct WinoArgs {
     float* out; const float* in; const float* U; const float* isc; const float* osc; const float* bias; const float* res;
@@ -40,10 +46,10 @@ struct WinoArgs {
     int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) {
+__global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wm = wid >> 1, wr = wid & 1;
+    const int wm = wid >> 1, wr = wid & 1;                     // wm 0..3: 32 output channels each
     // block -> (cell tile, M block): the j-th block of XCD x takes tile (j / mblocks) * 8 + x and M block j % mblocks
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int tile = (jx / p.mblocks) * 8 + xcd, mb = jx % p.mblocks;
@@ -54,24 +60,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) 
     const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
     const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
 
-    f32x16 acc[2][4];
+    f32x16 acc[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][c][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     // staging geometry: item e = tid + 256 i -> (channel, row, pair); one element offset and one LDS offset per item
     int g_off[N_IN], l_off[N_IN];
 #pragma unroll
     for (int i = 0; i < N_IN; ++i) {
-        const int e = tid + NTHREADS * i;
+        const int e = tid + WT * i;
         const int pr = e % NP, row = (e / NP) % (TH + 2), ch = e / RS;
         g_off[i] = (ch * p.H + (y0 - 1 + row)) * p.W + x0 + 2 * pr - 1;
-        l_off[i] = ch * 4 * RS + row * NP + pr;
+        l_off[i] = e < N_ITEMS ? ch * 4 * RS + row * NP + pr : -1;
     }
-    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * 8 * M
+    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * 16 * M
     const size_t stage_in = (size_t)KC * p.H * p.W, stage_w = (size_t)3 * 4 * KC * p.M;
     f32x4 rin[N_IN];
     float rsc[N_IN];
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) 
         const float* base = inb + s * stage_in;
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
-            const int e = tid + NTHREADS * i, ch = e / RS;
+            if (l_off[i] < 0) continue;
+            const int e = tid + WT * i, ch = e / RS;
             rsc[i] = iscb ? iscb[s * KC + ch] : 1.f;
             if (!edge) {
                 rin[i] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
@@ -95,11 +100,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) 
         }
         const float* us = p.U + s * stage_w + w_off;
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * 8 * p.M);
+        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * 16 * p.M);
     };
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < N_IN; ++i) {
+            if (l_off[i] < 0) continue;
             const float sc = rsc[i];
             const float d0 = rin[i][0] * sc, d1 = rin[i][1] * sc, d2 = rin[i][2] * sc, d3 = rin[i][3] * sc;
             float* dst = smem + l_off[i];
@@ -109,28 +115,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) 
             dst[3 * RS] = d1 - d3;
         }
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(smem + T_FLOATS + 4 * (tid + NTHREADS * i)) = rw[i];
+        for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(smem + T_FLOATS + 4 * (tid + WT * i)) = rw[i];
     };
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;          // + (2 ks * 4 + c) * RS + ky * NP
-    const int a_off = T_FLOATS + half * BM + wm * 64 + l31;             // + ((ky * 4 + c) * KC + 2 ks) * BM
+    const int a_off = T_FLOATS + half * BM + wm * 32 + l31;             // + ((ky * 4 + c) * KC + 2 ks) * BM
 
     issue(0);
     commit();
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
         if (s + 1 < nstage) issue(s + 1);
+        // 48 steps (ks, ky, c), one MFMA each; the operands of step i + 1 are read before the MFMA of step i is issued
+        {
+            constexpr int NST = (KC / 2) * 12;
+            float av[2], bv[2];
+            auto rd = [&](int st, int slot) {
+                const int ks = st / 12, ky = (st % 12) / 4, c = st % 4;
+                bv[slot] = smem[b_off + (2 * ks * 4 + c) * RS + ky * NP];
+                av[slot] = smem[a_off + ((ky * 4 + c) * KC + 2 * ks) * BM];
+            };
+            rd(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float bv = smem[b_off + (2 * ks * 4 + c) * RS + ky * NP];
-                    const float* ua = smem + a_off + ((ky * 4 + c) * KC + 2 * ks) * BM;
-                    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[0], bv, acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[32], bv, acc[1][c], 0, 0, 0);
-                }
+            for (int st = 0; st < NST; ++st) {
+                if (st + 1 < NST) rd(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);       // keep those reads in front of the MFMA of step st
+                acc[st % 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1], bv[st & 1], acc[st % 4], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -138,38 +149,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino3x3_kernel(const WinoArgs p) 
         __syncthreads();
     }
     // epilogue: output transform (two adjacent columns per accumulator element), then the direct kernel's epilogue stages
-    const int mbase = mb * BM + wm * 64;
+    const int mbase = mb * BM + wm * 32;
     const size_t plane = (size_t)p.H * p.W;
     const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
     const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dm = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = mbase + dm;
-            float v0 = acc[mt][0][r] + acc[mt][1][r] + acc[mt][2][r];
-            float v1 = acc[mt][1][r] - acc[mt][2][r] - acc[mt][3][r];
-            const float sc = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f, bi = p.bias ? p.bias[m] : 0.f;
-            v0 = v0 * sc + bi;
-            v1 = v1 * sc + bi;
-            if (p.act >= 3) {
-                v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
-                v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
-            }
-            const size_t o = off0 + (size_t)dm * plane;
-            if (p.res) {
-                const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + o);
-                v0 += rv[0]; v1 += rv[1];
-            }
-            if (p.mref) {
-                const f32x2 q = *reinterpret_cast<const f32x2*>(p.mref + o);
-                v0 *= q[0] > 0.f ? p.mgain : 0.2f * p.mgain;
-                v1 *= q[1] > 0.f ? p.mgain : 0.2f * p.mgain;
-            }
-            f32x2 v; v[0] = v0; v[1] = v1;
-            *reinterpret_cast<f32x2*>(p.out + o) = v;
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = mbase + dm;
+        float v0 = acc[0][r] + acc[1][r] + acc[2][r];
+        float v1 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float sc = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f, bi = p.bias ? p.bias[m] : 0.f;
+        v0 = v0 * sc + bi;
+        v1 = v1 * sc + bi;
+        if (p.act >= 3) {
+            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
         }
+        const size_t o = off0 + (size_t)dm * plane;
+        if (p.res) {
+            const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + o);
+            v0 += rv[0]; v1 += rv[1];
+        }
+        if (p.mref) {
+            const f32x2 q = *reinterpret_cast<const f32x2*>(p.mref + o);
+            v0 *= q[0] > 0.f ? p.mgain : 0.2f * p.mgain;
+            v1 *= q[1] > 0.f ? p.mgain : 0.2f * p.mgain;
+        }
+        f32x2 v; v[0] = v0; v[1] = v1;
+        *reinterpret_cast<f32x2*>(p.out + o) = v;
     }
 }
 
@@ -196,6 +204,6 @@ int te_wino_launch(float* out, const float* in, const float* U, const float* isc
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wino3x3_kernel, 96 * 1024);
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    wino3x3_kernel<<<dim3((unsigned)blocks), NTHREADS, lds, s>>>(a);
+    wino3x3_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
     return te::launch_status("te_conv_f32(TE_CONV_3X3W)");
 }
