@@ -15,7 +15,9 @@ from transeditor_amd import _lib, synth
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
-SHAPES = [(2, 8, 128, 4, 32), (1, 16, 128, 8, 64), (3, 24, 256, 12, 32), (2, 128, 128, 32, 32), (2, 64, 384, 16, 96), (1, 512, 512, 32, 32)]
+SHAPES = [(2, 8, 128, 4, 32), (1, 16, 128, 8, 64), (3, 24, 256, 12, 32), (2, 128, 128, 32, 32), (2, 64, 384, 16, 96), (1, 512, 512, 32, 32),
+          # 64- and 32-row M blocks (8 / 16 rows per tile): the narrow layers of the FFHQ-1024 tail
+          (2, 16, 64, 8, 32), (1, 64, 64, 32, 64), (2, 32, 32, 16, 32), (1, 64, 32, 64, 64), (1, 32, 96, 32, 32), (1, 8, 192, 24, 32)]
 
 
 @pytest.mark.parametrize('B,K,M,H,W', SHAPES)

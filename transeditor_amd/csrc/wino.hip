@@ -32,13 +32,21 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WT = 512;                                   // threads per block (8 waves)
-constexpr int KC = 8, TH = 4, TW = 32, NP = TW / 2, BM = 128, RS = (TH + 2) * NP;     // RS: floats per (channel, component) plane
-constexpr int T_FLOATS = KC * 4 * RS;                     // transformed input tile  [KC][4][TH + 2][NP]
-constexpr int U_FLOATS = 3 * 4 * KC * BM;                 // transformed weights     [3][4][KC][BM]
-constexpr int N_ITEMS = KC * RS;                          // input items (channel, row, pair) of a stage: 768
-constexpr int N_IN = (N_ITEMS + WT - 1) / WT;             // ... per thread: 2 (the second one only for the first 256 threads)
-constexpr int N_W4 = U_FLOATS / 4 / WT;                   // weight float4 per thread: 6
-static_assert(U_FLOATS % (4 * WT) == 0, "staging split");
+constexpr int KC = 8, TW = 32, NP = TW / 2;
+// Block tile BM (M) x TH rows x 32 columns; the 8 waves split as (BM / 32 along M) x (TH / 2 row pairs):
+//   BM = 128: 4 x 2, TH = 4      BM = 64: 2 x 4, TH = 8      BM = 32: 1 x 8, TH = 16
+// (64- and 32-channel layers - the FFHQ-1024 tail - keep eight waves busy by covering more rows per block)
+template <int BM> struct Geo {
+    static constexpr int NMW = BM / 32, WNR = 8 / NMW, TH = 2 * WNR;
+    static constexpr int RS = (TH + 2) * NP;               // floats per (channel, component) plane
+    static constexpr int T_FLOATS = KC * 4 * RS;           // transformed input tile  [KC][4][TH + 2][NP]
+    static constexpr int U_FLOATS = 3 * 4 * KC * BM;       // transformed weights     [3][4][KC][BM]
+    static constexpr int N_ITEMS = KC * RS;                // input items (channel, row, pair) of a stage
+    static constexpr int N_IN = (N_ITEMS + WT - 1) / WT;   // ... per thread (the last one bounds-checked)
+    static constexpr int N_W4T = U_FLOATS / 4;             // weight float4 of a stage
+    static constexpr int N_W4 = (N_W4T + WT - 1) / WT;     // ... per thread (bounds-checked for BM = 32)
+    static constexpr int C4 = BM / 4;                      // float4 per weight row
+};
 
 struct WinoArgs {
     float* out; const float* in; const float* U; const float* isc; const float* osc; const float* bias; const float* res;
@@ -46,10 +54,13 @@ struct WinoArgs {
     int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y;
 };
 
+template <int BM>
 __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
+    typedef Geo<BM> G;
+    constexpr int TH = G::TH, RS = G::RS, T_FLOATS = G::T_FLOATS, N_ITEMS = G::N_ITEMS, N_IN = G::N_IN, N_W4 = G::N_W4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int wm = wid >> 1, wr = wid & 1;                     // wm 0..3: 32 output channels each
+    const int wm = wid / G::WNR, wr = wid % G::WNR;            // wm: 32 output channels each; wr: a pair of rows
     // block -> (cell tile, M block): the j-th block of XCD x takes tile (j / mblocks) * 8 + x and M block j % mblocks
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int tile = (jx / p.mblocks) * 8 + xcd, mb = jx % p.mblocks;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
         g_off[i] = (ch * p.H + (y0 - 1 + row)) * p.W + x0 + 2 * pr - 1;
         l_off[i] = e < N_ITEMS ? ch * 4 * RS + row * NP + pr : -1;
     }
-    const int w_off = (tid >> 5) * p.M + mb * BM + 4 * (tid & 31);          // float4 i: + i * 16 * M
+    // weights: float4 idx = tid + 512 i -> row idx / C4 (of 96), column 4 (idx % C4)
     const size_t stage_in = (size_t)KC * p.H * p.W, stage_w = (size_t)3 * 4 * KC * p.M;
     f32x4 rin[N_IN];
     float rsc[N_IN];
@@ -98,9 +109,13 @@ __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
                 for (int q = 0; q < 4; ++q) rin[i][q] = (rowok && gx + q >= 0 && gx + q < p.W) ? base[g_off[i] + q] : 0.f;
             }
         }
-        const float* us = p.U + s * stage_w + w_off;
+        const float* us = p.U + s * stage_w + mb * BM;
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)i * 16 * p.M);
+        for (int i = 0; i < N_W4; ++i) {
+            const int idx = tid + WT * i;
+            if (G::N_W4T % WT == 0 || idx < G::N_W4T)
+                rw[i] = *reinterpret_cast<const f32x4*>(us + (size_t)(idx / G::C4) * p.M + 4 * (idx % G::C4));
+        }
     };
     auto commit = [&]() {
 #pragma unroll
@@ -115,7 +130,10 @@ __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
             dst[3 * RS] = d1 - d3;
         }
 #pragma unroll
-        for (int i = 0; i < N_W4; ++i) *reinterpret_cast<f32x4*>(smem + T_FLOATS + 4 * (tid + WT * i)) = rw[i];
+        for (int i = 0; i < N_W4; ++i) {
+            const int idx = tid + WT * i;
+            if (G::N_W4T % WT == 0 || idx < G::N_W4T) *reinterpret_cast<f32x4*>(smem + T_FLOATS + 4 * idx) = rw[i];
+        }
     };
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_off = half * 4 * RS + (2 * wr + rr) * NP + jj;          // + (2 ks * 4 + c) * RS + ky * NP
@@ -183,27 +201,43 @@ __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
 
 }  // namespace
 
+static int wino_bm(int M) { return M % 128 == 0 ? 128 : (M % 64 == 0 ? 64 : (M % 32 == 0 ? 32 : 0)); }
+
 extern "C" int te_conv_wino_supported(int B, int K, int M, int H, int W) {
-    return (B > 0 && K >= KC && K % KC == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0 &&
-            (int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
+    if (!(B > 0 && K >= KC && K % KC == 0 && M > 0 && H > 0 && W >= TW && W % TW == 0)) return 0;
+    const int bm = wino_bm(M);
+    if (!bm) return 0;
+    const int th = 2 * (8 / (bm / 32));
+    return (H % th == 0 && (int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / th) * (W / TW) * (M / bm) < 0x7FFFFFF0) ? 1 : 0;
+}
+
+template <int BM>
+static void wino_launch_t(WinoArgs a, hipStream_t s) {
+    typedef Geo<BM> G;
+    a.tiles_x = a.W / TW; a.tiles_y = a.H / G::TH; a.mblocks = a.M / BM;
+    a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    const size_t lds = sizeof(float) * (G::T_FLOATS + G::U_FLOATS);
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)wino3x3_kernel<BM>, 96 * 1024);
+    const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
+    wino3x3_kernel<BM><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
 }
 
 int te_wino_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                    const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s) {
     TE_REQUIRE(te_conv_wino_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
-               "te_conv_f32(TE_CONV_3X3W): needs K %% 8 == 0, M %% 128 == 0, H %% 4 == 0, W %% 32 == 0 (te_conv_wino_supported)");
+               "te_conv_f32(TE_CONV_3X3W): needs K %% 8 == 0, M %% 32 == 0, W %% 32 == 0 and H a multiple of the tile height "
+               "(te_conv_wino_supported)");
     TE_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(res) |
                  reinterpret_cast<uintptr_t>(mask_ref)) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_3X3W): 16-byte aligned tensors required");
     WinoArgs a{};
     a.out = out; a.in = in; a.U = U; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
-    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
-    a.ntiles = B * a.tiles_x * a.tiles_y;
-    const size_t lds = sizeof(float) * (T_FLOATS + U_FLOATS);
-    static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)wino3x3_kernel, 96 * 1024);
-    const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    wino3x3_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    switch (wino_bm(M)) {
+        case 128: wino_launch_t<128>(a, s); break;
+        case 64: wino_launch_t<64>(a, s); break;
+        default: wino_launch_t<32>(a, s); break;
+    }
     return te::launch_status("te_conv_f32(TE_CONV_3X3W)");
 }
