@@ -144,7 +144,7 @@ class KernelTimer:
                 'achieved_note': 'achieved = ALGORITHMIC FLOPs (2 * 9 * K * M * H * W * B per launch) / measured time.  The 3x3 stride-1 '
                                  'launches from 32x32 up run the 1-D Winograd F(2,3) form (csrc/wino.hip), which executes 2/3 of those '
                                  'multiply-adds on the matrix pipe: their class can exceed the 157.3 TFLOP/s of executed work; '
-                                 'executed_tflops / executed_frac price the MFMA work actually issued',',
+                                 'executed_tflops / executed_frac price the MFMA work actually issued',
                 'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
                 'algorithmic_gflop_per_step': gflop / steps,
                 'whole_step_tflops': gflop / 1e3 / wall_s if wall_s else None,
