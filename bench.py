@@ -108,7 +108,9 @@ class KernelTimer:
             s.record()
             out = orig_wgrad(g, x, kind, H, W, *a, **k)
             e.record()
-            timer.records.append(('wgrad_' + names[kind], flops, s, e, flops))
+            # (the pair form of the 3x3 weight gradient: 12/18 of the direct form's multiply-adds, as above)
+            timer.records.append(('wgrad_' + names[kind], flops, s, e,
+                                  flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0)))
             return out
 
         _lib.conv, _lib.wgrad_slabs = conv, wgrad
@@ -143,7 +145,8 @@ class KernelTimer:
                 'executed_tflops': executed, 'executed_frac': executed / PEAK_FP32_TFLOPS,
                 'achieved_note': 'achieved = ALGORITHMIC FLOPs (2 * 9 * K * M * H * W * B per launch) / measured time.  The 3x3 stride-1 '
                                  'launches from 32x32 up run the 1-D Winograd F(2,3) form (csrc/wino.hip), which executes 2/3 of those '
-                                 'multiply-adds on the matrix pipe: their class can exceed the 157.3 TFLOP/s of executed work; '
+                                 'multiply-adds on the matrix pipe (and so does the pair form, F(3,2), of the 3x3 weight gradient on the 8-wave tile): '
+                                 'those classes can exceed the 157.3 TFLOP/s of executed work; '
                                  'executed_tflops / executed_frac price the MFMA work actually issued',
                 'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
                 'algorithmic_gflop_per_step': gflop / steps,

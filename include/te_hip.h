@@ -193,6 +193,10 @@ int te_conv_res_f32(float* out, float* ws, const float* in, const float* wp, con
  * te_wgrad_slab_count returns S (chunks per sample) for the given problem; the caller allocates
  * slabs[B][S][Co][Ci][taps] and reduces them with te_wgrad_reduce_f32. */
 int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W);
+/* 1 when te_wgrad_f32 / te_wgrad_group_f32 run this problem in the PAIR form (3x3 only: horizontal cell pairs, the three taps of
+ * a kernel row from four products per pair - 1-D Winograd F(3,2) - i.e. 2/3 of the direct form's multiply-adds on the matrix
+ * pipe for the same slabs), else 0.  Only a report for FLOP accounting (bench.py): results and slab layout do not depend on it. */
+int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W);
 int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H,
                  int W, int S, te_stream_t stream);
 /* GROUPED form for the PLAIN (unmodulated) weight gradient of small images: NB consecutive samples share one slab

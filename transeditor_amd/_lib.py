@@ -42,6 +42,7 @@ _SIGNATURES = {
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
+    'te_wgrad_pair_form': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_group_plan': (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P]),
     'te_wgrad_group_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -381,6 +382,11 @@ def wgrad_slabs(g, x, kind, H, W, group=False):
     slabs = torch.empty(B, S, Co, Ci, taps, device=g.device, dtype=g.dtype)
     _check(lib().te_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), kind, B, Co, Ci, H, W, S, _stream()), 'te_wgrad_f32')
     return slabs
+
+
+def wgrad_pair_form(kind, Co, Ci, H, W):
+    """does the weight-gradient kernel take the pair (Winograd F(3,2)) form for this problem?  (FLOP accounting only)"""
+    return bool(lib().te_wgrad_pair_form(kind, Co, Ci, H, W))
 
 
 def wgrad_reduce(slabs, w, wscale=1.0, isc=None, osc=None, want_w=True, want_isc=False, want_osc=False):

@@ -7,8 +7,8 @@
 //   T2        : cells = low-res pixels;    g at (2i+ky, 2j+kx) (shifted),    x at (i,j) (plain)
 //
 // GEMM view: rows = co (A operand = g), cols = ci (B operand = x), reduction = cells, one 32x32 accumulator
-// per tap -> each wave owns 1 x 1 x NTAP tiles (144 accumulator registers for 3x3); a block of 4 waves covers
-// 64 co x 64 ci.  The reduction over cells is split over blocks (per sample b, S chunks per sample) and every
+// per tap -> each wave owns 1 x 1 x NTAP tiles (144 accumulator registers for 3x3; 192 in the pair form of the 3x3
+// kernel, which trades 18 MFMAs per 4 cells for 12 - see wgrad_mfma_kernel); a block of 4 waves covers 64 co x 64 ci.  The reduction over cells is split over blocks (per sample b, S chunks per sample) and every
 // block writes its own slab: no atomics, deterministic.  Keeping the slabs PER SAMPLE with NO modulation
 // applied is what lets one pass over the activations produce all three gradients (te_wgrad_reduce_f32):
 //   dW[co,ci,t]  = sum_b osc[b,co] isc[b,ci] slab_b      d isc[b,ci] = sum_{co,t} W osc[b,co] slab_b
@@ -69,11 +69,21 @@ __device__ unsigned long long te_wgrad_prof_buf[8192 * 8];
 #define WPROF(i)
 #endif
 
-template <int KIND, int NWP>
+// WINO (3x3 only): the cells of a stage are taken as horizontal PAIRS and the three taps of a kernel row come out of FOUR
+// products per pair instead of six - the 1-D Winograd form F(3,2), the transpose of the F(2,3) the forward kernel (wino.hip)
+// uses.  For the pair (g0, g1) of the output gradient and the four inputs e0..e3 under it (one tap row ky):
+//     u = [g0, g0+g1, g0-g1, -g1]     t = [e0-e2, e1+e2, e2-e1, e1-e3]     m_c = sum over pairs u_c t_c   (one accumulator each)
+//     dW[ky][0] = m0 + (m1+m2)/2      dW[ky][1] = (m1-m2)/2                dW[ky][2] = (m1+m2)/2 + m3
+// so a k-step of the matrix pipe (two pairs: lane half h takes pair 2*ks + h) issues 12 MFMAs for 4 cells where the direct form
+// issues 18.  The 12 accumulators are folded back to the 9 taps when the slab is written: slab format, reducers and callers
+// are the same as for the direct form.
+template <int KIND, int NWP, bool WINO>
 __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p) {
+    static_assert(!WINO || KIND == TE_CONV_3X3, "pair form: 3x3 only");
     constexpr int NTHREADS = NWP * 128;
     constexpr int PCH = NWP * 32;
     constexpr int NT = WK<KIND>::NT;
+    constexpr int NACC = WINO ? 12 : NT;
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);   // which operand carries the tap shift
     constexpr int NP = WK<KIND>::NP;                // plain-tile elements per thread   (PCH*NC / 512)
     constexpr int NQ = (WK<KIND>::NQ8 * 512 + NTHREADS - 1) / NTHREADS;   // shifted-tile elements per thread
@@ -105,9 +115,9 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
     const __amdgpu_buffer_rsrc_t qrs = make_rsrc(GSHIFT ? gP : xP, q_sample * (unsigned)p.NB);
     const int q_tile = p.QH * p.QW;
 
-    f32x16 acc[NT];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -285,13 +295,22 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
 
     // ---- MFMAs over the cells of a staged tile (2 cells per k-step: lane half h takes cell 2*ks + h);
     //      operands of step ks+1 are read from LDS before the MFMAs of step ks are issued
-    const int nks = p.NC >> 1;
+    const int nks = WINO ? p.NC >> 2 : p.NC >> 1;
     float a_c[GSHIFT ? NT : 1], b_c[GSHIFT ? 1 : NT];
     auto pos_shift = [&](int ks) {
         const int c0 = 2 * ks, cy = c0 >> p.lgTW, cx = c0 & (p.TW - 1);
         return (KIND == TE_CONV_T2) ? 2 * cy * p.QW + 2 * cx : cy * p.QW + cx;
     };
+    float w_g0 = 0.f, w_g1 = 0.f, w_e0 = 0.f, w_e1 = 0.f, w_e2 = 0.f, w_e3 = 0.f;     // pair form: operands in flight
+    int w_xo = 0;
     auto first_operands = [&](const float* g_l, const float* x_l) {
+        if constexpr (WINO) {
+            const int c0 = 4 * min(kw, nks - 1) + 2 * half;         // first cell of this lane's pair
+            w_xo = (c0 >> p.lgTW) * p.QW + (c0 & (p.TW - 1));
+            w_g0 = g_l[c0]; w_g1 = g_l[c0 + 1];
+            w_e0 = x_l[w_xo]; w_e1 = x_l[w_xo + 1]; w_e2 = x_l[w_xo + 2]; w_e3 = x_l[w_xo + 3];
+            return;
+        }
         const int k0 = min(kw, nks - 1);
         const int sh = pos_shift(k0);
         if (!GSHIFT) {
@@ -305,6 +324,44 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
         }
     };
     auto steps = [&](const float* g_l, const float* x_l, int ks_from, int ks_to) {      // k-steps ks_from <= ks < ks_to
+        if constexpr (WINO) {
+            // software pipeline at tap-row granularity: the four inputs of the NEXT tap row (after row 2: row 0 and the g pair of
+            // the next k-step) are read from LDS before the four MFMAs of the current row are issued
+#pragma unroll 1
+            for (int ks = ks_from; ks < ks_to; ks += kstride) {
+                const int kn = (ks + kstride < nks) ? ks + kstride : ks;          // last step re-reads itself (harmless)
+                const int cn = 4 * kn + 2 * half, xo_n = (cn >> p.lgTW) * p.QW + (cn & (p.TW - 1));
+                const float* xr = x_l + w_xo;
+                const float u0 = w_g0, u1 = w_g0 + w_g1, u2 = w_g0 - w_g1, u3 = -w_g1;
+                float t0 = w_e0 - w_e2, t1 = w_e1 + w_e2, t2 = w_e2 - w_e1, t3 = w_e1 - w_e3;
+                w_e0 = xr[p.QW]; w_e1 = xr[p.QW + 1]; w_e2 = xr[p.QW + 2]; w_e3 = xr[p.QW + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, t0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, t1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2, t2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u3, t3, acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                t0 = w_e0 - w_e2; t1 = w_e1 + w_e2; t2 = w_e2 - w_e1; t3 = w_e1 - w_e3;
+                w_e0 = xr[2 * p.QW]; w_e1 = xr[2 * p.QW + 1]; w_e2 = xr[2 * p.QW + 2]; w_e3 = xr[2 * p.QW + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, t0, acc[4], 0, 0, 0);
+                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, t1, acc[5], 0, 0, 0);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2, t2, acc[6], 0, 0, 0);
+                acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(u3, t3, acc[7], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                t0 = w_e0 - w_e2; t1 = w_e1 + w_e2; t2 = w_e2 - w_e1; t3 = w_e1 - w_e3;
+                w_e0 = x_l[xo_n]; w_e1 = x_l[xo_n + 1]; w_e2 = x_l[xo_n + 2]; w_e3 = x_l[xo_n + 3];
+                w_g0 = g_l[cn]; w_g1 = g_l[cn + 1];
+                w_xo = xo_n;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0, t0, acc[8], 0, 0, 0);
+                acc[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1, t1, acc[9], 0, 0, 0);
+                acc[10] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2, t2, acc[10], 0, 0, 0);
+                acc[11] = __builtin_amdgcn_mfma_f32_32x32x2f32(u3, t3, acc[11], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll 2
         for (int ks = ks_from; ks < ks_to; ks += kstride) {
             float a_n[GSHIFT ? NT : 1], b_n[GSHIFT ? 1 : NT];
@@ -332,8 +389,9 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
         }
     };
 
-    const int g_off = a_ch * (GSHIFT ? p.QS : p.PS) + (GSHIFT ? 2 * half : half) + (GSHIFT ? PCH * p.PS : 0);   // inside an image
-    const int x_off = b_ch * (GSHIFT ? p.PS : p.QS) + half + (GSHIFT ? 0 : PCH * p.PS);
+    // (pair form: the lane half selects a PAIR, applied inside the step)
+    const int g_off = a_ch * (GSHIFT ? p.QS : p.PS) + (WINO ? 0 : (GSHIFT ? 2 * half : half)) + (GSHIFT ? PCH * p.PS : 0);   // inside an image
+    const int x_off = b_ch * (GSHIFT ? p.PS : p.QS) + (WINO ? 0 : half) + (GSHIFT ? 0 : PCH * p.PS);
     if (t_begin < t_end) {
         issue(t_begin);
         commit(smem, smem + PCH * p.PS);
@@ -389,19 +447,19 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
 
     if constexpr (NWP == 2) {
         if (kstride > 1) {        // block-uniform: combine the K-split partial tiles, one round per extra share
-            float* red = smem + (size_t)grp * (NT * 16 * 64);
+            float* red = smem + (size_t)grp * (NACC * 16 * 64);
             for (int rnd = 1; rnd < kstride; ++rnd) {
                 __syncthreads();
                 if (kw == rnd) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NACC; ++t)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
                 }
                 __syncthreads();
                 if (kw == 0) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NACC; ++t)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
                 }
@@ -419,8 +477,18 @@ __global__ __launch_bounds__(NWP * 128, 2) void wgrad_mfma_kernel(const WgArgs p
         const int co = co0 + (GSHIFT ? qb : pb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < p.Co && ci < p.Ci) {
             float* dst = sl + ((size_t)co * p.Ci + ci) * NT;
+            if constexpr (WINO) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) dst[t] = acc[t][r];
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float hs = 0.5f * (acc[4 * ky + 1][r] + acc[4 * ky + 2][r]);
+                    dst[3 * ky + 0] = acc[4 * ky + 0][r] + hs;
+                    dst[3 * ky + 1] = 0.5f * (acc[4 * ky + 1][r] - acc[4 * ky + 2][r]);
+                    dst[3 * ky + 2] = hs + acc[4 * ky + 3][r];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dst[t] = acc[t][r];
+            }
         }
     }
 }
@@ -463,16 +531,25 @@ bool fill_geometry(WgArgs& a) {
 
 inline int pick_nwp(int Co, int Ci) { return (Co <= 64 && Ci <= 64) ? 2 : 4; }
 
-template <int KIND, int NWP>
+// The pair form (WINO) of the 3x3 kernel: 8-wave tile only (twelve accumulators plus the 4-wave tile's 34 staging registers do
+// not fit 256 VGPRs), stages of whole pair couples (a k-step = 4 cells).  Measured on the same box at the FFHQ-256 batch-16
+// shapes (profiles/experiments/r04_wgrad_pair_ab.log): 125.6 -> 153.4, 124.4 -> 158.4, 133.0 -> 171.4 TFLOP/s algorithmic,
+// same deviation from an fp64 reference (1.0e-6 vs 1.1e-6 relative).  TE_WGRAD_DIRECT=1 (read once) keeps the direct form, for A/B runs.
+inline bool pair_form_3x3(int Co, int Ci, int NC) {
+    static const bool direct = getenv("TE_WGRAD_DIRECT") && atoi(getenv("TE_WGRAD_DIRECT"));
+    return !direct && pick_nwp(Co, Ci) == 4 && NC % 4 == 0;
+}
+
+template <int KIND, int NWP, bool WINO>
 void launch_wgrad_t(const WgArgs& a, hipStream_t s) {
     constexpr int PCH = NWP * 32;
     size_t lds = ((KIND == TE_CONV_1X1 || NWP == 2) ? 1 : 2) * sizeof(float) * ((size_t)PCH * a.PS + (size_t)QCH * a.QS);   // 8-wave 3x3 / T2: two operand images
-    if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * WK<KIND>::NT * 16 * 64);     // K-split partial tiles (<= 2 groups)
+    if (NWP == 2) lds = std::max(lds, sizeof(float) * 2 * (WINO ? 12 : WK<KIND>::NT) * 16 * 64);     // K-split partial tiles (<= 2 groups)
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP>, 160 * 1024);
+    te::allow_big_lds(attr_done, (const void*)wgrad_mfma_kernel<KIND, NWP, WINO>, 160 * 1024);
     constexpr bool GSHIFT = (KIND == TE_CONV_T2);
     dim3 grid((unsigned)(a.B / a.NB * a.S), (unsigned)te::cdiv(a.Co, GSHIFT ? QCH : PCH), (unsigned)te::cdiv(a.Ci, GSHIFT ? PCH : QCH));
-    wgrad_mfma_kernel<KIND, NWP><<<grid, NWP * 128, lds, s>>>(a);
+    wgrad_mfma_kernel<KIND, NWP, WINO><<<grid, NWP * 128, lds, s>>>(a);
 }
 
 template <int KIND>
@@ -480,8 +557,11 @@ int launch_wgrad(WgArgs a, hipStream_t s) {
     if (!fill_geometry<KIND>(a)) return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: unsupported image size %dx%d", a.H, a.W);
     if ((int64_t)a.NB * a.Co * a.Hg * a.Wg * 4 >= (int64_t)OOB || (int64_t)a.NB * a.Ci * a.Hx * a.Wx * 4 >= (int64_t)OOB)
         return te::fail(TE_ERR_UNSUPPORTED, "te_wgrad_f32: a sample group exceeds 2 GiB");
-    if (pick_nwp(a.Co, a.Ci) == 2) launch_wgrad_t<KIND, 2>(a, s);
-    else launch_wgrad_t<KIND, 4>(a, s);
+    if constexpr (KIND == TE_CONV_3X3) {
+        if (pair_form_3x3(a.Co, a.Ci, a.NC)) { launch_wgrad_t<KIND, 4, true>(a, s); return 0; }
+    }
+    if (pick_nwp(a.Co, a.Ci) == 2) launch_wgrad_t<KIND, 2, false>(a, s);
+    else launch_wgrad_t<KIND, 4, false>(a, s);
     return 0;
 }
 
@@ -803,6 +883,12 @@ extern "C" int te_debug_wgrad_prof(void* host_dst, int64_t bytes) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_wgrad_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+extern "C" int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W) {
+    if (kind != TE_CONV_3X3 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return 0;
+    const int TW = std::max(2, std::min(32, pow2ceil(W))), TH = std::max(1, std::min(pow2ceil(H), 64 / TW));
+    return pair_form_3x3(Co, Ci, TH * TW) ? 1 : 0;
+}
 
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
