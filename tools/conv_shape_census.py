@@ -12,7 +12,7 @@ from transeditor_amd.train_step import TrainStep, default_args       # noqa: E40
 
 DEV = 'cuda'
 recs = []
-names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1'}
+names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1', _lib.CONV_3X3W: 'conv3x3w'}
 orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
 ON = [False]
 

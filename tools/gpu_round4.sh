@@ -29,6 +29,7 @@ rm -f gpurun_out/pmc/*.db gpurun_out/pmc/*.csv
 ( timeout 300 python tools/conv_shape_census.py ) > gpurun_out/${TAG}_conv_shape_census.log 2>&1; echo "shape census rc=$?"
 ( timeout 300 python tools/conv_fuzz.py 1000 5 ) > gpurun_out/${TAG}_conv_fuzz.log 2>&1; echo "conv fuzz rc=$?"; tail -1 gpurun_out/${TAG}_conv_fuzz.log
 ( timeout 200 python tools/step_census.py 16 ) > gpurun_out/${TAG}_step_census.txt 2> gpurun_out/${TAG}_step_census.err; echo "step census rc=$?"
+( timeout 150 python tools/wgrad_pair_time.py; TE_WGRAD_DIRECT=1 timeout 150 python tools/wgrad_pair_time.py ) > gpurun_out/${TAG}_wgrad_pair_ab.log 2>&1
 ( timeout 120 python tools/exp_time.py product fir ) > gpurun_out/${TAG}_fir_time.log 2>&1
 grep "ms per step" gpurun_out/${TAG}_rocprof_path.log gpurun_out/${TAG}_rocprof_r1.log
 tail -c 900 gpurun_out/${TAG}_bench_n1.json | head -c 300; echo

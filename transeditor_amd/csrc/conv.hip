@@ -119,6 +119,8 @@ struct ConvArgs {
     } reg[3];
     int nreg;
     int ntiles, mblocks;     // grid: ceil(ntiles / 8) * 8 * mblocks blocks along x (see the kernel's block -> work mapping)
+    int nt8, nbody;          // banded order: tiles [0, nbody) (the first region) go to the XCDs in 8 bands of nt8 tiles; the thin edge
+                             // regions of T2 after them stay interleaved (every XCD gets its share of the cheap tiles); nt8 = 0: all interleaved
     int ksplit, kchunk;      // split of the input-channel loop over blockIdx.z (small images: too few tiles to fill the chip)
 };
 
@@ -168,13 +170,23 @@ __global__ __launch_bounds__(NTHREADS, OCC) void conv_mfma_kernel(const ConvArgs
 
     // ---- region + tile coordinates
     // ---- block -> (cell tile, M block).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so
-    // the j-th block of XCD x takes tile (j / mblocks) * 8 + x and M block j % mblocks: the M blocks of a tile run on ONE XCD at
-    // the same time and share its input tile through that L2, tiles are walked in order (the short edge tiles of T2 come last
-    // for every M block, which is what a greedy dispatcher wants at the tail), and a tile id past the end exits.
+    // the j-th block of XCD x takes the (j / mblocks)-th tile of that XCD and M block j % mblocks: the M blocks of a tile run on
+    // ONE XCD at the same time and share its input tile through that L2.  Which tile that is: XCD x walks the x-th eighth of
+    // the first region's tile list (te::xcd_banded(): neighbouring tiles share halo rows / columns, i.e. whole 128-byte lines,
+    // through one L2 - 1628 -> 664 MB read for the 128 -> 128 @256^2 launch, profiles/experiments/r04_xcd_band_ab.log), then
+    // the short edge tiles of T2 interleaved (tile q * 8 + x: every XCD gets its share of the cheap tiles, and they come last
+    // for every M block, which is what a greedy dispatcher wants at the tail); a tile id past the end exits.
 #if TE_CONV_XCD
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int tile_id = (jx / p.mblocks) * 8 + xcd, mblk = jx % p.mblocks;
-    if (tile_id >= p.ntiles) return;
+    const int tq = jx / p.mblocks, mblk = jx % p.mblocks;
+    int tile_id;
+    if (p.nt8 && tq < p.nt8) {
+        tile_id = (int)(((int64_t)xcd * p.nbody) >> 3) + tq;      // band x = tiles [x nbody / 8, (x + 1) nbody / 8)
+        if (tile_id >= (int)(((int64_t)(xcd + 1) * p.nbody) >> 3)) return;
+    } else {
+        tile_id = p.nt8 ? p.nbody + (tq - p.nt8) * 8 + xcd : tq * 8 + xcd;
+        if (tile_id >= p.ntiles) return;
+    }
 #else
     const int tile_id = blockIdx.x % p.ntiles, mblk = blockIdx.x / p.ntiles;
 #endif
@@ -895,8 +907,11 @@ void launch_f(const ConvArgs& a, int nblocks, size_t lds_floats, hipStream_t s) 
     te::allow_big_lds(attr_done, (const void*)conv_mfma_kernel<KIND, TC, HAS_ISC, MS, OCC, FAST, EPI>, 128 * 1024);
     ConvArgs b = a;
     b.ntiles = nblocks; b.mblocks = (int)te::cdiv(a.M, BM);
+    b.nbody = (a.nreg > 1) ? a.reg[1].first_block : nblocks;
+    b.nt8 = te::xcd_banded() ? (int)te::cdiv(b.nbody, 8) : 0;
+    const int64_t per_xcd = b.nt8 ? b.nt8 + te::cdiv(nblocks - b.nbody, 8) : te::cdiv(nblocks, 8);
 #if TE_CONV_XCD
-    dim3 grid((unsigned)(te::cdiv(nblocks, 8) * 8 * b.mblocks), 1u, (unsigned)a.ksplit);
+    dim3 grid((unsigned)(per_xcd * 8 * b.mblocks), 1u, (unsigned)a.ksplit);
 #else
     dim3 grid((unsigned)(nblocks * b.mblocks), 1u, (unsigned)a.ksplit);
 #endif

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
+#include <stdlib.h>
 #include "../../include/te_hip.h"
 
 namespace te {
@@ -33,6 +34,15 @@ inline void allow_big_lds(std::atomic<uint64_t>& done, const void* fn, int bytes
 
 constexpr int kNumCU = 256;  // MI355X
 constexpr int kNumXCD = 8;
+
+// Tile order of the convolution launches over the 8 XCDs (workgroup ids go round-robin over them, each XCD has its own L2):
+// banded (default) = XCD x walks the x-th EIGHTH of the tile list, so horizontally and vertically adjacent tiles - which share
+// halo columns / rows, i.e. whole 128-byte lines - run on the same L2; interleaved (TE_XCD_INTERLEAVED=1, the order of rounds
+// 2-3) = XCD x takes tiles x, x + 8, ...  A/B with counters: profiles/experiments/r04_xcd_band_ab.log.
+inline bool xcd_banded() {
+    static const bool interleaved = getenv("TE_XCD_INTERLEAVED") && atoi(getenv("TE_XCD_INTERLEAVED"));
+    return !interleaved;
+}
 
 }  // namespace te
 

@@ -23,7 +23,7 @@
 // of stage s (register prefetch), transformed and written to the single LDS image after them (two barriers per stage); inside
 // the MFMA loop the LDS operands of step i + 1 are read before the MFMA of step i is issued (sched_barrier-pinned).  Block ->
 // (tile, M block) is XCD-aware like the direct kernel's: the M blocks of a tile run on one XCD and share the input tile through
-// its L2.  Epilogue = the direct kernel's: out = (act(osc * conv + bias) + res) * slope(mask_ref).
+// its L2, and an XCD walks a contiguous band of the tile list.  Epilogue = the direct kernel's: out = (act(osc * conv + bias) + res) * slope(mask_ref).
 #include "conv_common.h"
 
 namespace {
@@ -51,7 +51,7 @@ template <int BM> struct Geo {
 struct WinoArgs {
     float* out; const float* in; const float* U; const float* isc; const float* osc; const float* bias; const float* res;
     const float* mref; float mgain; int act;
-    int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y;
+    int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y, nt8;
 };
 
 template <int BM>
@@ -63,8 +63,11 @@ __global__ __launch_bounds__(WT, 4) void wino3x3_kernel(const WinoArgs p) {
     const int wm = wid / G::WNR, wr = wid % G::WNR;            // wm: 32 output channels each; wr: a pair of rows
     // block -> (cell tile, M block): the j-th block of XCD x takes tile (j / mblocks) * 8 + x and M block j % mblocks
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int tile = (jx / p.mblocks) * 8 + xcd, mb = jx % p.mblocks;
-    if (tile >= p.ntiles) return;                              // (grid padded to a multiple of 8 tiles; block-uniform)
+    // (banded, te::xcd_banded(): XCD x walks tiles [x n / 8, (x + 1) n / 8) so that neighbouring tiles share their halo lines in
+    //  one L2: 1671 -> 650 MB read at 128 -> 128 @256^2, profiles/experiments/r04_xcd_band_ab.log; else tile q * 8 + x)
+    const int tq = jx / p.mblocks, mb = jx % p.mblocks;
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;      // (grid padded; block-uniform)
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     const int x0 = tx * TW, y0 = ty * TH;
     const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
@@ -216,6 +219,7 @@ static void wino_launch_t(WinoArgs a, hipStream_t s) {
     typedef Geo<BM> G;
     a.tiles_x = a.W / TW; a.tiles_y = a.H / G::TH; a.mblocks = a.M / BM;
     a.ntiles = a.B * a.tiles_x * a.tiles_y;
+    a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const size_t lds = sizeof(float) * (G::T_FLOATS + G::U_FLOATS);
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wino3x3_kernel<BM>, 96 * 1024);
