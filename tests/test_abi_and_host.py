@@ -48,6 +48,12 @@ def test_argument_validation_returns_error_codes(libpath):
     assert L.te_conv_packed_numel(1, 512, 256, 3) == 9 * 512 * 256
     assert L.te_wgrad_slab_count(0, 16, 128, 128, 256, 256) >= 1
     assert L.te_wgrad_slab_count(0, 0, 128, 128, 256, 256) < 0
+    # host-side plans of the Winograd forms (pure functions of the shape)
+    assert L.te_conv_wino_supported(16, 128, 128, 256, 256) == 1 and L.te_conv_wino_supported(16, 128, 128, 16, 16) == 0
+    assert L.te_conv_wino_supported(16, 3, 128, 256, 256) == 0 and L.te_conv_wino_supported(4, 32, 32, 1024, 1024) == 1
+    assert L.te_conv_packed_numel(_lib.PACK_WFWD, 128, 256, 3) == 12 * 128 * 256
+    assert L.te_wgrad_pair_form(0, 128, 128, 256, 256) == 1 and L.te_wgrad_pair_form(0, 64, 64, 512, 512) == 0
+    assert L.te_wgrad_pair_form(1, 128, 128, 64, 64) == 0 and L.te_wgrad_pair_form(0, 128, 128, 1, 1) == 0
 
 
 def test_product_path_fails_loudly_on_cpu(libpath):

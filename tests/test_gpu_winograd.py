@@ -100,3 +100,37 @@ def test_winograd_layouts_through_the_multi_pack_launch_and_the_module_path():
         outs.append((y.detach(),) + gs)
     for name, p, q in zip(('y', 'dx', 'dw', 'ds', 'db'), outs[0], outs[1]):
         assert rel_err(p, q) < 2e-5, name
+
+
+# ---- the pair form (1-D Winograd F(3,2)) of the 3x3 weight gradient (csrc/wgrad.hip, wgrad_mfma_kernel<3X3, 4, WINO>)
+PAIR_SHAPES = [  # B, Ci, Co, H, W: full 32-cell rows (16-byte staging), ragged widths / heights, 1- and 2-pixel-wide images, channel tails
+    (2, 128, 128, 64, 64), (1, 96, 160, 40, 40), (3, 72, 200, 37, 45), (2, 130, 66, 5, 3), (2, 256, 128, 9, 1), (1, 513, 512, 4, 4),
+    (2, 128, 192, 2, 2), (4, 512, 512, 8, 8)]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', PAIR_SHAPES)
+def test_weight_gradient_pair_form_vs_fp64(B, Ci, Co, H, W):
+    """slabs of the pair form, summed, against the fp64 correlation (the weight gradient of F.conv2d, model_spatial_query.py:331-335)"""
+    assert _lib.wgrad_pair_form(_lib.CONV_3X3, Co, Ci, H, W)
+    g = synth.normal((B, Co, H, W), f'pair.g.{Co}.{H}.{W}').to(DEV)
+    x = synth.normal((B, Ci, H, W), f'pair.x.{Ci}.{H}.{W}').to(DEV)
+    slabs = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
+    got = slabs.double().sum(dim=(0, 1))
+    want = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 3, 3), g.double(), padding=1).reshape(Co, Ci, 9)
+    assert rel_err(got, want) < 5e-6
+    # per sample: every slab group is the correlation of ITS sample (the reducer derives d style / d demod from them)
+    per = slabs.double().sum(dim=1)
+    for b in range(B):
+        wb = torch.nn.grad.conv2d_weight(x[b:b + 1].double(), (Co, Ci, 3, 3), g[b:b + 1].double(), padding=1).reshape(Co, Ci, 9)
+        assert rel_err(per[b], wb) < 5e-6
+    # grouped form (plain gradient of small images: NB samples share a slab)
+    grouped = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W, group=True)
+    assert rel_err(grouped.double().sum(dim=(0, 1)), want) < 5e-6
+
+
+def test_weight_gradient_pair_form_selection():
+    """8-wave tile only (one of the channel counts above 64), 3x3 only"""
+    assert _lib.wgrad_pair_form(_lib.CONV_3X3, 128, 128, 256, 256) and _lib.wgrad_pair_form(_lib.CONV_3X3, 32, 96, 7, 5)
+    assert not _lib.wgrad_pair_form(_lib.CONV_3X3, 64, 64, 512, 512)
+    assert not _lib.wgrad_pair_form(_lib.CONV_T2, 128, 128, 64, 64) and not _lib.wgrad_pair_form(_lib.CONV_1X1, 128, 128, 64, 64)
+    assert not _lib.wgrad_pair_form(_lib.CONV_3X3, 128, 128, 1, 1)        # a stage of 2 cells: no pair couple
