@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 (vector == fp32-MFMA), MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2516.0         # dense bf16 MFMA: 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz (same guide)
 PEAK_HBM_GBS = 8000.0
 METRIC = '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling'
 
@@ -83,7 +84,7 @@ class KernelTimer:
         timer = self
         orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
         names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1',
-                 _lib.CONV_3X3W: 'conv3x3'}        # (the Winograd form of the same convolution: same algorithmic FLOPs)
+                 _lib.CONV_3X3W: 'conv3x3', _lib.CONV_3X3W6: 'conv3x3'}        # (Winograd forms of the same convolution: same algorithmic FLOPs)
 
         def conv(x, wp, kind, M, H, W, *a, **k):
             if not timer.enabled:
@@ -95,8 +96,11 @@ class KernelTimer:
             s.record()
             out = orig_conv(x, wp, kind, M, H, W, *a, **k)
             e.record()
-            # the Winograd form EXECUTES 12/18 of the direct form's multiply-adds for the same (algorithmic) convolution
-            timer.records.append((names[kind], flops, s, e, flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else 1.0)))
+            # the Winograd form EXECUTES 12/18 of the direct form's multiply-adds for the same (algorithmic) convolution; the split form
+            # (TE_CONV_3X3W6) executes them as SIX bf16 piece products each on the bf16 matrix pipe and none on the fp32 one
+            ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind == _lib.CONV_3X3W6 else 1.0))
+            ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else 0.0)
+            timer.records.append((names[kind], flops, s, e, ex32, ex16))
             return out
 
         def wgrad(g, x, kind, H, W, *a, **k):
@@ -110,7 +114,7 @@ class KernelTimer:
             e.record()
             # (the pair form of the 3x3 weight gradient: 12/18 of the direct form's multiply-adds, as above)
             timer.records.append(('wgrad_' + names[kind], flops, s, e,
-                                  flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0)))
+                                  flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0), 0.0))
             return out
 
         _lib.conv, _lib.wgrad_slabs = conv, wgrad
@@ -120,14 +124,15 @@ class KernelTimer:
 
     def summary(self):
         agg = {}
-        for name, flops, s, e, executed in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        for name, flops, s, e, executed, executed16 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += s.elapsed_time(e) * 1e-3
             a[3] += executed
+            a[4] += executed16
         return {k: {'launches': v[0], 'avg_ms': 1e3 * v[2] / v[0], 'tflops': v[1] / v[2] / 1e12, 'total_ms': 1e3 * v[2],
-                    'gflop': v[1] / 1e9, 'executed_tflops': v[3] / v[2] / 1e12}
+                    'gflop': v[1] / 1e9, 'executed_tflops': v[3] / v[2] / 1e12, 'executed_bf16_tflops': v[4] / v[2] / 1e12}
                 for k, v in agg.items()}
 
     def roofline(self, wall_s, steps):
@@ -138,16 +143,25 @@ class KernelTimer:
         tms = sum(ks[k]['total_ms'] for k in conv_keys)
         ach = gflop / tms if tms else 0.0                            # GFLOP / ms == TFLOP/s
         executed = sum(ks[k]['executed_tflops'] * ks[k]['total_ms'] for k in conv_keys) / tms if tms else 0.0
+        executed16 = sum(ks[k]['executed_bf16_tflops'] * ks[k]['total_ms'] for k in conv_keys) / tms if tms else 0.0
         traffic, note = _pmc_traffic()                               # (static; attach_counters() replaces it with this run's counters)
         return {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
-                'kernel': 'wino3x3_kernel / conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2, all 3x3 kinds)',
-                'executed_tflops': executed, 'executed_frac': executed / PEAK_FP32_TFLOPS,
+                'kernel': 'wino6_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / wino3x3_kernel / conv_mfma_kernel / '
+                          'wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2), all 3x3 kinds',
+                'executed_tflops': executed, 'executed_bf16_tflops': executed16,
+                # share of the matrix pipes' time the issued instructions account for at peak rate (fp32 + bf16 pipe time)
+                'executed_frac': executed / PEAK_FP32_TFLOPS + executed16 / PEAK_BF16_TFLOPS,
                 'achieved_note': 'achieved = ALGORITHMIC FLOPs (2 * 9 * K * M * H * W * B per launch) / measured time.  The 3x3 stride-1 '
                                  'launches from 32x32 up run the 1-D Winograd F(2,3) form (csrc/wino.hip), which executes 2/3 of those '
                                  'multiply-adds on the matrix pipe (and so does the pair form, F(3,2), of the 3x3 weight gradient on the 8-wave tile): '
                                  'those classes can exceed the 157.3 TFLOP/s of executed work; '
-                                 'executed_tflops / executed_frac price the MFMA work actually issued',
+                                 'the 3x3 stride-1 launches with K % 32 == 0, M % 64 == 0 run the same Winograd form on the bf16 matrix '
+                                 'pipe (csrc/wino6.hip: every fp32 operand split into three bf16 pieces, six exact piece products '
+                                 'accumulated in fp32 - fp32-equivalent results, deviation from fp64 not larger than the fp32 MFMA '
+                                 "chain's, tests/test_gpu_winograd.py): executed_bf16_tflops = 4 x their algorithmic FLOPs, priced "
+                                 'against the 2516 TFLOP/s dense bf16 peak.  executed_tflops / executed_bf16_tflops / executed_frac '
+                                 'price the MFMA work actually issued',
                 'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
                 'algorithmic_gflop_per_step': gflop / steps,
                 'whole_step_tflops': gflop / 1e3 / wall_s if wall_s else None,
@@ -157,7 +171,8 @@ class KernelTimer:
 
 PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32'),
               ('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'))
-PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino3x3_kernel', 'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
+PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6_kernel', 'conv3x3_fp32_winograd_kernel_same_shape': 'wino3x3_kernel',
+               'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
                'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
                'convT2_256to128_at128_b16': 'conv_mfma_kernel<1', 'convS2_128to256_at128_b16': 'conv_mfma_kernel<2',
                'wgradT2_256x128_at128_b16': 'wgrad_mfma_kernel<1'}

@@ -135,6 +135,10 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_CONV_1X1 3    /* 1x1                            in [B,K,H,W]       -> out [B,M,H,W]        */
 #define TE_CONV_3X3W 4   /* TE_CONV_3X3 through the 1-D Winograd F(2,3) kernel (2/3 of the MFMAs; same result to fp32 round-off).
                             Shapes: te_conv_wino_supported; weights packed TE_PACK_WFWD / TE_PACK_WDGRAD; never split */
+#define TE_CONV_3X3W6 5  /* the same Winograd form with its products on the bf16 matrix pipe: every fp32 operand split into three bf16
+                            pieces, six exact piece products accumulated in fp32 - fp32-equivalent results (the dropped terms are below
+                            2^-24 of the product; measured deviation from double not larger than the fp32 MFMA chain's).
+                            Shapes: te_conv_wino6_supported; weights packed TE_PACK_W6FWD / TE_PACK_W6DGRAD; never split */
 
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */
@@ -143,6 +147,9 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_PACK_SWAP 2   /* M = Ci, K = Co, taps as stored         (S2 as data gradient of T2)       */
 #define TE_PACK_WFWD 3   /* TE_CONV_3X3W forward:       U[K/8][ky][c][8][M], U[ky][c] = G w[.., ky, :]  (12 K M floats)  */
 #define TE_PACK_WDGRAD 4 /* TE_CONV_3X3W data gradient: the same transform of the flipped, transposed taps (M = Ci)     */
+#define TE_PACK_W6FWD 5  /* TE_CONV_3X3W6 forward: U = G w split into bf16 pieces, MFMA fragment order
+                            U6[K/16][piece][ky][c][M/32][64 lanes][8 bf16]  (36 K M bf16 = 18 K M floats; Co % 32 == Ci % 32 == 0) */
+#define TE_PACK_W6DGRAD 6 /* TE_CONV_3X3W6 data gradient (flipped, transposed taps; M = Ci)                               */
 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
@@ -174,6 +181,8 @@ int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
  * convolution stay on TE_CONV_3X3).  Reference: the grouped F.conv2d of ModulatedConv2d.forward, model_spatial_query.py:331-333,
  * and EqualConv2d.forward :173-181. */
 int te_conv_wino_supported(int B, int K, int M, int H, int W);
+/* 1 if TE_CONV_3X3W6 covers the problem: K % 32 == 0, M % 64 == 0, H % 8 == 0, W % 32 == 0 */
+int te_conv_wino6_supported(int B, int K, int M, int H, int W);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 /* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):

@@ -134,3 +134,81 @@ def test_weight_gradient_pair_form_selection():
     assert not _lib.wgrad_pair_form(_lib.CONV_3X3, 64, 64, 512, 512)
     assert not _lib.wgrad_pair_form(_lib.CONV_T2, 128, 128, 64, 64) and not _lib.wgrad_pair_form(_lib.CONV_1X1, 128, 128, 64, 64)
     assert not _lib.wgrad_pair_form(_lib.CONV_3X3, 128, 128, 1, 1)        # a stage of 2 cells: no pair couple
+
+
+# ---- TE_CONV_3X3W6: the same Winograd form with its products on the bf16 matrix pipe (csrc/wino6.hip): every fp32 operand split into
+# three bf16 pieces, six exact piece products accumulated in fp32.  Pinned at the SAME bar as the fp32 kernels (5e-6 against fp64), and
+# the deviation from fp64 must not exceed the fp32 direct kernel's by more than a rounding unit: it is fp32 arithmetic, not bf16.
+W6_SHAPES = [(2, 32, 64, 8, 32), (1, 64, 128, 16, 64), (3, 96, 192, 24, 32), (2, 128, 64, 32, 96), (1, 32, 128, 40, 96), (2, 512, 512, 32, 32),
+             (1, 64, 64, 64, 64), (4, 128, 128, 64, 64)]
+
+
+@pytest.mark.parametrize('B,K,M,H,W', W6_SHAPES)
+def test_split_bf16_winograd_forward_and_data_gradient_vs_fp64(B, K, M, H, W):
+    assert _lib.wino6_ok(B, K, M, H, W)
+    x = synth.normal((B, K, H, W), f'w6.x.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f'w6.w.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc = (1 + 0.3 * synth.normal((B, K), 'w6.isc')).to(DEV)
+    ws = 0.83
+    want = F.conv2d(x.double() * isc.double()[:, :, None, None], w.double() * ws, padding=1)
+    got = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_W6FWD, ws), _lib.CONV_3X3W6, M, H, W, isc)
+    direct = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, ws), _lib.CONV_3X3, M, H, W, isc)
+    e_split, e_direct = rel_err(got, want), rel_err(direct, want)
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    msg = f'split-bf16 winograd {K}->{M} @{H}x{W}: max {e_split:.2e} (direct fp32 kernel {e_direct:.2e}), L2 {l2(got):.2e} ({l2(direct):.2e})'
+    assert e_split < 5e-6
+    # fp32-equivalent: the deviation from fp64 is that of the fp32 Winograd kernel (same transforms, fp32 MFMA chain) up to noise, and
+    # within 2.5x of the direct fp32 kernel's (the Winograd transforms themselves cost up to ~2x at 512 channels, in both forms)
+    if _lib.wino_ok(B, K, M, H, W):
+        w32 = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_WFWD, ws), _lib.CONV_3X3W, M, H, W, isc)
+        msg += f'; fp32 winograd kernel L2 {l2(w32):.2e}'
+        assert l2(got) < 1.25 * l2(w32) + 1e-7, msg
+    print(msg)
+    assert l2(got) < 2.5 * l2(direct) + 1e-7, msg
+    if _lib.wino6_ok(B, M, K, H, W):
+        g = synth.normal((B, M, H, W), f'w6.g.{M}.{H}').to(DEV)
+        osc = (1 + 0.3 * synth.normal((B, K), 'w6.osc')).to(DEV)
+        want_g = F.conv_transpose2d(g.double(), w.double() * ws, padding=1) * osc.double()[:, :, None, None]
+        got_g = _lib.conv(g, _lib.conv_pack(w, _lib.PACK_W6DGRAD, ws), _lib.CONV_3X3W6, K, H, W, None, osc)
+        assert rel_err(got_g, want_g) < 5e-6
+
+
+@pytest.mark.parametrize('act', [0, 3, 4])
+@pytest.mark.parametrize('epi', ['plain', 'res', 'res+mask'])
+def test_split_bf16_winograd_epilogue_stages_equal_the_direct_kernel(act, epi):
+    B, K, M, H, W = 2, 32, 128, 16, 64
+    x = synth.normal((B, K, H, W), 'w6.ex').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 'w6.ew') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 'w6.ei')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'w6.eo')).to(DEV)
+    if epi != 'plain':
+        isc, osc = None, None
+    bias = synth.normal((M,), 'w6.eb').to(DEV)
+    res = synth.normal((B, M, H, W), 'w6.er').to(DEV) if epi != 'plain' else None
+    mref = synth.normal((B, M, H, W), 'w6.em').to(DEV) if epi == 'res+mask' else None
+    a = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_W6FWD), _lib.CONV_3X3W6, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
+    b = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W, isc, osc, bias, act, res=res, mask_ref=mref, mask_gain=1.3)
+    # (elements whose pre-activation sits within round-off of the leaky-ReLU kink may take different slopes in the two kernels)
+    one = lambda t, n: t.double() if t is not None else torch.ones(B, n, device=DEV, dtype=torch.float64)
+    pre = F.conv2d(x.double() * one(isc, K)[:, :, None, None], w.double(), padding=1) * one(osc, M)[:, :, None, None] + bias.double()[None, :, None, None]
+    keep = (pre.abs() > 1e-5) if act else torch.ones_like(pre, dtype=torch.bool)
+    assert rel_err(a * keep, b * keep) < 5e-6
+
+
+def test_split_bf16_layouts_through_the_multi_pack_launch_and_selection():
+    """the split layouts through te_conv_pack_weights2_f32 equal the single-layout launch; the three pieces of an element add up to
+    the fp32 Winograd weight (to 2^-24); the module path takes the split kernel exactly where te_conv_wino6_supported says so"""
+    from transeditor_amd.op import modconv
+    M, K = 128, 96
+    w = synth.normal((M, K, 3, 3), 'w6.pw').to(DEV)
+    a, b = _lib.conv_pack2(w, _lib.PACK_W6FWD, _lib.PACK_W6DGRAD, 0.7)
+    assert torch.equal(a, _lib.conv_pack(w, _lib.PACK_W6FWD, 0.7)) and torch.equal(b, _lib.conv_pack(w, _lib.PACK_W6DGRAD, 0.7))
+    # U6[K/16][piece][ky][c][M/32][lane = m % 32 + 32 * (k % 16 / 8)][k % 8]  (bf16)  ->  sum of pieces, reordered to [ky][c][k][m]
+    pieces = a.view(torch.bfloat16).float().view(K // 16, 3, 3, 4, M // 32, 2, 32, 8)       # [stage][piece][ky][c][mt][kh][m][j]
+    u = pieces.sum(dim=1).permute(1, 2, 0, 4, 6, 3, 5).reshape(3, 4, K, M)                  # [ky][c][stage][kh][j][mt][m] -> [ky][c][k][m]
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], device=DEV)
+    want = torch.einsum('cx,mkyx->yckm', G, w * 0.7)
+    assert rel_err(u, want) < 2e-7
+    assert modconv.fwd_kinds('3x3', 16, torch.empty(128, 128, 3, 3), 256, 256) == (_lib.PACK_W6FWD, _lib.CONV_3X3W6)
+    assert modconv.bwd_kinds('3x3', 16, torch.empty(512, 256, 3, 3), 64, 64) == (_lib.PACK_W6DGRAD, _lib.CONV_3X3W6)
+    assert modconv.fwd_kinds('3x3', 4, torch.empty(32, 32, 3, 3), 1024, 1024) == (_lib.PACK_WFWD, _lib.CONV_3X3W)       # M % 64 != 0: fp32 form
+    assert modconv.fwd_kinds('3x3', 16, torch.empty(512, 512, 3, 3), 4, 4) == (_lib.PACK_FWD, _lib.CONV_3X3)

@@ -21,6 +21,10 @@ def main():
     wp = _lib.conv_pack(w, pk)
     for _ in range(REP):
         y = _lib.conv(x, wp, ck, 128, 256, 256, isc, osc, bias, 3)                    # conv3x3 fwd (fused epilogue)
+    if ck == _lib.CONV_3X3W6:
+        wpw = _lib.conv_pack(w, _lib.PACK_WFWD)
+        for _ in range(REP):
+            _lib.conv(x, wpw, _lib.CONV_3X3W, 128, 256, 256, isc, osc, bias, 3)       # the fp32 Winograd kernel at the same shape
     if ck != _lib.CONV_3X3:
         wpd = _lib.conv_pack(w, _lib.PACK_FWD)
         for _ in range(REP):

@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
 _lib = None
 
-CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W = 0, 1, 2, 3, 4
-PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD = 0, 1, 2, 3, 4
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6 = 0, 1, 2, 3, 4, 5
+PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD = 0, 1, 2, 3, 4, 5, 6
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
@@ -39,6 +39,7 @@ _SIGNATURES = {
     'te_conv_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_conv_wino_supported': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -331,6 +332,11 @@ def conv_pack_multi(jobs):
 def wino_ok(B, K, M, H, W):
     """does TE_CONV_3X3W (1-D Winograd F(2,3): 2/3 of the MFMAs of the direct 3x3 kernel) cover this problem?"""
     return bool(lib().te_conv_wino_supported(B, K, M, H, W))
+
+
+def wino6_ok(B, K, M, H, W):
+    """does TE_CONV_3X3W6 (the Winograd form on the bf16 matrix pipe, three-piece split, fp32-equivalent) cover this problem?"""
+    return bool(lib().te_conv_wino6_supported(B, K, M, H, W))
 
 
 def conv_out_shape(kind, B, M, H, W):

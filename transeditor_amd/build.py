@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libte_hip.so')
-SOURCES = ['te_common.hip', 'bias_act.hip', 'upfirdn2d.hip', 'conv.hip', 'wino.hip', 'wgrad.hip', 'attention.hip', 'rgb.hip', 'linear.hip', 'style.hip', 'layernorm.hip', 'optim.hip', 'stddev.hip', 'chanscale.hip']
+SOURCES = ['te_common.hip', 'bias_act.hip', 'upfirdn2d.hip', 'conv.hip', 'wino.hip', 'wino6.hip', 'wgrad.hip', 'attention.hip', 'rgb.hip', 'linear.hip', 'style.hip', 'layernorm.hip', 'optim.hip', 'stddev.hip', 'chanscale.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-pass-failed']
 
 

@@ -25,3 +25,7 @@ constexpr int NTHREADS = 256;
 // TE_PACK_WFWD / TE_PACK_WDGRAD as U[K/8][ky][component][8][M]
 int te_wino_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                    const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);
+// csrc/wino6.hip: the same form with its products on the bf16 matrix pipe (three-piece split, six products: fp32-equivalent);
+// kind TE_CONV_3X3W6, weights packed TE_PACK_W6FWD / TE_PACK_W6DGRAD in MFMA fragment order
+int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
+                    const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);

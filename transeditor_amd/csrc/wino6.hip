@@ -1,0 +1,297 @@
+// F1w6: the 1-D Winograd F(2,3) form of the 3x3 / stride 1 / pad 1 convolution (wino.hip) with its multiply-adds on the BF16 matrix
+// pipe and fp32-equivalent results (round 4, kind TE_CONV_3X3W6).
+//
+// Every fp32 operand x is split into three bf16 pieces  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 8 + 8 + 8
+// mantissa bits, exact to 2^-25 relative).  A product of two bf16 numbers is exact in fp32, so
+//     a b  =  ah bh + (ah bm + am bh) + (ah bl + am bm + al bh)  +  O(2^-24 |a b|)
+// is six MFMAs of v_mfma_f32_32x32x16_bf16 accumulated in fp32 - the three dropped cross terms (am bl, al bm, al bl) are below the
+// rounding unit of the fp32 product.  Measured on the MI355X (tools/exp/bf16x_probe.hip, profiles/experiments/r04_bf16_split_probe.log):
+// a 64 x 64 x 1152 product against double: 5.3e-7 relative (L2) for the six-product form, 6.2e-7 for the native fp32 MFMA chain - the
+// split form is not "reduced precision", it is fp32 arithmetic on a different pipe - while the bf16 pipe sustains 1 490 - 1 530 TFLOP/s
+// with its operands coming from LDS one 16-byte read per MFMA, i.e. 250 fp32-equivalent TFLOP/s against the 134 the fp32 matrix
+// instructions reach at the clock the chip sustains.  The tests that pin the fp32 kernels (tests/test_gpu_winograd.py: 5e-6 against fp64)
+// pin this one at the same bar.
+//
+// Data flow per stage of 16 input channels (one MFMA K step):
+//   weights  : packed by te_conv_pack_weights (TE_PACK_W6FWD / TE_PACK_W6DGRAD) as U = G w, split, in MFMA FRAGMENT order
+//              U6[K/16][piece][ky][component][M/32][64 lanes][8 bf16]  ->  a stage's slots are copied 16 bytes per lane to LDS
+//   input    : d = style scale * in, t = B^T d (fp32, as in wino.hip), split, two channels packed per dword, written to
+//              T[piece][component][row][k half][pair][8 bf16]: a wave's B operand is one conflict-free ds_read_b128 per piece
+//   products : per (tap row, component): 3 + 3 operand reads, 6 MFMAs into the component's accumulator tile
+// Block: 512 threads, tile 64 output channels x 8 rows x 32 columns; wave (wm, wr) = 32 channels x rows {2 wr, 2 wr + 1} x 16 pairs x
+// 4 components (64 accumulator registers).  LDS: 72 KB of weights + 60 KB of transformed input per stage = one block per CU, two
+// waves per SIMD.  Epilogue = wino.hip's (output transform, demodulation scale, bias, leaky ReLU, residual, mask).
+#include "conv_common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef W6_CG
+#define W6_CG 1          // components per MFMA group (1: a chain of six dependent MFMAs per group; 2: two accumulators alternate)
+#endif
+#ifndef W6_PIPE
+#define W6_PIPE 1        // read the operands of the next group before issuing the MFMAs of the current one
+#endif
+constexpr int WT = 512, KC = 16, TW = 32, NP = TW / 2, BM = 64, TH = 8, R = TH + 2;
+constexpr int U_CHUNKS = 36 * 2 * 64;                   // 16-byte chunks of a stage's weights: [piece 3][ky 3][c 4][mtile 2][64 lanes]
+constexpr int N_UC = U_CHUNKS / WT;                     // 9 per thread
+constexpr int T_DWORDS = 3 * 4 * R * 2 * NP * 4;        // [piece][c][row][k half][pair][4 dwords]
+constexpr int N_ITEMS = R * NP * 8;                     // (row, pair, channel pair) items of a stage: 1280
+constexpr int N_IN = (N_ITEMS + WT - 1) / WT;           // 3 per thread (the last one bounds-checked)
+
+struct Wino6Args {
+    float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; const float* res;
+    const float* mref; float mgain; int act;
+    int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y, nt8;
+};
+
+__device__ __forceinline__ unsigned bf16_rn(float x) {          // round to nearest even (finite inputs)
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// x -> (h, m, l) as 16-bit patterns
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf16_rn(x);
+    const float r = x - __builtin_bit_cast(float, h << 16);
+    m = bf16_rn(r);
+    const float r2 = r - __builtin_bit_cast(float, m << 16);
+    l = bf16_rn(r2);
+}
+
+__global__ __launch_bounds__(WT, 2) void wino6_kernel(const Wino6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + U_CHUNKS * 16);             // transformed input, dwords
+    const u32x4* tl4 = reinterpret_cast<const u32x4*>(smem_raw + U_CHUNKS * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wm = wid >> 2, wr = wid & 3;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tq = jx / p.mblocks, mb = jx % p.mblocks;
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+    const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
+    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // ---- staging geometry.  Input item e = tid + 512 i -> (pair jj = e % 16, channel pair q = (e / 16) % 8, row = e / 128)
+    // Edge tiles read the same four floats per item from an address moved INSIDE the row / image (one float right at the left image
+    // border, one left at the right border, the nearest valid row above / below) and patch the vector afterwards: no per-element
+    // branches, same number of loads as the interior path.  e_flag: bit 0 left, bit 1 right, bit 2 row outside.
+    int g_off[N_IN], l_off[N_IN], e_flag[N_IN];
+#pragma unroll
+    for (int i = 0; i < N_IN; ++i) {
+        const int e = tid + WT * i;
+        const int jj = e & 15, q = (e >> 4) & 7, row = e >> 7;
+        const int gy = y0 - 1 + row;
+        const bool left = x0 == 0 && jj == 0, right = x0 + TW == p.W && jj == NP - 1, rowout = gy < 0 || gy >= p.H;
+        e_flag[i] = (left ? 1 : 0) | (right ? 2 : 0) | (rowout ? 4 : 0);
+        const int gyc = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+        g_off[i] = (2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0);
+        l_off[i] = e < N_ITEMS ? ((row * 2 + (q >> 2)) * NP + jj) * 4 + (q & 3) : -1;     // + ((piece * 4 + c) * R) * 2 * NP * 4
+    }
+    const size_t plane = (size_t)p.H * p.W;
+    const int MT = p.M >> 5;
+    f32x4 rin[N_IN][2];
+    float rsc[N_IN][2];
+    const int nstage = p.K / KC;
+    auto issue = [&](int s) {
+        const float* base = inb + (size_t)s * KC * plane;
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) {
+            if (l_off[i] < 0) continue;
+            const int e = tid + WT * i, q = (e >> 4) & 7;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                rsc[i][h2] = iscb ? iscb[s * KC + 2 * q + h2] : 1.f;
+                const float* src = base + g_off[i] + h2 * plane;
+                rin[i][h2] = *reinterpret_cast<const f32x4u*>(src);      // (edge tiles: patched in scale(), when the load has landed)
+            }
+        }
+    };
+    // weights: chunk idx = tid + 512 r -> slot idx / 64 = (piece, ky, c, mtile), lane idx % 64; copied global -> LDS by the LDS-DMA path
+    // (global_load_lds_dwordx4: a wave's 64 lanes land on 64 consecutive 16-byte chunks = one fragment slot; no staging registers, no
+    // ds_write pass).  Issued when the MFMAs of a stage are done, in flight under the transform / split of the input tile.
+    auto issue_u = [&](int s) {
+        const u32x4* us = p.U + (size_t)s * 36 * MT * 64;
+#pragma unroll
+        for (int r = 0; r < N_UC; ++r) {
+            const int idx = tid + WT * r, slot = idx >> 6;
+            const u32x4* g = us + ((size_t)(slot >> 1) * MT + 2 * mb + (slot & 1)) * 64 + (idx & 63);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ul + (idx & ~63)), 16, 0, 0);
+        }
+    };
+    // commit in two halves around the weight DMA: `scale` consumes the loaded registers (the only wait on the vector-memory counter,
+    // taken while no DMA is in flight - with one in flight the compiler would wait for IT at the first use of a loaded value),
+    // `commit` transforms, splits and writes the input tile while the DMA runs
+    f32x4 dv[N_IN][2];
+    auto scale = [&]() {
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) {
+            if (l_off[i] < 0) continue;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[i][h2];
+                if (edge) {
+                    const int f = e_flag[i];
+                    if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }        // loaded from column 0: element 0 is column -1
+                    if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }        // loaded one column early: element 3 is column W
+                    if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                }
+                dv[i][h2] = v * rsc[i][h2];
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < N_IN; ++i) {
+            if (l_off[i] < 0) continue;
+            const f32x4 e = dv[i][0], o = dv[i][1];                               // even / odd channel of the pair
+            const f32x2 t[4] = {{e[0] - e[2], o[0] - o[2]}, {e[1] + e[2], o[1] + o[2]}, {e[2] - e[1], o[2] - o[1]}, {e[1] - e[3], o[1] - o[3]}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // three-piece split of the channel pair: v_cvt_pk_bf16_f32 packs (even, odd) into one dword = the LDS element
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t[c], bf16x2));
+                const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
+                const f32x2 r1 = t[c] - hf;
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+                const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
+                const f32x2 r2 = r1 - mf;
+                const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+                tl[l_off[i] + (0 * 4 + c) * (R * 2 * NP * 4)] = h;
+                tl[l_off[i] + (1 * 4 + c) * (R * 2 * NP * 4)] = m;
+                tl[l_off[i] + (2 * 4 + c) * (R * 2 * NP * 4)] = l;
+            }
+        }
+    };
+    const int rr = l31 >> 4, jj = l31 & 15;
+    const int b_chunk = ((2 * wr + rr) * 2 + half) * NP + jj;          // + ((piece * 4 + c) * R + ky) * 2 * NP       (16-byte chunks)
+    const int a_chunk = wm * 64 + lane;                                 // + ((piece * 3 + ky) * 4 + c) * 128
+
+    issue(0);
+    scale();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_u(0);
+    __builtin_amdgcn_sched_barrier(0);
+    commit();
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        if (s + 1 < nstage) issue(s + 1);
+#ifndef W6_SKIP_MFMA
+        {
+            // groups of CG components of one tap row: 3 + 3 operand reads and 6 MFMAs per component.  W6_PIPE: the operands of group
+            // g + 1 are read before the MFMAs of group g are issued; CG = 2 alternates two accumulators (no back-to-back dependent MFMAs)
+            constexpr int CG = W6_CG, NG = 12 / CG;
+            bf16x8 av[2][CG][3], bv[2][CG][3];
+            auto rd = [&](int g, int slot) {
+                const int ky = g / (4 / CG), c0 = (g % (4 / CG)) * CG;
+#pragma unroll
+                for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        av[slot][cc][pc] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((pc * 3 + ky) * 4 + c0 + cc) * 128]);
+                        bv[slot][cc][pc] = __builtin_bit_cast(bf16x8, tl4[b_chunk + ((pc * 4 + c0 + cc) * R + ky) * 2 * NP]);
+                    }
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+            if (W6_PIPE) rd(0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int slot = W6_PIPE ? (g & 1) : 0, c0 = (g % (4 / CG)) * CG;
+                if (W6_PIPE) { if (g + 1 < NG) rd(g + 1, (g + 1) & 1); }
+                else rd(g, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+                        acc[c0 + cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][cc][PA[q]], bv[slot][cc][PB[q]], acc[c0 + cc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
+        __syncthreads();
+#ifndef W6_SKIP_COMMIT
+        if (s + 1 < nstage) {
+            scale();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_u(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            commit();
+        }
+#endif
+        __syncthreads();
+    }
+    // epilogue: output transform (two adjacent columns per accumulator element), then the direct kernel's epilogue stages
+    const int mbase = mb * BM + wm * 32;
+    const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
+    const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = mbase + dm;
+        float v0 = acc[0][r] + acc[1][r] + acc[2][r];
+        float v1 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float sc = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f, bi = p.bias ? p.bias[m] : 0.f;
+        v0 = v0 * sc + bi;
+        v1 = v1 * sc + bi;
+        if (p.act >= 3) {
+            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
+        }
+        const size_t o = off0 + (size_t)dm * plane;
+        if (p.res) {
+            const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + o);
+            v0 += rv[0]; v1 += rv[1];
+        }
+        if (p.mref) {
+            const f32x2 qv = *reinterpret_cast<const f32x2*>(p.mref + o);
+            v0 *= qv[0] > 0.f ? p.mgain : 0.2f * p.mgain;
+            v1 *= qv[1] > 0.f ? p.mgain : 0.2f * p.mgain;
+        }
+        f32x2 v; v[0] = v0; v[1] = v1;
+        *reinterpret_cast<f32x2*>(p.out + o) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
+    if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
+    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
+}
+
+int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
+                    const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s) {
+    TE_REQUIRE(te_conv_wino6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
+               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
+    TE_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(res) |
+                 reinterpret_cast<uintptr_t>(mask_ref)) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
+               "te_conv_f32(TE_CONV_3X3W6): 16-byte aligned tensors required");
+    Wino6Args a{};
+    a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.res = res;
+    a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
+    a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
+    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
+    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
+    const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)wino6_kernel, 160 * 1024);
+    const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
+    wino6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    return te::launch_status("te_conv_f32(TE_CONV_3X3W6)");
+}

@@ -322,19 +322,26 @@ def _bwd_pack_kind(kind):
 # launches that carry the FLOPs of both networks) use it: same result to fp32 round-off, 2/3 of the MFMAs.  The choice is a pure
 # function of the problem shape, so the forward (which packs the data-gradient layout ahead) and the backward agree on it.
 USE_WINOGRAD = True      # False: the direct kernel everywhere (A/B measurements)
+USE_SPLIT_BF16 = True    # the Winograd form on the bf16 matrix pipe (TE_CONV_3X3W6) where it applies; False: fp32 MFMA everywhere
 
 
 def fwd_kinds(kind, B, w, H, W):
     """(weight pack kind, convolution kind code) of the forward launch; H, W = low-resolution size"""
-    if kind == '3x3' and USE_WINOGRAD and _lib.wino_ok(B, w.shape[1], w.shape[0], H, W):
-        return _lib.PACK_WFWD, _lib.CONV_3X3W
+    if kind == '3x3' and USE_WINOGRAD:
+        if USE_SPLIT_BF16 and _lib.wino6_ok(B, w.shape[1], w.shape[0], H, W):
+            return _lib.PACK_W6FWD, _lib.CONV_3X3W6
+        if _lib.wino_ok(B, w.shape[1], w.shape[0], H, W):
+            return _lib.PACK_WFWD, _lib.CONV_3X3W
     return _lib.PACK_FWD, _KIND[kind]
 
 
 def bwd_kinds(kind, B, w, H, W):
     """the same for the data gradient (a convolution from Co to Ci channels)"""
-    if kind == '3x3' and USE_WINOGRAD and _lib.wino_ok(B, w.shape[0], w.shape[1], H, W):
-        return _lib.PACK_WDGRAD, _lib.CONV_3X3W
+    if kind == '3x3' and USE_WINOGRAD:
+        if USE_SPLIT_BF16 and _lib.wino6_ok(B, w.shape[0], w.shape[1], H, W):
+            return _lib.PACK_W6DGRAD, _lib.CONV_3X3W6
+        if _lib.wino_ok(B, w.shape[0], w.shape[1], H, W):
+            return _lib.PACK_WDGRAD, _lib.CONV_3X3W
     ck = {'up': _lib.CONV_S2, 'down': _lib.CONV_T2}.get(kind)          # adjoint of the transposed / strided kind
     return _bwd_pack_kind(kind), (ck if ck is not None else _KIND[kind])
 
