@@ -48,6 +48,19 @@ PEAK_HBM_GBS = 8000.0
 METRIC = '256x256 images/sec/GPU, G+D fwd+bwd, batch 16; 1/2/4/8-GPU scaling'
 
 
+def _arithmetic_note():
+    from transeditor_amd.op import modconv
+    if modconv.USE_WINOGRAD and modconv.USE_SPLIT_BF16:
+        return ('fp32 in, fp32 out, fp32 accumulation everywhere.  The 3x3 stride-1 convolutions with K % 32 == 0, M % 64 == 0 form their '
+                'products on the bf16 matrix pipe from a three-piece split of every fp32 operand (x = h + m + l, 24 mantissa bits; six '
+                'exact piece products per multiply, the dropped ones below 2^-24): fp32-equivalent - measured deviation from fp64 BELOW '
+                "the fp32-MFMA Winograd kernel's at every tested shape (tests/test_gpu_winograd.py, profiles/r04_pytest_gpu.log).  "
+                'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere.')
+    return 'fp32 matrix / vector instructions everywhere (TE_SPLIT_BF16=0)'
+
+
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -744,7 +757,7 @@ def main():
                        config={'workload': f'FFHQ-{size} generator fwd+bwd ONLY (BASELINE {cfg}; NOT the G+D metric), batch '
                                            f'{B}/GPU, num_trans=8, random-init weights, random latents',
                                'global_batch': world * B, 'parallelism': f'dp{world}',
-                               'per_gpu_images_per_sec': B * args.steps / elapsed})
+                               'per_gpu_images_per_sec': B * args.steps / elapsed, 'arithmetic': _arithmetic_note()})
             if roof:
                 out['roofline'] = roof
                 if world == 1:
@@ -797,7 +810,8 @@ def main():
                                    f'batch {B}/GPU, num_trans=8, random-init weights, synthetic real images',
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'per_gpu_images_per_sec': B * args.steps / elapsed,
-                       'lazy_steps_in_window': {'r1': n_r1, 'path': n_path, 'of_iterations': args.steps}})
+                       'lazy_steps_in_window': {'r1': n_r1, 'path': n_path, 'of_iterations': args.steps},
+                       'arithmetic': _arithmetic_note()})
     if timer.installed:
         out['roofline'] = timer.roofline(elapsed, args.steps)
     out['substeps'] = clock.summary(targs)

@@ -26,6 +26,8 @@ adjoint kernel pair of 'up').
 """
 import contextlib
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -322,7 +324,9 @@ def _bwd_pack_kind(kind):
 # launches that carry the FLOPs of both networks) use it: same result to fp32 round-off, 2/3 of the MFMAs.  The choice is a pure
 # function of the problem shape, so the forward (which packs the data-gradient layout ahead) and the backward agree on it.
 USE_WINOGRAD = True      # False: the direct kernel everywhere (A/B measurements)
-USE_SPLIT_BF16 = True    # the Winograd form on the bf16 matrix pipe (TE_CONV_3X3W6) where it applies; False: fp32 MFMA everywhere
+# the Winograd form on the bf16 matrix pipe (TE_CONV_3X3W6: three-piece split, fp32-equivalent results) where it applies;
+# TE_SPLIT_BF16=0 (or False here): fp32 matrix instructions everywhere (A/B measurements)
+USE_SPLIT_BF16 = os.environ.get('TE_SPLIT_BF16', '1') != '0'
 
 
 def fwd_kinds(kind, B, w, H, W):
