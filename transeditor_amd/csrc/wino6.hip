@@ -239,13 +239,32 @@ __global__ __launch_bounds__(WT, 2) void wino6_kernel(const Wino6Args p) {
     const int mbase = mb * BM + wm * 32;
     const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
     const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+    // (the 16 demodulation scales / biases of this lane are loaded up front: inside the store loop every load would wait behind the
+    //  previous row's store - the compiler cannot prove `out` does not alias them - i.e. 16 serialized L2 round trips per block)
+    float scv[16], biv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+        scv[r] = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f;
+        biv[r] = p.bias ? p.bias[m] : 0.f;
+    }
+    f32x2 resv[16], mrefv[16];                      // likewise the residual / mask rows of the discriminator's launches
+    if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            resv[r] = *reinterpret_cast<const f32x2*>(p.res + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+    }
+    if (p.mref) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mrefv[r] = *reinterpret_cast<const f32x2*>(p.mref + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = mbase + dm;
         float v0 = acc[0][r] + acc[1][r] + acc[2][r];
         float v1 = acc[1][r] - acc[2][r] - acc[3][r];
-        const float sc = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f, bi = p.bias ? p.bias[m] : 0.f;
+        const float sc = scv[r], bi = biv[r];
         v0 = v0 * sc + bi;
         v1 = v1 * sc + bi;
         if (p.act >= 3) {
@@ -253,14 +272,10 @@ __global__ __launch_bounds__(WT, 2) void wino6_kernel(const Wino6Args p) {
             v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
         }
         const size_t o = off0 + (size_t)dm * plane;
-        if (p.res) {
-            const f32x2 rv = *reinterpret_cast<const f32x2*>(p.res + o);
-            v0 += rv[0]; v1 += rv[1];
-        }
+        if (p.res) { v0 += resv[r][0]; v1 += resv[r][1]; }
         if (p.mref) {
-            const f32x2 qv = *reinterpret_cast<const f32x2*>(p.mref + o);
-            v0 *= qv[0] > 0.f ? p.mgain : 0.2f * p.mgain;
-            v1 *= qv[1] > 0.f ? p.mgain : 0.2f * p.mgain;
+            v0 *= mrefv[r][0] > 0.f ? p.mgain : 0.2f * p.mgain;
+            v1 *= mrefv[r][1] > 0.f ? p.mgain : 0.2f * p.mgain;
         }
         f32x2 v; v[0] = v0; v[1] = v1;
         *reinterpret_cast<f32x2*>(p.out + o) = v;
