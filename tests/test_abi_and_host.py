@@ -53,6 +53,10 @@ def test_argument_validation_returns_error_codes(libpath):
     assert L.te_conv_wino_supported(16, 3, 128, 256, 256) == 0 and L.te_conv_wino_supported(4, 32, 32, 1024, 1024) == 1
     assert L.te_conv_packed_numel(_lib.PACK_WFWD, 128, 256, 3) == 12 * 128 * 256
     assert L.te_wgrad_pair_form(0, 128, 128, 256, 256) == 1 and L.te_wgrad_pair_form(0, 64, 64, 512, 512) == 0
+    assert L.te_conv_wino6_supported(16, 128, 128, 256, 256) == 1 and L.te_conv_wino6_supported(4, 64, 64, 512, 512) == 1
+    assert L.te_conv_wino6_supported(4, 32, 32, 1024, 1024) == 0 and L.te_conv_wino6_supported(16, 512, 512, 16, 16) == 0      # M % 64, W % 32
+    assert L.te_conv_wino6_supported(16, 48, 64, 32, 32) == 0                                                                    # K % 32
+    assert L.te_conv_packed_numel(_lib.PACK_W6FWD, 128, 256, 3) == 18 * 128 * 256 == L.te_conv_packed_numel(_lib.PACK_W6DGRAD, 128, 256, 3)
     assert L.te_wgrad_pair_form(1, 128, 128, 64, 64) == 0 and L.te_wgrad_pair_form(0, 128, 128, 1, 1) == 0
 
 
@@ -360,3 +364,24 @@ def test_packed_weight_cache_refresh_logic(monkeypatch):
         assert calls['single'] == 5
         mc.packed(p2[1], 0, 1.0)                                  # the dropped entry is repacked at its next use
         assert calls['single'] == 6 and len(cache) == 4
+
+
+def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
+    """op/modconv.fwd_kinds / bwd_kinds (no GPU): split-bf16 Winograd where te_conv_wino6_supported says so, fp32 Winograd where only
+    te_conv_wino_supported does, the direct kernels elsewhere; TE_SPLIT_BF16 / USE_WINOGRAD switch the forms off in that order"""
+    from transeditor_amd import _lib
+    from transeditor_amd.op import modconv
+    w = lambda co, ci: torch.empty(co, ci, 3, 3)
+    assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_W6FWD, _lib.CONV_3X3W6)
+    assert modconv.bwd_kinds('3x3', 16, w(256, 512), 64, 64) == (_lib.PACK_W6DGRAD, _lib.CONV_3X3W6)
+    assert modconv.fwd_kinds('3x3', 4, w(32, 32), 1024, 1024) == (_lib.PACK_WFWD, _lib.CONV_3X3W)
+    assert modconv.fwd_kinds('3x3', 16, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)
+    assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_T2 and modconv.bwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_S2
+    old = modconv.USE_SPLIT_BF16, modconv.USE_WINOGRAD
+    try:
+        modconv.USE_SPLIT_BF16 = False
+        assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_WFWD, _lib.CONV_3X3W)
+        modconv.USE_WINOGRAD = False
+        assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_FWD, _lib.CONV_3X3)
+    finally:
+        modconv.USE_SPLIT_BF16, modconv.USE_WINOGRAD = old
