@@ -21,6 +21,10 @@
 // Block: 512 threads, tile 64 output channels x 8 rows x 32 columns; wave (wm, wr) = 32 channels x rows {2 wr, 2 wr + 1} x 16 pairs x
 // 4 components (64 accumulator registers).  LDS: 72 KB of weights + 60 KB of transformed input per stage = one block per CU, two
 // waves per SIMD.  Epilogue = wino.hip's (output transform, demodulation scale, bias, leaky ReLU, residual, mask).
+// Measured (tools/wino6_check.py, batch 16): 225 / 248 / 261 / 265 TFLOP/s algorithmic at 128 -> 128 @256^2, 256 -> 256 @128^2,
+// 512 -> 512 @64^2 / @32^2 against 167 / 173 / 177 / 176 of wino.hip and 134 - 140 of the direct kernel on the same box; with the
+// staging compiled out the MFMA loop alone runs at 368: a stage's MFMAs and its staging do not overlap inside the one resident block
+// (variants that tried - per-tap-row weight DMA, smaller double-buffered tiles on paper - lost to barriers or L2 bandwidth).
 #include "conv_common.h"
 
 namespace {
