@@ -1,5 +1,7 @@
+"""Time of TE_CONV_3X3W6 with and without the residual + mask epilogue stages at the discriminator's conv1 shapes (joint batch of 32).
+    python tools/wino6_epilogue_time.py"""
 import math, os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transeditor_amd import _lib
 from tools.exp_time import timeit
 DEV='cuda'
