@@ -55,7 +55,8 @@ def _arithmetic_note():
                 'products on the bf16 matrix pipe from a three-piece split of every fp32 operand (x = h + m + l, 24 mantissa bits; six '
                 'exact piece products per multiply, the dropped ones below 2^-24): fp32-equivalent - measured deviation from fp64 BELOW '
                 "the fp32-MFMA Winograd kernel's at every tested shape (tests/test_gpu_winograd.py, profiles/r04_pytest_gpu.log).  "
-                'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere.')
+                'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere (same-box A/B of this line, round 4: 115.9 against 101.8 '
+                'img/s, profiles/r04_bench_quick_split_bf16_{on,off}.json).')
     return 'fp32 matrix / vector instructions everywhere (TE_SPLIT_BF16=0)'
 
 
