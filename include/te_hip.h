@@ -176,13 +176,21 @@ int te_conv_f32(float* out, const float* in, const float* wp, const float* isc, 
  * second kernel sums them in a fixed order (DETERMINISTIC, no atomics, no memset).  te_conv_f32 itself (no workspace)
  * never splits (same result up to summation order, slower on 4x4 ... 16x16 images). */
 int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
-/* 1 if TE_CONV_3X3W covers the problem: K % 8 == 0, M % 128 == 0, H % 4 == 0, W % 32 == 0 (every 3x3 layer of the generator
- * and discriminator from 32x32 up at the FFHQ-256 channel counts; the narrow tail of FFHQ-1024 and the 513-channel final
- * convolution stay on TE_CONV_3X3).  Reference: the grouped F.conv2d of ModulatedConv2d.forward, model_spatial_query.py:331-333,
+/* 1 if TE_CONV_3X3W covers the problem: K % 8 == 0, W % 32 == 0, and M % 128 == 0 with H % 4 == 0, or M % 64 == 0 with
+ * H % 8 == 0, or M % 32 == 0 with H % 16 == 0 (block tile = 128 / 64 / 32 output channels x 4 / 8 / 16 rows x 32 columns):
+ * every 3x3 stride-1 layer of the generator and discriminator from 32x32 up incl. the 32 / 64-channel tail of FFHQ-1024; the
+ * 513-channel final convolution of the discriminator and images narrower than 32 stay on TE_CONV_3X3.  Reference: the grouped F.conv2d of ModulatedConv2d.forward, model_spatial_query.py:331-333,
  * and EqualConv2d.forward :173-181. */
 int te_conv_wino_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_3X3W6 covers the problem: K % 32 == 0, M % 64 == 0, H % 8 == 0, W % 32 == 0 */
 int te_conv_wino6_supported(int B, int K, int M, int H, int W);
+/* Kernel form of TE_CONV_3X3W6 (process-wide; returns the previous value; anything but 0 / 1 only queries):
+ *   1 = ping-pong (round 5, default): the two waves of every SIMD work half a stage apart - one feeds the matrix pipe from its
+ *       half tile while the other transforms / splits / writes the next half tile and renews half of the weight image;
+ *   0 = block-phase (round 4): all eight waves multiply, barrier, all eight waves stage, barrier.
+ * Both forms issue the same products in the same order per output element: results are bit-identical.  TE_W6_FORM in the
+ * environment sets the initial value (A/B measurements). */
+int te_conv_wino6_form(int form);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 /* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):

@@ -20,11 +20,21 @@ def main():
     os.makedirs(objdir, exist_ok=True)
     hipcc = B._hipcc()
     procs = []
+    # sources that never mention one of the macros are taken from the product build's objects (transeditor_amd/build/*.o)
+    macros = [f[2:].split('=')[0] for f in flags if f.startswith('-D')]
+    B.build(verbose=False)
+    objs = []
     for src in B.SOURCES:
+        prod_obj = os.path.join(B.HERE, 'build', src.replace('.hip', '.o'))
+        text = open(os.path.join(B.CSRC, src)).read() + ''.join(
+            open(os.path.join(B.CSRC, h)).read() for h in os.listdir(B.CSRC) if h.endswith('.h'))
+        if macros and os.path.exists(prod_obj) and not any(m in text for m in macros) and \
+                os.path.getmtime(prod_obj) >= os.path.getmtime(os.path.join(B.CSRC, src)):
+            objs.append(prod_obj)
+            continue
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         procs.append((src, obj, subprocess.Popen([hipcc, *B.FLAGS, *flags, '-c', os.path.join(B.CSRC, src), '-o', obj],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    objs = []
     for src, obj, p in procs:
         o, _ = p.communicate()
         if p.returncode:

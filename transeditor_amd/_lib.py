@@ -40,6 +40,7 @@ _SIGNATURES = {
     'te_conv_splitk_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_conv_wino_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_conv_wino6_form': (C.c_int, [_I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -332,6 +333,11 @@ def conv_pack_multi(jobs):
 def wino_ok(B, K, M, H, W):
     """does TE_CONV_3X3W (1-D Winograd F(2,3): 2/3 of the MFMAs of the direct 3x3 kernel) cover this problem?"""
     return bool(lib().te_conv_wino_supported(B, K, M, H, W))
+
+
+def wino6_form(form=-1):
+    """kernel form of TE_CONV_3X3W6: 1 = ping-pong (default), 0 = block-phase; returns the previous value (-1: query only)"""
+    return int(lib().te_conv_wino6_form(form))
 
 
 def wino6_ok(B, K, M, H, W):

@@ -286,7 +286,289 @@ __global__ __launch_bounds__(WT, 2) void wino6_kernel(const Wino6Args p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the PING-PONG form of the same kernel (wino6p_kernel).  wino6_kernel above alternates "all eight waves multiply" and "all
+// eight waves stage" between two block-wide barriers, so the matrix pipe idles while the next stage is transformed, split and written
+// (measured: 36 % of the kernel).  Double-buffering the whole stage does not fit (2 x 132 KB), so the tile is cut the other way:
+//
+//   * the 8-row tile is two HALF tiles of 4 rows (6 input rows each, 36 KB of transformed pieces per half: T0, T1); the weights of a
+//     stage (72 KB) stay ONE image shared by both halves: 144 KB of LDS;
+//   * waves 0-3 (group 0) own half 0, waves 4-7 (group 1) own half 1.  Waves w and w + 4 share a SIMD, so every SIMD holds one wave
+//     of each group.  The groups run half a stage apart:
+//         phase X(s): group 0 multiplies  T0(s) x U(s)   |  group 1 transforms / splits / writes T1(s)
+//         phase Y(s): group 1 multiplies  T1(s) x U(s)   |  group 0 transforms / splits / writes T0(s + 1)
+//     i.e. on every SIMD one wave feeds the matrix pipe while its partner does the vector-ALU / LDS-write / DMA work of staging
+//     (the arrangement MI355X_MICROARCH.md "Two waves per SIMD" describes for attention: matrix beside memory, never matrix beside
+//     matrix).  A half tile is private to its group, so the only hand-off between the groups is the weight image;
+//   * the weight image is renewed in two halves without a second buffer.  A multiplying wave walks the 12 (tap row, component)
+//     groups in order; the first six read Ua, the last six Ub.  Ua(s) is dead once group 1 is past the middle of Y(s): group 0 (then
+//     staging) issues the DMA of Ua(s + 1) right behind that mid-phase barrier and waits for it before the end-of-phase barrier.
+//     Ub(s - 1) is dead at the end of Y(s - 1): group 1 (staging in X(s)) issues Ub(s) first thing and waits before the mid-phase
+//     barrier of X(s), behind which group 0 starts to read it.  Four barriers per stage (mid-X, end-X, mid-Y, end-Y), each of them a
+//     point where the multiplying wave has its operands for the next six MFMAs in registers already;
+//   * the mid-phase barrier sits in front of group 5's MFMAs (whose operands were read before it) and in front of the first Ub read.
+// Same arithmetic, same packed weights, same epilogue and the same supported shapes as wino6_kernel; TE_W6_FORM=0 selects the old form.
+constexpr int PH = 4, PR = PH + 2;
+constexpr int TP_PLANE = PR * 2 * NP * 4;                 // dwords of one (piece, component) plane of a half tile
+constexpr int TP_DWORDS = 12 * TP_PLANE;                  // 9 216 dwords = 36 KB
+constexpr int GT = WT / 2;                                // threads of a group
+constexpr int P_IN = (PR * NP * 8) / GT;                  // (row, pair, channel pair) items per thread and stage: 768 / 256 = 3
+static_assert(PR * NP * 8 == P_IN * GT, "items must divide over the group");
+#ifndef W6P_SPLIT
+#define W6P_SPLIT 2          // items committed in front of the mid-phase barrier (the rest behind it)
+#endif
+#ifndef W6P_PRIO
+#define W6P_PRIO 0           // 1: the multiplying wave raises its priority for the phase
+#endif
+#ifndef W6P_ILV
+#define W6P_ILV 2            // operand reads of the next group issued per MFMA of the current one (2: all six behind the first three)
+#endif
+
+__device__ __forceinline__ void w6p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void w6p_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep the role branches scalar
+    const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wrl = wq & 1, gt = tid & (GT - 1);
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + U_CHUNKS * 16) + grp * TP_DWORDS;      // this group's half tile
+    const u32x4* tl4 = reinterpret_cast<const u32x4*>(tl);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tq = jx / p.mblocks, mb = jx % p.mblocks;
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH, yh = y0 + PH * grp;
+    const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
+    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // staging geometry of this group's half: item e = gt + 256 i -> (pair jj = e % 16, channel pair q = (e / 16) % 8, row = e / 128)
+    int g_off[P_IN], l_off[P_IN], e_flag[P_IN];
+#pragma unroll
+    for (int i = 0; i < P_IN; ++i) {
+        const int e = gt + GT * i;
+        const int jj = e & 15, q = (e >> 4) & 7, row = e >> 7;
+        const int gy = yh - 1 + row;
+        const bool left = x0 == 0 && jj == 0, right = x0 + TW == p.W && jj == NP - 1, rowout = gy < 0 || gy >= p.H;
+        e_flag[i] = (left ? 1 : 0) | (right ? 2 : 0) | (rowout ? 4 : 0);
+        const int gyc = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+        g_off[i] = (2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0);
+        l_off[i] = ((row * 2 + (q >> 2)) * NP + jj) * 4 + (q & 3);                        // + (piece * 4 + c) * TP_PLANE
+    }
+    const size_t plane = (size_t)p.H * p.W;
+    const int MT = p.M >> 5;
+    f32x4 rin[P_IN][2];
+    float rsc[P_IN][2];
+    const int nstage = p.K / KC;
+    auto issue = [&](int s) {
+        const float* base = inb + (size_t)s * KC * plane;
+#pragma unroll
+        for (int i = 0; i < P_IN; ++i) {
+            const int e = gt + GT * i, q = (e >> 4) & 7;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                rsc[i][h2] = iscb ? iscb[s * KC + 2 * q + h2] : 1.f;
+                rin[i][h2] = *reinterpret_cast<const f32x4u*>(base + g_off[i] + h2 * plane);
+            }
+        }
+    };
+    // weight half `uh` of stage s: 36 fragment slots (3 pieces x 6 (tap row, component) groups x 2 M tiles), 9 per wave of the group
+    auto issue_u = [&](int uh, int s) {
+        const u32x4* us = p.U + (size_t)s * 36 * MT * 64;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int j = wq * 9 + r, piece = j / 12, rem = j % 12, kc = (rem >> 1) + 6 * uh, mt = rem & 1;
+            const int pk = piece * 12 + kc;                                   // == (piece * 3 + ky) * 4 + c
+            const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ul + (pk * 2 + mt) * 64), 16, 0, 0);
+        }
+    };
+    f32x4 dv[P_IN][2];
+    auto scale = [&]() {
+#pragma unroll
+        for (int i = 0; i < P_IN; ++i)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[i][h2];
+                if (edge) {
+                    const int f = e_flag[i];
+                    if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+                    if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }
+                    if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                }
+                dv[i][h2] = v * rsc[i][h2];
+            }
+    };
+    auto commit1 = [&](int i) {
+        const f32x4 e = dv[i][0], o = dv[i][1];                               // even / odd channel of the pair
+        const f32x2 t[4] = {{e[0] - e[2], o[0] - o[2]}, {e[1] + e[2], o[1] + o[2]}, {e[2] - e[1], o[2] - o[1]}, {e[1] - e[3], o[1] - o[3]}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t[c], bf16x2));
+            const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
+            const f32x2 r1 = t[c] - hf;
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+            const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
+            const f32x2 r2 = r1 - mf;
+            const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+            tl[l_off[i] + (0 * 4 + c) * TP_PLANE] = h;
+            tl[l_off[i] + (1 * 4 + c) * TP_PLANE] = m;
+            tl[l_off[i] + (2 * 4 + c) * TP_PLANE] = l;
+        }
+    };
+    const int rr = l31 >> 4, jj = l31 & 15;
+    const int b_chunk = ((2 * wrl + rr) * 2 + half) * NP + jj;          // + ((piece * 4 + c) * PR + ky) * 2 * NP       (16-byte chunks)
+    const int a_chunk = wm * 64 + lane;                                 // + ((piece * 3 + ky) * 4 + c) * 128
+
+    // prologue: both groups fetch their half of stage 0; group 0 stages its half and brings in the whole weight image
+    issue(0);
+    if (grp == 0) {
+        scale();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_u(0, 0);
+        issue_u(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < P_IN; ++i) commit1(i);
+        w6p_wait_vm();
+    }
+    w6p_barrier();
+    const int nphase = 2 * nstage;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const bool last = ph == nphase - 1;
+        if ((ph & 1) == grp) {
+            // ---- multiply: this group's half of stage ph / 2
+            const int s = ph >> 1;
+            if (s + 1 < nstage) issue(s + 1);
+#ifndef W6_SKIP_MFMA
+            bf16x8 av[2][3], bv[2][3];
+            auto rd1 = [&](int g, int slot, int q) {
+                const int ky = g >> 2, c = g & 3;
+                if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((q * 3 + ky) * 4 + c) * 128]);
+                else bv[slot][q - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk + (((q - 3) * 4 + c) * PR + ky) * 2 * NP]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rd1(0, 0, q);
+            if (W6P_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                const int slot = g & 1, c = g & 3;
+                if (g == 5 && !last) w6p_barrier();                          // (uniform: `last` depends on ph only)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
+                    if (g + 1 < 12) {
+                        if (W6P_ILV == 1) rd1(g + 1, slot ^ 1, q);
+                        else if (W6P_ILV == 2 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
+                        else if (W6P_ILV == 6 && q == 0) {
+#pragma unroll
+                            for (int q2 = 0; q2 < 6; ++q2) rd1(g + 1, slot ^ 1, q2);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (W6P_PRIO) __builtin_amdgcn_s_setprio(0);
+#else
+            if (!last) w6p_barrier();
+#endif
+        } else {
+            // ---- stage: this group's half of stage (ph + 1) / 2, and its share of the weight image
+            const int cs = (ph + 1) >> 1;
+            const bool work = cs < nstage;
+#ifndef W6_SKIP_COMMIT
+            if (work) {
+                scale();
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 1 && cs > 0) issue_u(1, cs);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < W6P_SPLIT; ++i) commit1(i);
+                if (grp == 1 && cs > 0) w6p_wait_vm();
+            }
+#endif
+            if (!last) w6p_barrier();
+#ifndef W6_SKIP_COMMIT
+            if (work) {
+                if (grp == 0) issue_u(0, cs);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = W6P_SPLIT; i < P_IN; ++i) commit1(i);
+                if (grp == 0) w6p_wait_vm();
+            }
+#endif
+        }
+        if (!last) w6p_barrier();
+    }
+    // epilogue: as wino6_kernel (output transform, demodulation scale, bias, leaky ReLU, residual, mask); group 0 is here one phase early
+    const int wr = grp * 2 + wrl;
+    const int mbase = mb * BM + wm * 32;
+    const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
+    const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+    float scv[16], biv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+        scv[r] = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f;
+        biv[r] = p.bias ? p.bias[m] : 0.f;
+    }
+    f32x2 resv[16], mrefv[16];
+    if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            resv[r] = *reinterpret_cast<const f32x2*>(p.res + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+    }
+    if (p.mref) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mrefv[r] = *reinterpret_cast<const f32x2*>(p.mref + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v0 = acc[0][r] + acc[1][r] + acc[2][r];
+        float v1 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float sc = scv[r], bi = biv[r];
+        v0 = v0 * sc + bi;
+        v1 = v1 * sc + bi;
+        if (p.act >= 3) {
+            v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+            v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
+        }
+        const size_t o = off0 + (size_t)dm * plane;
+        if (p.res) { v0 += resv[r][0]; v1 += resv[r][1]; }
+        if (p.mref) {
+            v0 *= mrefv[r][0] > 0.f ? p.mgain : 0.2f * p.mgain;
+            v1 *= mrefv[r][1] > 0.f ? p.mgain : 0.2f * p.mgain;
+        }
+        f32x2 v; v[0] = v0; v[1] = v1;
+        *reinterpret_cast<f32x2*>(p.out + o) = v;
+    }
+}
+
 }  // namespace
+
+// kernel form of TE_CONV_3X3W6: 1 = ping-pong (wino6p_kernel, round 5, default), 0 = block-phase (wino6_kernel, round 4); same results
+// bit for bit (same products, same accumulation order per output element).  TE_W6_FORM in the environment sets the initial value.
+static std::atomic<int> g_w6_form{[] { const char* e = getenv("TE_W6_FORM"); return e ? atoi(e) : 1; }()};
+extern "C" int te_conv_wino6_form(int form) {
+    const int old = g_w6_form.load(std::memory_order_relaxed);
+    if (form == 0 || form == 1) g_w6_form.store(form, std::memory_order_relaxed);
+    return old;
+}
 
 extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
     if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
@@ -307,10 +589,17 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
     a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
     a.ntiles = B * a.tiles_x * a.tiles_y;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
-    const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;
-    static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)wino6_kernel, 160 * 1024);
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    wino6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    if (g_w6_form.load(std::memory_order_relaxed) == 1) {
+        const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
+        static std::atomic<uint64_t> attr_done_p{0};
+        te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel, 160 * 1024);
+        wino6p_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    } else {
+        const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;
+        static std::atomic<uint64_t> attr_done{0};
+        te::allow_big_lds(attr_done, (const void*)wino6_kernel, 160 * 1024);
+        wino6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    }
     return te::launch_status("te_conv_f32(TE_CONV_3X3W6)");
 }
