@@ -33,7 +33,7 @@ def main():
             objs.append(prod_obj)
             continue
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
-        procs.append((src, obj, subprocess.Popen([hipcc, *B.FLAGS, *flags, '-c', os.path.join(B.CSRC, src), '-o', obj],
+        procs.append((src, obj, subprocess.Popen([hipcc, *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), *flags, '-c', os.path.join(B.CSRC, src), '-o', obj],
                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, obj, p in procs:
         o, _ = p.communicate()

@@ -315,16 +315,21 @@ constexpr int TP_DWORDS = 12 * TP_PLANE;                  // 9 216 dwords = 36 K
 constexpr int GT = WT / 2;                                // threads of a group
 constexpr int P_IN = (PR * NP * 8) / GT;                  // (row, pair, channel pair) items per thread and stage: 768 / 256 = 3
 static_assert(PR * NP * 8 == P_IN * GT, "items must divide over the group");
-#ifndef W6P_SPLIT
-#define W6P_SPLIT 2          // items committed in front of the mid-phase barrier (the rest behind it)
-#endif
-#ifndef W6P_PRIO
-#define W6P_PRIO 0           // 1: the multiplying wave raises its priority for the phase
-#endif
-#ifndef W6P_ILV
-#define W6P_ILV 2            // operand reads of the next group issued per MFMA of the current one (2: all six behind the first three)
-#endif
 
+#ifdef W6P_PROF      // experimental builds: per-wave cycle counts of the phases (s_memtime), read back with te_debug_w6p_prof
+__device__ unsigned long long te_w6p_prof_buf[2048 * 8 * 8];
+#define W6P_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define W6P_ACC(i, a, b) pc[i] += (b) - (a)
+#else
+#define W6P_T(v)
+#define W6P_ACC(i, a, b)
+#endif
+#ifndef W6P_SLOT0
+#define W6P_SLOT0 21         // MFMA slot behind which the staging arithmetic starts (72 slots, the program has 51): the fetch it
+#endif                       // consumes is issued half a phase earlier by group 1
+#ifndef W6P_PRIO
+#define W6P_PRIO 1           // 1: a wave raises its priority while it multiplies (+1 - 1.5 % over 0); 3: static priority for group 1 (-3 %)
+#endif
 __device__ __forceinline__ void w6p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void w6p_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -353,7 +358,8 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
     // staging geometry of this group's half: item e = gt + 256 i -> (pair jj = e % 16, channel pair q = (e / 16) % 8, row = e / 128)
-    int g_off[P_IN], l_off[P_IN], e_flag[P_IN];
+    unsigned g_off[P_IN];          // (never negative: the left-border item is moved one column to the right)
+    int l_off[P_IN], e_flag[P_IN];
 #pragma unroll
     for (int i = 0; i < P_IN; ++i) {
         const int e = gt + GT * i;
@@ -362,24 +368,23 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         const bool left = x0 == 0 && jj == 0, right = x0 + TW == p.W && jj == NP - 1, rowout = gy < 0 || gy >= p.H;
         e_flag[i] = (left ? 1 : 0) | (right ? 2 : 0) | (rowout ? 4 : 0);
         const int gyc = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
-        g_off[i] = (2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0);
+        g_off[i] = (unsigned)((2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0));
         l_off[i] = ((row * 2 + (q >> 2)) * NP + jj) * 4 + (q & 3);                        // + (piece * 4 + c) * TP_PLANE
     }
+    const unsigned q2 = 2u * ((gt >> 4) & 7);
     const size_t plane = (size_t)p.H * p.W;
     const int MT = p.M >> 5;
     f32x4 rin[P_IN][2];
-    float rsc[P_IN][2];
+    float rsc[2] = {1.f, 1.f};     // style scales of this thread's channel pair (the same pair for its three items: 256 % 128 == 0)
     const int nstage = p.K / KC;
+    // (uniform base pointer + unsigned 32-bit per-thread offset: the scalar-base addressing form, no 64-bit address registers)
     auto issue = [&](int s) {
-        const float* base = inb + (size_t)s * KC * plane;
 #pragma unroll
-        for (int i = 0; i < P_IN; ++i) {
-            const int e = gt + GT * i, q = (e >> 4) & 7;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const float* base = inb + ((size_t)s * KC + h2) * plane;
+            if (iscb) rsc[h2] = (iscb + s * KC + h2)[q2];          // (uniform branch around the load: no select, no wait at the join)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                rsc[i][h2] = iscb ? iscb[s * KC + 2 * q + h2] : 1.f;
-                rin[i][h2] = *reinterpret_cast<const f32x4u*>(base + g_off[i] + h2 * plane);
-            }
+            for (int i = 0; i < P_IN; ++i) rin[i][h2] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
         }
     };
     // weight half `uh` of stage s: 36 fragment slots (3 pieces x 6 (tap row, component) groups x 2 M tiles), 9 per wave of the group
@@ -389,69 +394,105 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         for (int r = 0; r < 9; ++r) {
             const int j = wq * 9 + r, piece = j / 12, rem = j % 12, kc = (rem >> 1) + 6 * uh, mt = rem & 1;
             const int pk = piece * 12 + kc;                                   // == (piece * 3 + ky) * 4 + c
-            const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + lane;
+            const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + (unsigned)lane;      // uniform base + 32-bit lane offset
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(ul + (pk * 2 + mt) * 64), 16, 0, 0);
         }
     };
-    f32x4 dv[P_IN][2];
-    auto scale = [&]() {
+    // ---- the arithmetic of staging (style scale, B^T d, three-piece split) as a PROGRAM OF 51 SLOTS that the multiplying wave runs
+    // behind its own MFMAs (one slot per MFMA; all slot indices are compile-time after unrolling).  Measured with the first
+    // ping-pong version (profiles/experiments/r05_w6p_phase_profile.log): the same ~50 vector-ALU instructions per item issued by the
+    // PARTNER wave of a SIMD that streams MFMAs cost 10 (older wave) to 27 (younger wave) cycles apiece - more than the multiplying
+    // phase lasts - while instructions of the multiplying wave itself issue in the shadow of its own MFMAs (32 cycles each).
+    //   slots 0..2         : item k: edge patch, style scale (in place in rin)
+    //   slots 3 + 4 u + j  : unit u = item * 4 + component, step j:  0: t = (B^T d)_c for the channel pair, h = bf16x2(t)
+    //                        1: t -= h    2: m = bf16x2(t), unpack m    3: t -= m, l = bf16x2(t)
+    // The results wait in `res` (36 registers) for the staging phase, which only moves them to LDS.
+    unsigned res[P_IN][4][3];
+    float te = 0.f, to = 0.f, fe = 0.f, fo = 0.f;
+    constexpr int N_SLOT = 3 + 4 * 4 * P_IN;
+    auto arith = [&](int k) {
+        if (k < 0) {
+        } else if (k < P_IN) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[k][h2];
+                if (edge) {
+                    const int f = e_flag[k];
+                    if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }        // loaded from column 0: element 0 is column -1
+                    if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }        // loaded one column early: element 3 is column W
+                    if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                }
+                rin[k][h2] = v * rsc[h2];
+                asm volatile("" : "+v"(rin[k][h2]));
+            }
+        } else if (k < N_SLOT) {
+            const int u = (k - P_IN) >> 2, j = (k - P_IN) & 3, i = u >> 2, c = u & 3;
+            if (j == 0) {
+                const f32x4 e = rin[i][0], o = rin[i][1];                         // even / odd channel of the pair
+                te = c == 0 ? e[0] - e[2] : (c == 1 ? e[1] + e[2] : (c == 2 ? e[2] - e[1] : e[1] - e[3]));
+                to = c == 0 ? o[0] - o[2] : (c == 1 ? o[1] + o[2] : (c == 2 ? o[2] - o[1] : o[1] - o[3]));
+                const f32x2 t = {te, to};
+                // v_cvt_pk_bf16_f32 packs (even, odd) into one dword = the LDS element
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[i][c][0] = h;
+                fe = __builtin_bit_cast(float, h << 16);
+                fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
+                asm volatile("" : "+v"(res[i][c][0]));
+            } else if (j == 1) {
+                te -= fe; to -= fo;
+            } else if (j == 2) {
+                const f32x2 t = {te, to};
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[i][c][1] = m;
+                fe = __builtin_bit_cast(float, m << 16);
+                fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
+                asm volatile("" : "+v"(res[i][c][1]));
+            } else {
+                te -= fe; to -= fo;
+                const f32x2 t = {te, to};
+                res[i][c][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                asm volatile("" : "+v"(res[i][c][2]));
+            }
+            // (pin the step HERE: the values have no use before the staging phase, and the compiler otherwise sinks the whole
+            //  program behind the mid-phase barrier)
+            asm volatile("" : "+v"(te), "+v"(to), "+v"(fe), "+v"(fo));
+        }
+    };
+    auto write_res = [&]() {
 #pragma unroll
         for (int i = 0; i < P_IN; ++i)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                f32x4 v = rin[i][h2];
-                if (edge) {
-                    const int f = e_flag[i];
-                    if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
-                    if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }
-                    if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-                }
-                dv[i][h2] = v * rsc[i][h2];
-            }
-    };
-    auto commit1 = [&](int i) {
-        const f32x4 e = dv[i][0], o = dv[i][1];                               // even / odd channel of the pair
-        const f32x2 t[4] = {{e[0] - e[2], o[0] - o[2]}, {e[1] + e[2], o[1] + o[2]}, {e[2] - e[1], o[2] - o[1]}, {e[1] - e[3], o[1] - o[3]}};
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t[c], bf16x2));
-            const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
-            const f32x2 r1 = t[c] - hf;
-            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-            const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
-            const f32x2 r2 = r1 - mf;
-            const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-            tl[l_off[i] + (0 * 4 + c) * TP_PLANE] = h;
-            tl[l_off[i] + (1 * 4 + c) * TP_PLANE] = m;
-            tl[l_off[i] + (2 * 4 + c) * TP_PLANE] = l;
-        }
+                for (int pc = 0; pc < 3; ++pc) tl[l_off[i] + (pc * 4 + c) * TP_PLANE] = res[i][c][pc];
     };
     const int rr = l31 >> 4, jj = l31 & 15;
     const int b_chunk = ((2 * wrl + rr) * 2 + half) * NP + jj;          // + ((piece * 4 + c) * PR + ky) * 2 * NP       (16-byte chunks)
     const int a_chunk = wm * 64 + lane;                                 // + ((piece * 3 + ky) * 4 + c) * 128
 
-    // prologue: both groups fetch their half of stage 0; group 0 stages its half and brings in the whole weight image
+    // prologue: every group transforms and writes its half of stage 0 and fetches stage 1; group 0 brings in the whole weight image
     issue(0);
-    if (grp == 0) {
-        scale();
-        __builtin_amdgcn_sched_barrier(0);
-        issue_u(0, 0);
-        issue_u(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) { issue_u(0, 0); issue_u(1, 0); }
 #pragma unroll
-        for (int i = 0; i < P_IN; ++i) commit1(i);
-        w6p_wait_vm();
-    }
+    for (int k = 0; k < N_SLOT; ++k) arith(k);
+    write_res();
+    issue(1);
+    w6p_wait_vm();
     w6p_barrier();
     const int nphase = 2 * nstage;
+    if (W6P_PRIO == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
+#ifdef W6P_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ph = 0; ph < nphase; ++ph) {
         const bool last = ph == nphase - 1;
+        W6P_T(t0);
         if ((ph & 1) == grp) {
-            // ---- multiply: this group's half of stage ph / 2
-            const int s = ph >> 1;
-            if (s + 1 < nstage) issue(s + 1);
-#ifndef W6_SKIP_MFMA
+            // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of stage ph / 2 + 1 (rin -> res)
+            // (in a group's last multiplying phase the arithmetic runs on the stale registers of the last fetch and its results are never
+            //  written: ONE copy of the MFMA stream instead of two with their own register allocation and 64 moves between them)
             bf16x8 av[2][3], bv[2][3];
             auto rd1 = [&](int g, int slot, int q) {
                 const int ky = g >> 2, c = g & 3;
@@ -461,58 +502,73 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
 #pragma unroll
             for (int q = 0; q < 6; ++q) rd1(0, 0, q);
-            if (W6P_PRIO) __builtin_amdgcn_s_setprio(1);
+            if (W6P_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int g = 0; g < 12; ++g) {
                 const int slot = g & 1, c = g & 3;
-                if (g == 5 && !last) w6p_barrier();                          // (uniform: `last` depends on ph only)
+#ifdef W6P_PROF
+                if (g == 5) { W6P_T(ta); w6p_barrier(); W6P_T(tb); W6P_ACC(0, t0, ta); W6P_ACC(1, ta, tb); pc[2] -= tb; }
+#else
+                if (g == 5) w6p_barrier();             // mid-phase barrier (every phase, the last one too: no branch in the MFMA stream)
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
+#ifndef W6_SKIP_MFMA
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
-                    if (g + 1 < 12) {
-                        if (W6P_ILV == 1) rd1(g + 1, slot ^ 1, q);
-                        else if (W6P_ILV == 2 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
-                        else if (W6P_ILV == 6 && q == 0) {
-#pragma unroll
-                            for (int q2 = 0; q2 < 6; ++q2) rd1(g + 1, slot ^ 1, q2);
-                        }
-                    }
+#endif
+                    if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
+#ifndef W6_SKIP_COMMIT
+                    arith(g * 6 + q - W6P_SLOT0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (W6P_PRIO) __builtin_amdgcn_s_setprio(0);
-#else
-            if (!last) w6p_barrier();
+            if (W6P_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+#ifdef W6P_PROF
+            { asm volatile("s_nop 0" ::: "memory"); W6P_T(tc); pc[2] += tc; }
 #endif
         } else {
-            // ---- stage: this group's half of stage (ph + 1) / 2, and its share of the weight image
+            // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
             const int cs = (ph + 1) >> 1;
-            const bool work = cs < nstage;
-#ifndef W6_SKIP_COMMIT
+            const bool work = cs >= 1 && cs < nstage;
+            const bool fetch = cs >= 1 && cs + 1 < nstage;
             if (work) {
-                scale();
+                // group 1 renews Ub in front of the mid-phase barrier (the partner reads it right behind): DMA first, the LDS writes
+                // of this half tile in its shadow, then the wait for the DMA; its fetch of the next stage goes BEHIND the barrier, where
+                // this group has nothing else to do (waiting for those loads too - their HBM latency - in front of the barrier cost the
+                // multiplying partner ~1 000 cycles per stage: profiles/experiments/r05_w6p_phase_profile.log).  Group 0 fetches first
+                // (its DMA comes behind the barrier).
+                if (grp == 1) issue_u(1, cs);
+                else if (fetch) issue(cs + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (grp == 1 && cs > 0) issue_u(1, cs);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < W6P_SPLIT; ++i) commit1(i);
-                if (grp == 1 && cs > 0) w6p_wait_vm();
-            }
-#endif
-            if (!last) w6p_barrier();
 #ifndef W6_SKIP_COMMIT
-            if (work) {
-                if (grp == 0) issue_u(0, cs);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = W6P_SPLIT; i < P_IN; ++i) commit1(i);
-                if (grp == 0) w6p_wait_vm();
-            }
+                write_res();
 #endif
+                if (grp == 1) w6p_wait_vm();
+            }
+            W6P_T(ta);
+            w6p_barrier();
+            W6P_T(tb);
+            if (work && grp == 0) { issue_u(0, cs); w6p_wait_vm(); }
+            if (fetch && grp == 1) issue(cs + 1);
+            W6P_T(tc);
+            W6P_ACC(3, t0, ta); W6P_ACC(4, ta, tb); W6P_ACC(5, tb, tc);
         }
+        W6P_T(t8);
         if (!last) w6p_barrier();
+        W6P_T(t9);
+        W6P_ACC(6, t8, t9);
     }
+#ifdef W6P_PROF
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* d = te_w6p_prof_buf + ((size_t)blockIdx.x * 8 + wid) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = pc[i];
+        d[6] = pc[6] | ((__builtin_amdgcn_s_memrealtime() - rstart) << 40);          // (100 MHz counter: the shader clock follows)
+        d[7] = ((unsigned long long)nstage << 48) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFFFull);
+    }
+#endif
     // epilogue: as wino6_kernel (output transform, demodulation scale, bias, leaky ReLU, residual, mask); group 0 is here one phase early
     const int wr = grp * 2 + wrl;
     const int mbase = mb * BM + wm * 32;
@@ -569,6 +625,12 @@ extern "C" int te_conv_wino6_form(int form) {
     if (form == 0 || form == 1) g_w6_form.store(form, std::memory_order_relaxed);
     return old;
 }
+
+#ifdef W6P_PROF
+extern "C" int te_debug_w6p_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_w6p_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
     if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;

@@ -475,9 +475,21 @@ def conv_core(x, w, kind='3x3', wscale=1.0):
 # and the demodulation ride INSIDE the convolution kernels (staging / epilogue, the arguments the fused first-order path has
 # always used): per layer and order, three activation-sized elementwise passes and their autograd accumulations disappear
 # (path-length step: 161 chan_scale launches and ~5 ms per step).
+_SCALE_FLOOR = 1e-20
+
+
 def _nonzero(s):
-    """the scale gradients divide by the scale: an exact zero (measure zero, but representable) becomes the smallest normal number"""
-    return torch.where(s == 0, torch.full_like(s, 1.2e-38), s)
+    """The scale gradients of the closed family divide by the scale (dP/ds = sum_p x * (s U) / s with s U = the data gradient the
+    kernel returns).  Scales of magnitude below 1e-20 - exact zeros included - are moved to +-1e-20 BEFORE they enter the family
+    (kernels and divisions see the same value): the product s U then stays a normal number for every |U| > 1e-18, so the quotient is
+    sum_p x U to fp32 accuracy instead of 0 / garbage (the former guard, 1.2e-38, let s U flush to zero), and the outputs move by less
+    than 1e-20 |x w| - far below half an ulp of anything they are added to.  Both scales are guarded (the demodulation coefficient
+    is rsqrt(... + 1e-8) > 0 in the model, but modconv_closed takes any osc).  What the division form cannot remove: under
+    create_graph, d(dP/ds)/ds is two terms of size |dP/ds| / |s| that cancel analytically; their round-off, ~6e-8 |dP/ds| / |s|, is
+    what a channel with a small style scale adds to a second-order gradient (pinned second-order parity: tests/test_gpu_timed_second_order.py)."""
+    if s is None:
+        return None
+    return torch.where(s.abs() < _SCALE_FLOOR, torch.where(s < 0, -_SCALE_FLOOR, _SCALE_FLOOR).to(s.dtype), s)
 
 
 def _rgb_ok(w, d, x_like, kind):
@@ -576,7 +588,7 @@ USE_CLOSED_MODCONV = True      # False: the chan_scale -> conv_core -> chan_scal
 
 def modconv_closed(x, w, isc, osc, kind='3x3', wscale=1.0):
     """osc (.) conv(isc (.) x, wscale * w), differentiable to any order with the scales inside the convolution kernels"""
-    return _MCFwd.apply(x, w, _nonzero(isc), osc, kind, float(wscale))
+    return _MCFwd.apply(x, w, _nonzero(isc), _nonzero(osc), kind, float(wscale))
 
 
 def _composite(x, w, isc, osc, bias, act, kind, wscale=1.0):
