@@ -14,12 +14,14 @@ scaling, data parallel) and every backward ends in the bucketed gradient all-red
 ONE JSON line.
 
 Objects in the JSON beside the driver contract:
-  roofline      dominant kernel class = the fp32-MFMA implicit-GEMM convolutions (forward / data-gradient /
-                weight-gradient of every 3x3 kind, G and D): ALGORITHMIC FLOPs of those launches in the timed region /
-                their summed duration, measured live with HIP events on the launch stream; `whole_step_frac` prices
-                the SAME algorithmic FLOPs against the whole wall-clock step.  `traffic`, `mfma_util_pct`, `mhz` and
-                `counters` come from rocprofv3 --pmc passes spawned by THIS run after the timed region (N = 1;
-                `traffic_source` "live", or "static" = the committed summary if the passes could not run).
+  roofline      the MFMA convolution launches (forward / data-gradient / weight-gradient of every 3x3 kind, G and D) in the timed
+                region, timed live with HIP events on the launch stream.  `frac` = executed matrix-pipe work / peak, per pipe:
+                executed fp32-MFMA FLOPs / 157.3 T + executed bf16-MFMA FLOPs / 2 516 T (`achieved` / `peak`: the same ratio in
+                bf16-pipe-equivalent TFLOP/s); `dominant_kernel` = the split-bf16 Winograd kernel alone against the bf16 peak;
+                `achieved_algorithmic` = algorithmic FLOPs / time (round 4's "frac" divided this by the fp32 peak: kept as
+                `algorithmic_vs_fp32_peak`); `whole_step_frac` = frac x the share of the wall-clock step those launches take.
+                `traffic`, `mfma_util_pct`, `mhz` and `counters` come from rocprofv3 --pmc passes spawned by THIS run after the
+                timed region (N = 1; `traffic_source` "live", or "static" = the committed summary if the passes could not run).
   substeps      HIP-event time of each sub-step (D / R1 / G / path) and the cadence-weighted ms per iteration.
   sub_benchmarks  (N = 1) configs[1] generator fwd+bwd at batch 16 and configs[4] FFHQ-1024 generator fwd+bwd at
                 batch 4, each with its own value and roofline.
@@ -60,6 +62,14 @@ def _arithmetic_note():
     return 'fp32 matrix / vector instructions everywhere (TE_SPLIT_BF16=0)'
 
 
+
+
+def _arithmetic_switches():
+    """what `dtype: "f32"` stands on in this run: fp32 tensors and accumulation everywhere; which launches form their products on the
+    bf16 pipe (three-piece split, fp32-equivalent) and in which kernel form"""
+    from transeditor_amd.op import modconv
+    return {'split_bf16': bool(modconv.USE_WINOGRAD and modconv.USE_SPLIT_BF16),
+            'split_bf16_kernel_form': {1: 'ping-pong (wino6p_kernel)', 0: 'block-phase (wino6_kernel)'}.get(_w6_form(), None)}
 
 
 def parse():
@@ -115,6 +125,8 @@ class KernelTimer:
             ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind == _lib.CONV_3X3W6 else 1.0))
             ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else 0.0)
             timer.records.append((names[kind], flops, s, e, ex32, ex16))
+            if kind == _lib.CONV_3X3W6:       # the dominant kernel on its own (a VIEW of the conv3x3 class, never summed with it)
+                timer.records.append(('conv3x3_split_bf16', flops, s, e, ex32, ex16))
             return out
 
         def wgrad(g, x, kind, H, W, *a, **k):
@@ -150,42 +162,71 @@ class KernelTimer:
                 for k, v in agg.items()}
 
     def roofline(self, wall_s, steps):
-        """roofline object over the MFMA convolution launches recorded since reset()"""
+        """roofline object over the MFMA convolution launches recorded since reset().
+
+        `frac` = share of the matrix pipes' time the ISSUED instructions account for at peak rate: executed fp32-MFMA FLOPs / 157.3 T
+        + executed bf16-MFMA FLOPs / 2 516 T (a Winograd launch executes 2/3 of its algorithmic multiply-adds, a split-bf16 launch six
+        bf16 piece products per multiply-add = 4x its algorithmic FLOPs on the bf16 pipe).  `achieved` / `peak` express the same ratio
+        in one unit, bf16-pipe-equivalent TFLOP/s (an fp32 MFMA FLOP occupies the pipe 16x as long as a bf16 one), so frac ==
+        achieved / peak.  The algorithmic rate (2 * 9 * K * M * H * W * B per launch / time) is `achieved_algorithmic`; round 4 divided
+        THAT by the fp32 peak and called it frac (1.098) - kept as `algorithmic_vs_fp32_peak`, it is not a fraction of any roofline."""
         ks = self.summary()
-        conv_keys = [k for k in ks if not k.endswith('1x1')]        # 1x1 (3 -> 128 stem of D, skip branches) are not 3x3 GEMMs
+        conv_keys = [k for k in ks if not k.endswith('1x1') and not k.endswith('_split_bf16')]   # (1x1: not 3x3 GEMMs; *_split_bf16: a view)
         gflop = sum(ks[k]['gflop'] for k in conv_keys)
         tms = sum(ks[k]['total_ms'] for k in conv_keys)
         ach = gflop / tms if tms else 0.0                            # GFLOP / ms == TFLOP/s
         executed = sum(ks[k]['executed_tflops'] * ks[k]['total_ms'] for k in conv_keys) / tms if tms else 0.0
         executed16 = sum(ks[k]['executed_bf16_tflops'] * ks[k]['total_ms'] for k in conv_keys) / tms if tms else 0.0
+        ex_frac = executed / PEAK_FP32_TFLOPS + executed16 / PEAK_BF16_TFLOPS
+        share = tms * 1e-3 / wall_s if wall_s else None
         traffic, note = _pmc_traffic()                               # (static; attach_counters() replaces it with this run's counters)
-        return {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
-                'kernel': 'wino6_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / wino3x3_kernel / conv_mfma_kernel / '
+        dom = ks.get('conv3x3_split_bf16')
+        dominant = None
+        if dom:
+            dominant = {'kernel': 'wino6p_kernel' if _w6_form() == 1 else 'wino6_kernel', 'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16)',
+                        'launches': dom['launches'], 'ms_per_step': dom['total_ms'] / steps,
+                        'share_of_step': dom['total_ms'] * 1e-3 / wall_s if wall_s else None,
+                        'achieved_algorithmic': dom['tflops'], 'achieved': dom['executed_bf16_tflops'], 'peak': PEAK_BF16_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': dom['executed_bf16_tflops'] / PEAK_BF16_TFLOPS}
+        return {'bound': 'mfma', 'achieved': ex_frac * PEAK_BF16_TFLOPS, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex_frac,
+                'achieved_unit_note': 'bf16-pipe-equivalent executed TFLOP/s = executed_bf16_tflops + executed_tflops x (2516 / 157.3)',
+                'peaks': {'bf16_mfma_dense': PEAK_BF16_TFLOPS, 'fp32_mfma': PEAK_FP32_TFLOPS},
+                'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
+                'kernel': ('wino6p_kernel' if _w6_form() == 1 else 'wino6_kernel') +
+                          ' (v_mfma_f32_32x32x16_bf16, three-piece split) / wino3x3_kernel / conv_mfma_kernel / '
                           'wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2), all 3x3 kinds',
-                'executed_tflops': executed, 'executed_bf16_tflops': executed16,
-                # share of the matrix pipes' time the issued instructions account for at peak rate (fp32 + bf16 pipe time)
-                'executed_frac': executed / PEAK_FP32_TFLOPS + executed16 / PEAK_BF16_TFLOPS,
-                'achieved_note': 'achieved = ALGORITHMIC FLOPs (2 * 9 * K * M * H * W * B per launch) / measured time.  The 3x3 stride-1 '
-                                 'launches from 32x32 up run the 1-D Winograd F(2,3) form (csrc/wino.hip), which executes 2/3 of those '
-                                 'multiply-adds on the matrix pipe (and so does the pair form, F(3,2), of the 3x3 weight gradient on the 8-wave tile): '
-                                 'those classes can exceed the 157.3 TFLOP/s of executed work; '
+                'dominant_kernel': dominant,
+                'executed_tflops': executed, 'executed_bf16_tflops': executed16, 'executed_frac': ex_frac,
+                'achieved_algorithmic': ach, 'algorithmic_vs_fp32_peak': ach / PEAK_FP32_TFLOPS,
+                'achieved_note': 'achieved_algorithmic = ALGORITHMIC FLOPs (2 * 9 * K * M * H * W * B per launch) / measured time.  The 3x3 '
+                                 'stride-1 launches from 32x32 up run the 1-D Winograd F(2,3) form (csrc/wino.hip), which executes 2/3 of '
+                                 'those multiply-adds (and so does the pair form, F(3,2), of the 3x3 weight gradient on the 8-wave tile); '
                                  'the 3x3 stride-1 launches with K % 32 == 0, M % 64 == 0 run the same Winograd form on the bf16 matrix '
                                  'pipe (csrc/wino6.hip: every fp32 operand split into three bf16 pieces, six exact piece products '
                                  'accumulated in fp32 - fp32-equivalent results, deviation from fp64 not larger than the fp32 MFMA '
                                  "chain's, tests/test_gpu_winograd.py): executed_bf16_tflops = 4 x their algorithmic FLOPs, priced "
-                                 'against the 2516 TFLOP/s dense bf16 peak.  executed_tflops / executed_bf16_tflops / executed_frac '
-                                 'price the MFMA work actually issued',
-                'kernel_time_share': tms * 1e-3 / wall_s if wall_s else None,
+                                 'against the 2516 TFLOP/s dense bf16 peak.  frac prices the MFMA work actually ISSUED on the pipe it '
+                                 'was issued on',
+                'kernel_time_share': share,
                 'algorithmic_gflop_per_step': gflop / steps,
                 'whole_step_tflops': gflop / 1e3 / wall_s if wall_s else None,
-                'whole_step_frac': gflop / 1e3 / wall_s / PEAK_FP32_TFLOPS if wall_s else None,
+                # the same executed work priced against the WHOLE wall-clock step (every other kernel and gap charged to it)
+                'whole_step_frac': ex_frac * share if share else None,
+                'whole_step_algorithmic_vs_fp32_peak': gflop / 1e3 / wall_s / PEAK_FP32_TFLOPS if wall_s else None,
                 'per_kernel': ks}
+
+
+def _w6_form():
+    try:
+        from transeditor_amd import _lib
+        return _lib.wino6_form(-1)
+    except Exception:
+        return None
 
 
 PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32'),
               ('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'))
-PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6_kernel', 'conv3x3_fp32_winograd_kernel_same_shape': 'wino3x3_kernel',
+PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6', 'conv3x3_fp32_winograd_kernel_same_shape': 'wino3x3_kernel',
                'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
                'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
                'convT2_256to128_at128_b16': 'conv_mfma_kernel<1', 'convS2_128to256_at128_b16': 'conv_mfma_kernel<2',
@@ -323,10 +364,13 @@ def _pick_threads(O, Pg, size):
     return best, sweep, ncpu
 
 
-def cpu_baseline_train(size):
-    """The reference's training iteration (train_spatial_query.py:166-294) through the CPU oracle on a bounded sample:
-    batch 2, every sub-step once (D, R1, G, path length on batch 1), Adam included; the iteration time is composed with
-    the lazy-regulariser cadence exactly as the GPU line is:  t = t_D + t_G + t_R1 / 16 + t_path / 4."""
+def cpu_baseline_train(size, config_batch=16):
+    """The reference's training iteration (train_spatial_query.py:166-294) through the CPU oracle on a bounded sample.
+    The two steps that carry the iteration - D and G - run ONCE AT THE CONFIG BATCH (16; D sees 16 real + 16 fake images), after
+    one untimed warm-up pass at batch 2; the two lazy regularisers run at a reduced batch (R1: 2 images, path length: 1 image) and
+    are scaled per image to their config batches (16 and 8) - they weigh 1/16 and 1/4 of an iteration.  Adam included.  The iteration
+    is composed with the cadence exactly as the GPU line is:  t = t_D + t_G + t_R1 / 16 + t_path / 4.  If the batch-2 pass predicts
+    more than ~4 minutes for the config-batch pair, the pair runs at batch 8 instead and `sample` says so."""
     from oracle import te_oracle as O
     from transeditor_amd import synth
     from transeditor_amd.model_spatial_query import Discriminator, Generator
@@ -335,18 +379,17 @@ def cpu_baseline_train(size):
     Pg, g_leaves = _oracle_params(Generator(size, 512, 512, token, n_trans=8, pixel_norm_op_dim=1).state_dict())
     Pd, d_leaves = _oracle_params(Discriminator(size).state_dict())
     threads, sweep, ncpu = _pick_threads(O, Pg, size)
-    B = 2
     g_opt = torch.optim.Adam(g_leaves, lr=0.002 * 0.8, betas=(0.0, 0.99 ** 0.8))
     d_opt = torch.optim.Adam(d_leaves, lr=0.002 * 16 / 17, betas=(0.0, 0.99 ** (16 / 17)))
-    real = torch.randn(B, 3, size, size).clamp(-1, 1)
     t = {}
 
-    def timed(name, fn):
+    def timed(name, fn, *a):
         t0 = time.perf_counter()
-        fn()
+        fn(*a)
         t[name] = time.perf_counter() - t0
 
-    def d_step():
+    def d_step(B):
+        real = torch.randn(B, 3, size, size).clamp(-1, 1)
         z, p = synth.latents(B, 900)
         with torch.no_grad():
             fake = O.generator_forward(Pg, z, p, size)[0]
@@ -356,8 +399,8 @@ def cpu_baseline_train(size):
             v.grad = g
         d_opt.step()
 
-    def r1_step():
-        r = real.clone().requires_grad_(True)
+    def r1_step(B):
+        r = torch.randn(B, 3, size, size).clamp(-1, 1).requires_grad_(True)
         pred = O.discriminator_forward(Pd, r, size)
         loss = 10.0 / 2 * O.d_r1_loss(pred, r) * 16 + 0 * pred[0]
         d_opt.zero_grad()
@@ -365,7 +408,7 @@ def cpu_baseline_train(size):
             v.grad = g
         d_opt.step()
 
-    def g_step():
+    def g_step(B):
         z, p = synth.latents(B, 901)
         fake = O.generator_forward(Pg, z, p, size)[0]
         for v in d_leaves:
@@ -378,8 +421,7 @@ def cpu_baseline_train(size):
             v.requires_grad_(True)
         g_opt.step()
 
-    def path_step():
-        n = max(1, B // 2)
+    def path_step(n):
         z, p = synth.latents(n, 902)
         img, lat, _ = O.generator_forward(Pg, z, p, size)
         noise = torch.randn_like(img) / math.sqrt(size * size)
@@ -389,16 +431,21 @@ def cpu_baseline_train(size):
             v.grad = g
         g_opt.step()
 
-    # one untimed warm-up pass of the two steps that carry the iteration (first-touch cost: oneDNN primitive creation,
-    # page faults of the 0.6 GB of activations), then every sub-step timed once
-    d_step()
-    g_step()
-    timed('d', d_step)
-    timed('r1', r1_step)
-    timed('g', g_step)
-    timed('path', path_step)
-    it = t['d'] + t['g'] + t['r1'] / 16 + t['path'] / 4
-    # per-image cost vs batch: generator forward at batch 2 (the sample) and batch 16 (the config)
+    # warm-up / calibration pass at batch 2 (first-touch cost: oneDNN primitive creation, thread pool, page faults), timed so that
+    # the config-batch pair can be bounded
+    timed('d2', d_step, 2)
+    timed('g2', g_step, 2)
+    timed('d2', d_step, 2)
+    timed('g2', g_step, 2)
+    BC = config_batch if (t['d2'] + t['g2']) * config_batch / 2 < 240 else config_batch // 2
+    timed('d', d_step, BC)
+    timed('g', g_step, BC)
+    timed('r1', r1_step, 2)
+    timed('path', path_step, 1)
+    r1_scaled = t['r1'] * BC / 2                  # R1 runs on the whole batch
+    path_scaled = t['path'] * (BC // 2) / 1       # the path-length step on batch / path_batch_shrink (= 2)
+    it = t['d'] + t['g'] + r1_scaled / 16 + path_scaled / 4
+    # per-image cost vs batch: generator forward at batch 2 and batch 16
     with torch.no_grad():
         z, p = synth.latents(16, 903)
         t0 = time.perf_counter()
@@ -414,13 +461,17 @@ def cpu_baseline_train(size):
     torch.autograd.grad(img.sum(), g_leaves, allow_unused=True)
     fb16 = time.perf_counter() - t0
     del img
-    return {'value': B / it, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'CPU oracle (PyTorch fp32 restatement of the reference) running ONE FFHQ-{size} G+D training iteration at '
-                      f'batch {B} (config batch is 16): D step {t["d"]:.2f} s, R1 step {t["r1"]:.2f} s, G step {t["g"]:.2f} s, '
-                      f'path-length step (batch 1) {t["path"]:.2f} s, Adam included; iteration = D + G + R1/16 + path/4 = '
-                      f'{it:.2f} s; after one untimed warm-up pass of the D and G steps',
+    return {'value': BC / it, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'CPU oracle (PyTorch fp32 restatement of the reference) running ONE FFHQ-{size} G+D training iteration: the D step '
+                      f'({t["d"]:.1f} s) and the G step ({t["g"]:.1f} s) at batch {BC}' +
+                      (' = THE CONFIG BATCH' if BC == config_batch else f' (config batch {config_batch}: predicted too long)') +
+                      f', once each, after a warm-up pass at batch 2 (D {t["d2"]:.1f} s, G {t["g2"]:.1f} s); the lazy regularisers at a reduced '
+                      f'batch, scaled per image: R1 on 2 images {t["r1"]:.1f} s -> x{BC // 2}, path length on 1 image {t["path"]:.1f} s -> '
+                      f'x{BC // 2}; Adam included; iteration = D + G + R1/16 + path/4 = {it:.1f} s',
+            'batch': BC, 'seconds': {k: round(v, 3) for k, v in t.items()},
             'batch_scaling': {'generator_fwd_s_per_image_batch2': f2, 'generator_fwd_s_per_image_batch16': f16,
-                              'note': 'per-image cost at the config batch relative to the sampled batch'},
+                              'iteration_images_per_sec_from_the_batch2_pass': 2 / (t['d2'] + t['g2'] + t['r1'] / 16 + t['path'] / 4),
+                              'note': 'per-image cost at the config batch relative to a batch-2 sample'},
             'generator_fwd_bwd_batch16': {'seconds': fb16, 'images_per_sec': 16 / fb16,
                                           'note': 'BASELINE configs[1] (generator fwd+bwd at the config batch 16) on the same cores, one pass'},
             'thread_sweep_s_generator_fwd_batch2': sweep, 'usable_threads': ncpu,
@@ -758,7 +809,8 @@ def main():
                        config={'workload': f'FFHQ-{size} generator fwd+bwd ONLY (BASELINE {cfg}; NOT the G+D metric), batch '
                                            f'{B}/GPU, num_trans=8, random-init weights, random latents',
                                'global_batch': world * B, 'parallelism': f'dp{world}',
-                               'per_gpu_images_per_sec': B * args.steps / elapsed, 'arithmetic': _arithmetic_note()})
+                               'per_gpu_images_per_sec': B * args.steps / elapsed, 'arithmetic': _arithmetic_note(),
+                               **_arithmetic_switches()})
             if roof:
                 out['roofline'] = roof
                 if world == 1:
@@ -812,7 +864,7 @@ def main():
                        'global_batch': world * B, 'parallelism': f'dp{world}',
                        'per_gpu_images_per_sec': B * args.steps / elapsed,
                        'lazy_steps_in_window': {'r1': n_r1, 'path': n_path, 'of_iterations': args.steps},
-                       'arithmetic': _arithmetic_note()})
+                       'arithmetic': _arithmetic_note(), **_arithmetic_switches()})
     if timer.installed:
         out['roofline'] = timer.roofline(elapsed, args.steps)
     out['substeps'] = clock.summary(targs)

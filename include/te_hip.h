@@ -138,7 +138,14 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_CONV_3X3W6 5  /* the same Winograd form with its products on the bf16 matrix pipe: every fp32 operand split into three bf16
                             pieces, six exact piece products accumulated in fp32 - fp32-equivalent results (the dropped terms are below
                             2^-24 of the product; measured deviation from double not larger than the fp32 MFMA chain's).
-                            Shapes: te_conv_wino6_supported; weights packed TE_PACK_W6FWD / TE_PACK_W6DGRAD; never split */
+                            Shapes: te_conv_wino6_supported; weights packed TE_PACK_W6FWD / TE_PACK_W6DGRAD; never split.
+                            Range: finite operands of any fp32 magnitude up to ~1.7e38 (the transform adds two neighbours) behave as
+                            in TE_CONV_3X3 (tests: scale sweep 1e-30 ... 1e+30 at the 5e-6 bar); below |x| ~ 1e-33 the third, then
+                            the second piece of an element underflows and that element's products lose bits (relative error 2^-15
+                            at 1e-36: contributions that small are below the rounding unit of any O(1e-30)+ sum anyway).
+                            Non-finite operands: an Inf / NaN input element makes exactly the outputs whose 3x3 window contains it
+                            non-finite - the same set as TE_CONV_3X3 - but as NaN where the direct kernel gives +-Inf
+                            (inf = h, inf - h = NaN is the second piece).  TE_SPLIT_BF16=0 (host) selects TE_CONV_3X3W instead. */
 
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */

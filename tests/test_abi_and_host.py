@@ -385,3 +385,33 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
         assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_FWD, _lib.CONV_3X3)
     finally:
         modconv.USE_SPLIT_BF16, modconv.USE_WINOGRAD = old
+
+
+def test_load_checkpoint_into_is_all_or_nothing():
+    """train_step.load_checkpoint_into validates its arguments BEFORE loading anything (the reference's restore,
+    train_spatial_query.py:475-492, is all-or-nothing): a partial set of training objects or a 'g_ema'-only file with training
+    objects raises and leaves every module untouched; a full checkpoint into g_ema only warns."""
+    import warnings
+
+    import torch
+    from transeditor_amd.train_step import load_checkpoint_into
+    mk = lambda: torch.nn.Linear(3, 2)
+    src = {k: mk() for k in ('g_ema', 'g', 'd')}
+    opt = {k: torch.optim.Adam(src[k].parameters()) for k in ('g', 'd')}
+    full = {'g_ema': src['g_ema'].state_dict(), 'g': src['g'].state_dict(), 'd': src['d'].state_dict(),
+            'g_optim': opt['g'].state_dict(), 'd_optim': opt['d'].state_dict()}
+    ema, g, d = mk(), mk(), mk()
+    before = ema.weight.clone()
+    go, do = torch.optim.Adam(g.parameters()), torch.optim.Adam(d.parameters())
+    with pytest.raises(ValueError):
+        load_checkpoint_into(full, ema, generator=g)                    # partial set of training objects
+    with pytest.raises(KeyError):
+        load_checkpoint_into({'g_ema': full['g_ema']}, ema, g, d, go, do)   # 'g_ema'-only file, training restore asked for
+    assert torch.equal(ema.weight, before)                                  # nothing was loaded on the failed attempts
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        load_checkpoint_into(full, ema)
+    assert any('g_ema only' in str(r.message) for r in rec)
+    assert torch.equal(ema.weight, src['g_ema'].weight)
+    load_checkpoint_into(full, ema, g, d, go, do)
+    assert torch.equal(g.weight, src['g'].weight) and torch.equal(d.weight, src['d'].weight)

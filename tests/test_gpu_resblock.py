@@ -176,35 +176,47 @@ def test_discriminator_stem_plus_first_block_node(frozen):
     img = synth.normal((4, 3, 64, 64), 'dst.img').clamp(-1, 1)
     P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'kernel' not in k else v) for k, v in sd.items()}
     names = [k for k, v in P.items() if v.requires_grad]
+    from pinning import capture, pinned, record_oracle
     ic = img.clone().requires_grad_(True)
-    ref = O.discriminator_forward(P, ic, 64)
+    with record_oracle() as bank:                     # the slope signs the oracle takes: the HIP passes below are pinned to them
+        ref = O.discriminator_forward(P, ic, 64)
     w = synth.normal((4, 1), 'dst.w')
     gref = torch.autograd.grad((ref * w).sum(), [ic] + [P[k] for k in names])
     Dn = Dn.to(DEV)
     if frozen:
         for p in Dn.parameters():
             p.requires_grad_(False)
-    idv = img.to(DEV).requires_grad_(True)
-    assert Dn._stem_fusable(idv)
-    pred = Dn(idv)
-    assert rel_err(pred, ref) < 1e-4
     params = dict(Dn.named_parameters())
-    ins = [idv] + ([] if frozen else [params[k] for k in names])
-    got = torch.autograd.grad((pred * w.to(DEV)).sum(), ins)
+
+    def run(second=False, bank_=None):
+        from transeditor_amd.op.modconv import second_order
+        import contextlib
+        idv = img.to(DEV).requires_grad_(True)
+        if not second:
+            assert Dn._stem_fusable(idv)
+        with (pinned(bank_) if bank_ is not None else contextlib.nullcontext({})) as st, (second_order() if second else contextlib.nullcontext()):
+            pred = Dn(idv)
+            got = torch.autograd.grad((pred * w.to(DEV)).sum(), [idv] + ([] if frozen else [params[k] for k in names]))
+        if bank_ is not None:
+            assert not st['unmatched'], st['unmatched']
+        return pred, got, st
+
+    # GATING comparison: slopes pinned to the oracle's (tests/pinning.py) - no flip is left, every gradient element-wise at 1e-4
+    pred, got, st = run(bank_=bank)
+    assert rel_err(pred, ref) < 1e-4
+    worst = 0.0
     for n, a, b in zip(['dimg'] + names, got, gref):
-        # whole-network first-order gradients (14 leaky-ReLU layers deep: a pre-activation within round-off of the kink flips
-        # its slope in one of the two fp32 implementations, see tests/test_gpu_timed_shapes.py): the north-star 1e-3 on the
-        # norm, 4e-3 element-wise in L2 (measured 2.0e-3 for the image gradient)
-        assert abs(float(a.double().norm()) - float(b.double().norm())) <= 1e-3 * float(b.double().norm()), n
-        assert rel_l2(a, b) < 4e-3, n
-    # the node against the unfused route of the same module (same kernels underneath, separate autograd nodes)
-    from transeditor_amd.op.modconv import second_order
-    idv2 = img.to(DEV).requires_grad_(True)
-    with second_order():
-        pred2 = Dn(idv2)
-    got2 = torch.autograd.grad((pred2 * w.to(DEV)).sum(), [idv2] + ([] if frozen else [params[k] for k in names]))
+        worst = max(worst, rel_l2(a, b))
+        assert rel_l2(a, b) < 1e-4, (n, rel_l2(a, b))
+    # the node against the unfused route of the same module (same kernels underneath, separate autograd nodes), pinned likewise
+    pred2, got2, _ = run(second=True, bank_=bank)
     assert rel_err(pred2, pred) < 1e-5
     for n, a, b in zip(['dimg'] + names, got, got2):
-        # (the two routes run different kernels for the first block - epilogue stages vs separate passes - so a pre-activation within
-        #  round-off of the kink may take the other slope: the flip bar of the comparison above; measured 2.0e-3 for the image gradient)
-        assert rel_l2(a, b) < 4e-3, n
+        assert rel_l2(a, b) < 1e-4, (n, rel_l2(a, b))
+    # INFORMATIONAL: the same comparison with free slopes.  A pre-activation within round-off of the kink takes the other slope in one
+    # of two correct fp32 implementations and moves single gradient entries by parts in a thousand (measured 2.0e-3 for the image
+    # gradient), so this bar only catches O(1) errors; precision is judged by the pinned comparison above.
+    _, free, _ = run()
+    flip = max(rel_l2(a, b) for a, b in zip(free, gref))
+    print(f'stem + first block (frozen={frozen}): pinned worst {worst:.2e} ({st["flips"]} of {st["elements"]} slopes pinned); free slopes {flip:.2e}')
+    assert flip < 2e-2

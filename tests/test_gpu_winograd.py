@@ -212,3 +212,102 @@ def test_split_bf16_layouts_through_the_multi_pack_launch_and_selection():
     assert modconv.bwd_kinds('3x3', 16, torch.empty(512, 256, 3, 3), 64, 64) == (_lib.PACK_W6DGRAD, _lib.CONV_3X3W6)
     assert modconv.fwd_kinds('3x3', 4, torch.empty(32, 32, 3, 3), 1024, 1024) == (_lib.PACK_WFWD, _lib.CONV_3X3W)       # M % 64 != 0: fp32 form
     assert modconv.fwd_kinds('3x3', 16, torch.empty(512, 512, 3, 3), 4, 4) == (_lib.PACK_FWD, _lib.CONV_3X3)
+
+
+# ---- round 5: range and non-finite behaviour of the split kernel, and the two kernel forms
+
+@pytest.mark.parametrize('which', ['input', 'weight', 'both'])
+@pytest.mark.parametrize('scale', [1e-30, 1e-15, 1e+15, 1e+30])
+def test_split_bf16_winograd_scale_sweep(scale, which):
+    """The three-piece split keeps fp32's RANGE, not only its precision at unit scale: tensors scaled by 1e-30 ... 1e+30 (inputs, weights,
+    or the square roots of the factor on both) give the scaled result at the same 5e-6 bar against fp64 and against the direct fp32
+    kernel.  (x = h + m + l with l ~ 2^-17 x: the last piece is a normal bf16 number down to |x| ~ 1e-33; elements below that lose
+    bits of an already negligible contribution.)"""
+    B, K, M, H, W = 2, 64, 128, 16, 64
+    x = synth.normal((B, K, H, W), 'w6.sx').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 'w6.sw') / (3 * math.sqrt(K))).to(DEV)
+    isc = (1 + 0.3 * synth.normal((B, K), 'w6.si')).to(DEV)
+    sx, sw = {'input': (scale, 1.0), 'weight': (1.0, scale), 'both': (math.sqrt(scale), math.sqrt(scale))}[which]
+    xs, ws_ = (x * sx).contiguous(), (w * sw).contiguous()
+    want = F.conv2d(xs.double() * isc.double()[:, :, None, None], ws_.double(), padding=1)
+    got = _lib.conv(xs, _lib.conv_pack(ws_, _lib.PACK_W6FWD), _lib.CONV_3X3W6, M, H, W, isc)
+    direct = _lib.conv(xs, _lib.conv_pack(ws_, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W, isc)
+    assert torch.isfinite(got).all()
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    print(f'split-bf16 scale sweep {which} x {scale:g}: L2 vs fp64 {l2(got):.2e} (direct fp32 kernel {l2(direct):.2e}), max {rel_err(got, want):.2e}')
+    assert rel_err(got, want) < 5e-6
+    assert l2(got) < 2.5 * l2(direct) + 1e-7
+
+
+def test_split_bf16_winograd_tiny_magnitudes_degrade_gracefully():
+    """below the range the last piece can hold (|x| ~ 1e-33 ... 1e-38: l, then m, become subnormal / zero) the kernel degrades to a
+    two-piece, then one-piece product - it never produces non-finite values or garbage: relative error bounded by 2^-15 at 1e-36."""
+    B, K, M, H, W = 1, 32, 64, 8, 32
+    x = synth.normal((B, K, H, W), 'w6.tx').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 'w6.tw') / (3 * math.sqrt(K))).to(DEV)
+    for s, bar in ((1e-33, 1e-5), (1e-36, 2 ** -15)):
+        xs = (x * s).contiguous()
+        want = F.conv2d(xs.double(), w.double(), padding=1)
+        got = _lib.conv(xs, _lib.conv_pack(w, _lib.PACK_W6FWD), _lib.CONV_3X3W6, M, H, W)
+        assert torch.isfinite(got).all()
+        e = float((got.double() - want).norm() / want.norm())
+        print(f'split-bf16 at input scale {s:g}: L2 vs fp64 {e:.2e}')
+        assert e < bar
+
+
+@pytest.mark.parametrize('form', [0, 1])
+def test_split_bf16_winograd_non_finite_inputs_propagate_like_the_direct_kernel(form):
+    """Inf / NaN in the input reach exactly the outputs whose 3x3 windows contain them - the set the direct fp32 kernel marks - and
+    nothing else; every other output is unaffected (same value as without the planted element, 5e-6).  WHAT the marked outputs hold
+    differs by design: the direct kernel gives w * inf = +-inf where the split kernel gives NaN (inf = h, inf - h = NaN is the
+    second piece; and Winograd's t = d0 - d2 may cancel infinities) - a non-finite value either way, documented in te_hip.h."""
+    B, K, M, H, W = 2, 32, 64, 16, 64
+    x = synth.normal((B, K, H, W), 'w6.nx').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 'w6.nw') / (3 * math.sqrt(K))).to(DEV)
+    w = torch.where(w.abs() < 1e-3, torch.full_like(w, 1e-3), w)        # no exact zeros / tiny taps: w * inf is +-inf in the direct kernel
+    clean = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W)
+    plants = [(0, 3, 5, 17, float('inf')), (0, 7, 0, 0, float('-inf')), (1, 30, 15, 63, float('nan')), (1, 0, 8, 31, float('inf')),
+              (0, 16, 7, 32, float('nan')), (1, 5, 15, 0, float('-inf'))]     # interior, corners, tile borders (x = 31 | 32, y = 7 | 8)
+    xp = x.clone()
+    for b, k, y, xx, v in plants:
+        xp[b, k, y, xx] = v
+    old = _lib.wino6_form(form)
+    try:
+        got = _lib.conv(xp, _lib.conv_pack(w, _lib.PACK_W6FWD), _lib.CONV_3X3W6, M, H, W)
+    finally:
+        _lib.wino6_form(old)
+    direct = _lib.conv(xp, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_3X3, M, H, W)
+    bad_direct, bad_got = ~torch.isfinite(direct), ~torch.isfinite(got)
+    expect = torch.zeros(B, 1, H, W, dtype=torch.bool, device=DEV)
+    for b, k, y, xx, v in plants:
+        expect[b, 0, max(0, y - 1):y + 2, max(0, xx - 1):xx + 2] = True
+    expect = expect.expand(B, M, H, W)
+    assert torch.equal(bad_direct, expect)              # (the yardstick itself)
+    assert torch.equal(bad_got, expect), f'{int((bad_got ^ expect).sum())} outputs differ in finiteness'
+    fin = ~expect
+    assert rel_err(got[fin], clean[fin]) < 5e-6
+
+
+@pytest.mark.parametrize('B,K,M,H,W', W6_SHAPES + [(2, 160, 64, 8, 64), (1, 96, 64, 32, 32)])
+def test_split_bf16_kernel_forms_are_bit_identical(B, K, M, H, W):
+    """ping-pong (round 5, default) and block-phase (round 4) forms of TE_CONV_3X3W6 issue the same products in the same order per
+    output element: identical bits, with every epilogue stage, on single- and multi-tile images and 2 - 32 channel stages"""
+    x = synth.normal((B, K, H, W), f'w6.fx.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f'w6.fw.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 'w6.fi')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'w6.fo')).to(DEV)
+    bias = synth.normal((M,), 'w6.fb').to(DEV)
+    res, mref = synth.normal((B, M, H, W), 'w6.fr').to(DEV), synth.normal((B, M, H, W), 'w6.fm').to(DEV)
+    u6 = _lib.conv_pack(w, _lib.PACK_W6FWD, 0.9)
+    out = {}
+    old = _lib.wino6_form(-1)
+    try:
+        for form in (0, 1):
+            _lib.wino6_form(form)
+            out[form] = (_lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, isc, osc, bias, 3),
+                         _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, None, None, bias, 4, res=res, mask_ref=mref, mask_gain=1.3),
+                         _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W))
+    finally:
+        _lib.wino6_form(old)
+    assert _lib.wino6_form(-1) == old
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)

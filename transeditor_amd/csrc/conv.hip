@@ -90,7 +90,8 @@ template <int KIND, int TC> constexpr int tile_cells() { return (4 / Cfg<KIND, T
 
 struct ConvArgs {
     float* out;
-    float* ws;               // split-K partial sums [ksplit][B][M][Ho][Wo] (NULL: accumulate into `out` with atomics)
+    float* ws;               // split-K partial sums [ksplit][B][M][Ho][Wo] (NULL: the launch does not split - te_conv_f32 - same result up to
+                             // summation order, slower on 4x4 ... 16x16 images; there are no atomics in this library)
     const float* in;
     const float* wp;
     const float* isc;

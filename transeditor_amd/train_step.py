@@ -85,8 +85,24 @@ def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_opti
         except ValueError:
             pass
         ckpt = torch.load(ckpt, map_location=device)
+    # all or nothing, like the reference's restore (:475-492): every argument is checked BEFORE anything is loaded
+    training = {'g': generator, 'd': discriminator, 'g_optim': g_optim, 'd_optim': d_optim}
+    given = [k for k, v in training.items() if v is not None]
+    if given:
+        missing_obj = [k for k, v in training.items() if v is None]
+        if missing_obj:
+            raise ValueError(f'load_checkpoint_into: a training restore needs generator, discriminator, g_optim and d_optim together '
+                             f'(got {given}, missing {missing_obj}); pass none of them to load g_ema only')
+        missing_key = [k for k in training if k not in ckpt]
+        if missing_key:
+            raise KeyError(f"load_checkpoint_into: the checkpoint holds no {missing_key} (keys: {sorted(ckpt)}): it is a 'g_ema'-only "
+                           f'file; call without generator / discriminator / optimisers')
+    elif 'g' in ckpt:
+        import warnings
+        warnings.warn("load_checkpoint_into: full training checkpoint ('g', 'd', 'g_optim', 'd_optim' present) loaded into g_ema only",
+                      stacklevel=2)
     g_ema.load_state_dict(ckpt['g_ema'])
-    if 'g' in ckpt and generator is not None:
+    if given:
         generator.load_state_dict(ckpt['g'])
         discriminator.load_state_dict(ckpt['d'])
         g_optim.load_state_dict(ckpt['g_optim'])
