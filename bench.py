@@ -302,7 +302,7 @@ def attach_counters(roof, live=True):
     roof['mfma_util_pct'], roof['mhz'] = top['mfma_util_pct'], top['mhz']
     roof['traffic_note'] = (f'LIVE: {note} over tools/kernel_once.py inside this bench run (outside the timed region); per launch of '
                             f'the dominant kernel at its top shape (3x3 128->128 @256x256, batch 16): FETCH_SIZE x2 (gfx950 '
-                            f'correction) + WRITE_SIZE vs {top["algorithmic_bytes"] / 1e6:.0f} MB algorithmic')
+                            f'correction) + WRITE_SIZE vs {(top["algorithmic_bytes"] or 0) / 1e6:.0f} MB algorithmic')
     roof['counters'] = ctr
     roof['hbm_bound_kernels'] = hbm_tail
     return roof

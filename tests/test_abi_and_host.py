@@ -389,8 +389,8 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
 
 def test_load_checkpoint_into_is_all_or_nothing():
     """train_step.load_checkpoint_into validates its arguments BEFORE loading anything (the reference's restore,
-    train_spatial_query.py:475-492, is all-or-nothing): a partial set of training objects or a 'g_ema'-only file with training
-    objects raises and leaves every module untouched; a full checkpoint into g_ema only warns."""
+    train_spatial_query.py:475-492, is all-or-nothing): a partial set of training objects or a file with some but not all training
+    entries raises and leaves every module untouched; a 'g_ema'-only file loads the EMA generator alone; a full checkpoint into g_ema only warns."""
     import warnings
 
     import torch
@@ -406,8 +406,11 @@ def test_load_checkpoint_into_is_all_or_nothing():
     with pytest.raises(ValueError):
         load_checkpoint_into(full, ema, generator=g)                    # partial set of training objects
     with pytest.raises(KeyError):
-        load_checkpoint_into({'g_ema': full['g_ema']}, ema, g, d, go, do)   # 'g_ema'-only file, training restore asked for
+        load_checkpoint_into({k: full[k] for k in ('g_ema', 'g', 'd')}, ema, g, d, go, do)   # neither a training nor a g_ema-only file
     assert torch.equal(ema.weight, before)                                  # nothing was loaded on the failed attempts
+    gw = g.weight.clone()
+    load_checkpoint_into({'g_ema': src['d'].state_dict()}, ema, g, d, go, do)   # a g_ema-only file: the EMA generator alone
+    assert torch.equal(ema.weight, src['d'].weight) and torch.equal(g.weight, gw)
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter('always')
         load_checkpoint_into(full, ema)

@@ -114,3 +114,61 @@ def test_reference_scripts_resolve_through_the_shim_and_bind_to_our_signatures()
     assert our_args[:len(ref_args)] == ref_args, (our_args, ref_args)
     our_defaults = [p.default for p in ours.parameters.values() if p.default is not inspect.Parameter.empty]
     assert our_defaults[:len(ref_defaults)] == ref_defaults
+
+
+def test_legacy_ddp_outputs_restores_differentiation_between_wrapper_outputs():
+    """torch >= 1.9: DistributedDataParallel(find_unused_parameters=True) returns its outputs through an identity autograd node, so
+    the reference's path-length step - autograd.grad of one output of the wrapped generator w.r.t. another (train_spatial_query.py:
+    226-232, :92-105) - raises; `utils.distributed.legacy_ddp_outputs()` (called by the drop-in `utils.distributed` on import)
+    restores the behaviour of the torch the reference pins.  gloo, one rank, CPU, a two-output toy module."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from transeditor_amd.utils.distributed import legacy_ddp_outputs
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.unused = torch.nn.Linear(4, 4), torch.nn.Linear(4, 3), torch.nn.Linear(2, 2)
+
+        def forward(self, x):
+            latent = self.a(x)
+            return torch.tanh(self.b(latent)), latent
+
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        net = Toy()
+        wrapped = DistributedDataParallel(net, find_unused_parameters=True, broadcast_buffers=False)
+        x = torch.randn(5, 4)
+
+        def path_step():
+            img, latent = wrapped(x)
+            g, = torch.autograd.grad(img.sum(), latent, create_graph=True)
+            wrapped.zero_grad()
+            g.pow(2).sum().backward()
+            return [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+
+        assert legacy_ddp_outputs(False)                 # torch's own behaviour
+        with pytest.raises(RuntimeError, match='not have been used in the graph'):
+            path_step()
+        assert legacy_ddp_outputs(True)
+        got = path_step()
+        img, latent = net(x)                             # the unwrapped module: same gradients, unused parameters without one
+        g, = torch.autograd.grad(img.sum(), latent, create_graph=True)
+        net.zero_grad()
+        g.pow(2).sum().backward()
+        for a, p in zip(got, net.parameters()):
+            assert (a is None) == (p.grad is None)
+            if a is not None:
+                assert torch.allclose(a, p.grad, rtol=0, atol=1e-6)
+        assert got[-1] is None and got[-2] is None       # `unused`
+    finally:
+        legacy_ddp_outputs(False)
+        dist.destroy_process_group()

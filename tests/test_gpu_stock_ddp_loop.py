@@ -12,6 +12,10 @@ Compared with `TrainStep` (the route every other test takes) on the same weights
     not, so the two build different graphs of the same function - every parameter gradient within 2e-4 (relative L2);
   * `.grad is None` exactly for the parameters DDP leaves unused (the noise-injection weights: 7 at 32 px, 13 at 256);
   * then two iterations with the real learning rate: stock Adam on DDP-reduced gradients keeps our parameters on FusedAdam's trajectory.
+FOUND by this test: on torch >= 1.9 the reference's path-length step fails under its own DDP wrapper - the wrapper returns
+`latents` and `fake_img` through an identity node (`_DDPSink`), so one is no longer an ancestor of the other - whatever model sits inside
+(the reference pins torch 1.7).  The test first shows that stock behaviour, then applies `utils.distributed.legacy_ddp_outputs()` (what
+the drop-in package does on import) and runs the loop.
 The group has one rank (the box has one GPU): the all-reduce is RCCL's, the arithmetic is sum / 1.  Runs in a child process
 with a timeout."""
 import os
@@ -163,12 +167,15 @@ def _compare(a, b):
     res = {}
     for key in a:
         worst, same, pat, nnone = 0.0, True, True, 0
+        top = max(float(y.double().norm()) for y in b[key] if y is not None)
         for x, y in zip(a[key], b[key]):
             pat = pat and ((x is None) == (y is None))
             if x is None or y is None:
                 nnone += x is None
                 continue
             same = same and torch.equal(x, y)
+            if float(y.double().norm()) <= 1e-6 * top:       # analytically zero (a key bias shifts every logit of a softmax row alike:
+                continue                                      # interact.*.atten.k_transform.bias) - round-off on both sides
             d = float((x.double() - y.double()).norm())
             n = float(y.double().norm())
             worst = max(worst, d / n if n > 0 else d)
@@ -184,6 +191,22 @@ def _worker(port, q):
     real = synth.normal((BATCH, 3, SIZE, SIZE), 'ddp.real').clamp(-1, 1).cuda()
     dist.init_process_group('nccl', rank=0, world_size=1)
     try:
+        # (0) torch's own behaviour first: the outputs of a find_unused_parameters wrapper pass an identity node, so the returned
+        # latents are not what the returned image was computed from - the reference's path-length step cannot run on torch >= 1.9
+        from torch.nn.parallel import DistributedDataParallel
+        from transeditor_amd.train_step import g_path_regularize
+        from transeditor_amd.utils.distributed import legacy_ddp_outputs
+        _, g_module, _ = _models()
+        wrapped = DistributedDataParallel(g_module, device_ids=[0], output_device=0, broadcast_buffers=False, find_unused_parameters=True)
+        z, p = _Sampler().latents(2)
+        img, lat, _ = wrapped(z, p, return_latents=True)
+        try:
+            g_path_regularize(img, lat, 0, torch.randn_like(img))
+            stock_error = None
+        except RuntimeError as e:
+            stock_error = str(e)
+        del wrapped, g_module, img, lat
+        assert legacy_ddp_outputs()                      # what dropin/utils/distributed.py does on import
         # (1) learning rate 0: every sub-step of both routes sees the SAME weights, gradients comparable one by one
         ref0, _ = _reference_loop(0.0, real, 1)
         ts0, _ = _train_step_route(0.0, real, 1)
@@ -198,7 +221,7 @@ def _worker(port, q):
                 finite = finite and bool(torch.isfinite(x).all())
                 close.append(float(((x - y).abs() <= 1e-3 + 1e-2 * y.abs()).float().mean()))
             pdiff[net] = (min(close), finite)
-        q.put((cmp0, pdiff))
+        q.put((cmp0, pdiff, stock_error))
     finally:
         dist.destroy_process_group()
 
@@ -209,12 +232,14 @@ def test_reference_loop_under_stock_ddp_and_adam_matches_train_step():
     pr = ctx.Process(target=_worker, args=(_free_port(), q))
     pr.start()
     try:
-        cmp0, pdiff = q.get(timeout=600)
+        cmp0, pdiff, stock_error = q.get(timeout=600)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
             pr.kill()
     assert pr.exitcode == 0
+    # torch >= 1.9: the unpatched wrapper breaks the reference's path-length step (whatever the model); legacy_ddp_outputs() repairs it
+    assert stock_error is not None and 'not have been used in the graph' in stock_error, stock_error
     print('stock DDP loop vs TrainStep (max rel-L2 over parameters, bit-identical, same None pattern, unused):',
           {k: (f'{v[0]:.2e}', v[1], v[2], v[3]) for k, v in cmp0.items()})
     for key in ('d0', 'g0'):                     # first order: the same kernels in the same order

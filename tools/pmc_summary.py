@@ -11,6 +11,7 @@ KEEP = ('conv_mfma', 'wino3x3', 'wino6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile
 # algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
 ALG = {
     'wino6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),       # algorithmic (direct-form) FLOPs
+    'wino6p_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the ping-pong form, round 5)
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),

@@ -94,9 +94,11 @@ def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_opti
             raise ValueError(f'load_checkpoint_into: a training restore needs generator, discriminator, g_optim and d_optim together '
                              f'(got {given}, missing {missing_obj}); pass none of them to load g_ema only')
         missing_key = [k for k in training if k not in ckpt]
-        if missing_key:
-            raise KeyError(f"load_checkpoint_into: the checkpoint holds no {missing_key} (keys: {sorted(ckpt)}): it is a 'g_ema'-only "
-                           f'file; call without generator / discriminator / optimisers')
+        if len(missing_key) == len(training):
+            given = []               # a 'g_ema'-only file (the published inference checkpoints, test_spatial_query.py:285): EMA generator alone
+        elif missing_key:
+            raise KeyError(f'load_checkpoint_into: the checkpoint holds {sorted(k for k in training if k in ckpt)} but not '
+                           f'{missing_key}: neither a training checkpoint (train_spatial_query.py:361-371) nor a g_ema-only file')
     elif 'g' in ckpt:
         import warnings
         warnings.warn("load_checkpoint_into: full training checkpoint ('g', 'd', 'g_optim', 'd_optim' present) loaded into g_ema only",

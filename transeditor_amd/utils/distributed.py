@@ -296,3 +296,32 @@ class GradSync:
         for bi in range(len(self.buckets)):
             self._seen[bi].clear()
             self._work[bi] = None
+
+
+def legacy_ddp_outputs(enable=True):
+    """Compatibility switch for running the reference's UNCHANGED loop (train_spatial_query.py:494-509 wraps both networks in
+    `DistributedDataParallel(find_unused_parameters=True)`) on a current PyTorch.
+
+    Since torch 1.9 such a wrapper returns its outputs through an identity autograd node (`_DDPSink`): the `latents` handed back
+    next to `fake_img` are then NEW tensors which `fake_img` does not descend from, and the reference's path-length regulariser -
+    `autograd.grad((fake_img * noise).sum(), latents, create_graph=True)` on the outputs of the WRAPPED generator (:226-232,
+    g_path_regularize :92-105) - raises "One of the differentiated Tensors appears to not have been used in the graph", whatever
+    model sits inside the wrapper (found by tests/test_gpu_stock_ddp_loop.py; the reference pins torch 1.7, environment.yaml:130,
+    which has no sink).  `legacy_ddp_outputs()` restores the 1.7 behaviour - outputs returned as the module produced them - by
+    replacing that node with a pass-through; `dropin/utils/distributed.py` calls it on import (TE_DROPIN_KEEP_DDP_SINK=1 keeps
+    torch's behaviour).  The product's own loop (TrainStep + GradSync) does not use DistributedDataParallel and is unaffected.
+    Returns True when the switch took effect."""
+    import torch.nn.parallel.distributed as ddp
+    if not hasattr(ddp, '_DDPSink'):
+        return False
+    if not hasattr(ddp, '_te_original_sink'):
+        ddp._te_original_sink = ddp._DDPSink
+
+    class _PassThrough:
+        @staticmethod
+        def apply(ddp_weakref, *inputs):
+            return inputs
+
+    ddp._DDPSink = _PassThrough if enable else ddp._te_original_sink
+    return True
+
