@@ -147,6 +147,12 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
                             non-finite - the same set as TE_CONV_3X3 - but as NaN where the direct kernel gives +-Inf
                             (inf = h, inf - h = NaN is the second piece).  TE_SPLIT_BF16=0 (host) selects TE_CONV_3X3W instead. */
 
+#define TE_CONV_S2S6 6   /* TE_CONV_S2 with its products on the bf16 matrix pipe (three-piece split, six exact piece products per multiply-add,
+                            fp32 accumulation: fp32-equivalent like TE_CONV_3X3W6, same range / non-finite behaviour).
+                            Shapes: te_conv_s2s6_supported; weights packed TE_PACK_S6FWD / TE_PACK_S6SWAP; never split.
+                            Reference: F.conv2d(stride 2) of ConvLayer(downsample=True), model_spatial_query.py:765-779, and the adjoint
+                            of conv_transpose2d(stride 2), :318 */
+
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */
 #define TE_PACK_FWD 0    /* M = Co, K = Ci, taps as stored         (forward 3x3 / 1x1 / T2, and S2) */
@@ -157,6 +163,9 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_PACK_W6FWD 5  /* TE_CONV_3X3W6 forward: U = G w split into bf16 pieces, MFMA fragment order
                             U6[K/16][piece][ky][c][M/32][64 lanes][8 bf16]  (36 K M bf16 = 18 K M floats; Co % 32 == Ci % 32 == 0) */
 #define TE_PACK_W6DGRAD 6 /* TE_CONV_3X3W6 data gradient (flipped, transposed taps; M = Ci)                               */
+#define TE_PACK_S6FWD 7  /* TE_CONV_S2S6, M = Co, K = Ci, taps as stored: three bf16 pieces per weight, MFMA fragment order
+                            S6[K/16][piece][tap][M/32][64 lanes][8 bf16]  (27 K M bf16; Co % 32 == Ci % 32 == 0)                  */
+#define TE_PACK_S6SWAP 8 /* TE_CONV_S2S6 as data gradient of the transposed kind: M = Ci, K = Co, taps as stored                  */
 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
@@ -191,6 +200,8 @@ int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
 int te_conv_wino_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_3X3W6 covers the problem: K % 32 == 0, M % 64 == 0, H % 8 == 0, W % 32 == 0 */
 int te_conv_wino6_supported(int B, int K, int M, int H, int W);
+/* 1 if TE_CONV_S2S6 covers the problem (H, W = OUTPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
+int te_conv_s2s6_supported(int B, int K, int M, int H, int W);
 /* Kernel form of TE_CONV_3X3W6 (process-wide; returns the previous value; anything but 0 / 1 only queries):
  *   1 = ping-pong (round 5, default): the two waves of every SIMD work half a stage apart - one feeds the matrix pipe from its
  *       half tile while the other transforms / splits / writes the next half tile and renews half of the weight image;

@@ -376,7 +376,13 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
     assert modconv.bwd_kinds('3x3', 16, w(256, 512), 64, 64) == (_lib.PACK_W6DGRAD, _lib.CONV_3X3W6)
     assert modconv.fwd_kinds('3x3', 4, w(32, 32), 1024, 1024) == (_lib.PACK_WFWD, _lib.CONV_3X3W)
     assert modconv.fwd_kinds('3x3', 16, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)
-    assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_T2 and modconv.bwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_S2
+    # (round 5) the strided kind on the bf16 pipe where te_conv_s2s6_supported says so: the up-sampling layers' data gradient and the
+    # discriminator's down-sampling convolutions from 16 x 16 outputs up; smaller images stay on the fp32 kernel
+    assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_T2
+    assert modconv.bwd_kinds('up', 16, w(256, 512), 64, 64) == (_lib.PACK_S6SWAP, _lib.CONV_S2S6)
+    assert modconv.fwd_kinds('down', 32, w(256, 128), 128, 128) == (_lib.PACK_S6FWD, _lib.CONV_S2S6)
+    assert modconv.fwd_kinds('down', 32, w(512, 512), 8, 8) == (_lib.PACK_FWD, _lib.CONV_S2)
+    assert modconv.bwd_kinds('up', 16, w(512, 512), 4, 4) == (_lib.PACK_SWAP, _lib.CONV_S2)
     old = modconv.USE_SPLIT_BF16, modconv.USE_WINOGRAD
     try:
         modconv.USE_SPLIT_BF16 = False

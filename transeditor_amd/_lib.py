@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
 _lib = None
 
-CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6 = 0, 1, 2, 3, 4, 5
-PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD = 0, 1, 2, 3, 4, 5, 6
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6, CONV_S2S6 = 0, 1, 2, 3, 4, 5, 6
+PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD, PACK_S6FWD, PACK_S6SWAP = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
@@ -41,6 +41,7 @@ _SIGNATURES = {
     'te_conv_wino_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_form': (C.c_int, [_I]),
+    'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -333,6 +334,11 @@ def conv_pack_multi(jobs):
 def wino_ok(B, K, M, H, W):
     """does TE_CONV_3X3W (1-D Winograd F(2,3): 2/3 of the MFMAs of the direct 3x3 kernel) cover this problem?"""
     return bool(lib().te_conv_wino_supported(B, K, M, H, W))
+
+
+def s2s6_ok(B, K, M, H, W):
+    """does TE_CONV_S2S6 (the stride-2 convolution on the bf16 matrix pipe, three-piece split) cover this problem?  H, W = output size"""
+    return bool(lib().te_conv_s2s6_supported(B, K, M, H, W))
 
 
 def wino6_form(form=-1):

@@ -29,3 +29,7 @@ int te_wino_launch(float* out, const float* in, const float* U, const float* isc
 // kind TE_CONV_3X3W6, weights packed TE_PACK_W6FWD / TE_PACK_W6DGRAD in MFMA fragment order
 int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                     const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);
+// csrc/s2s6.hip: the 3x3 / stride 2 / pad 0 convolution on the bf16 matrix pipe (three-piece split, six products: fp32-equivalent);
+// kind TE_CONV_S2S6, weights packed TE_PACK_S6FWD / TE_PACK_S6SWAP in MFMA fragment order
+int te_s2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
+                   const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);

@@ -72,14 +72,15 @@ class _ResBlock(Function):
         if yb.shape[2] % 2 == 0 or yb.shape[3] % 2 == 0:
             raise RuntimeError(f'resblock: blurred size {tuple(yb.shape[2:])} is not (2h+1)x(2w+1)')
         h, w_ = (yb.shape[2] - 1) // 2, (yb.shape[3] - 1) // 2
+        pk2, ck2 = fwd_kinds('down', x.shape[0], w2, h, w_)     # (the split-bf16 form of the strided convolution where it applies)
         if front:
-            wp2, wp2b = packed2(w2, _lib.PACK_FWD, _bwd_pack_kind('down'), s2)
+            wp2, wp2b = packed2(w2, pk2, _bwd_pack_kind('down'), s2)
         else:
-            wp2, wp2b = packed(w2, _lib.PACK_FWD, s2), None
+            wp2, wp2b = packed(w2, pk2, s2), None
         act2 = 3 if abs(_SQRT2 * gain - _SQRT2) < 1e-6 else 4
         if act2 == 4 and abs(_SQRT2 * gain - 1.0) > 1e-6:
             raise RuntimeError(f'resblock: leaky-ReLU gain {_SQRT2 * gain} is not one the kernels fuse (sqrt(2) or 1)')
-        y2 = _lib.conv(yb, wp2, _lib.CONV_S2, w2.shape[0], h, w_, None, None, b2, act2)
+        y2 = _lib.conv(yb, wp2, ck2, w2.shape[0], h, w_, None, None, b2, act2)
         ps = (pad_skip[0], pad_skip[1], pad_skip[0], pad_skip[1])
         xs = _lib.upfirdn2d_raw(x, k_skip, (1, 1), (2, 2), ps)
         if xs.shape[2:] != y2.shape[2:]:
