@@ -109,7 +109,7 @@ class KernelTimer:
         orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
         names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1',
                  _lib.CONV_3X3W: 'conv3x3', _lib.CONV_3X3W6: 'conv3x3',         # (Winograd forms of the same convolution: same algorithmic FLOPs)
-                 _lib.CONV_S2S6: 'convS2'}                                      # (the strided kind on the bf16 pipe)
+                 _lib.CONV_S2S6: 'convS2', _lib.CONV_T2S6: 'convT2'}            # (the strided / transposed kinds on the bf16 pipe)
 
         def conv(x, wp, kind, M, H, W, *a, **k):
             if not timer.enabled:
@@ -124,13 +124,15 @@ class KernelTimer:
             # the Winograd form EXECUTES 12/18 of the direct form's multiply-adds for the same (algorithmic) convolution; the split form
             # (TE_CONV_3X3W6) executes them as SIX bf16 piece products each on the bf16 matrix pipe and none on the fp32 one
             # (TE_CONV_S2S6: no Winograd form, six piece products per multiply-add = 6x the algorithmic FLOPs on the bf16 pipe)
-            ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind in (_lib.CONV_3X3W6, _lib.CONV_S2S6) else 1.0))
-            ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else (6.0 if kind == _lib.CONV_S2S6 else 0.0))
+            ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind in (_lib.CONV_3X3W6, _lib.CONV_S2S6, _lib.CONV_T2S6) else 1.0))
+            ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else (6.0 if kind in (_lib.CONV_S2S6, _lib.CONV_T2S6) else 0.0))
             timer.records.append((names[kind], flops, s, e, ex32, ex16))
             if kind == _lib.CONV_3X3W6:       # the dominant kernel on its own (a VIEW of the conv3x3 class, never summed with it)
                 timer.records.append(('conv3x3_split_bf16', flops, s, e, ex32, ex16))
             if kind == _lib.CONV_S2S6:
                 timer.records.append(('convS2_split_bf16', flops, s, e, ex32, ex16))
+            if kind == _lib.CONV_T2S6:
+                timer.records.append(('convT2_split_bf16', flops, s, e, ex32, ex16))
             return out
 
         def wgrad(g, x, kind, H, W, *a, **k):

@@ -153,6 +153,11 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
                             Reference: F.conv2d(stride 2) of ConvLayer(downsample=True), model_spatial_query.py:765-779, and the adjoint
                             of conv_transpose2d(stride 2), :318 */
 
+#define TE_CONV_T2S6 7   /* TE_CONV_T2 with its products on the bf16 matrix pipe (three-piece split, fp32-equivalent like TE_CONV_3X3W6): the body
+                            cells [0,H) x [0,W) in csrc/t2s6.hip, the last output row and column through the fp32 kernel.
+                            Shapes: te_conv_t2s6_supported; weights packed TE_PACK_T6FWD / TE_PACK_T6SWAP; never split; no residual / mask.
+                            Reference: conv_transpose2d(stride 2) of ModulatedConv2d.forward, model_spatial_query.py:310-321 */
+
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */
 #define TE_PACK_FWD 0    /* M = Co, K = Ci, taps as stored         (forward 3x3 / 1x1 / T2, and S2) */
@@ -166,6 +171,8 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_PACK_S6FWD 7  /* TE_CONV_S2S6, M = Co, K = Ci, taps as stored: three bf16 pieces per weight, MFMA fragment order
                             S6[K/16][piece][tap][M/32][64 lanes][8 bf16]  (27 K M bf16; Co % 32 == Ci % 32 == 0)                  */
 #define TE_PACK_S6SWAP 8 /* TE_CONV_S2S6 as data gradient of the transposed kind: M = Ci, K = Co, taps as stored                  */
+#define TE_PACK_T6FWD 9  /* TE_CONV_T2S6, M = Co, K = Ci: the TE_PACK_S6FWD layout followed (16-byte aligned) by the TE_PACK_FWD layout  */
+#define TE_PACK_T6SWAP 10 /* TE_CONV_T2S6 as data gradient of the strided kind: TE_PACK_S6SWAP followed by TE_PACK_SWAP                   */
 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
@@ -202,6 +209,8 @@ int te_conv_wino_supported(int B, int K, int M, int H, int W);
 int te_conv_wino6_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_S2S6 covers the problem (H, W = OUTPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
 int te_conv_s2s6_supported(int B, int K, int M, int H, int W);
+/* 1 if TE_CONV_T2S6 covers the problem (H, W = INPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
+int te_conv_t2s6_supported(int B, int K, int M, int H, int W);
 /* Kernel form of TE_CONV_3X3W6 (process-wide; returns the previous value; anything but 0 / 1 only queries):
  *   1 = ping-pong (round 5, default): the two waves of every SIMD work half a stage apart - one feeds the matrix pipe from its
  *       half tile while the other transforms / splits / writes the next half tile and renews half of the weight image;

@@ -378,7 +378,9 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
     assert modconv.fwd_kinds('3x3', 16, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)
     # (round 5) the strided kind on the bf16 pipe where te_conv_s2s6_supported says so: the up-sampling layers' data gradient and the
     # discriminator's down-sampling convolutions from 16 x 16 outputs up; smaller images stay on the fp32 kernel
-    assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64)[1] == _lib.CONV_T2
+    assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64) == (_lib.PACK_T6FWD, _lib.CONV_T2S6)
+    assert modconv.fwd_kinds('up', 16, w(512, 512), 8, 8) == (_lib.PACK_FWD, _lib.CONV_T2)
+    assert modconv.bwd_kinds('down', 32, w(256, 128), 128, 128) == (_lib.PACK_T6SWAP, _lib.CONV_T2S6)
     assert modconv.bwd_kinds('up', 16, w(256, 512), 64, 64) == (_lib.PACK_S6SWAP, _lib.CONV_S2S6)
     assert modconv.fwd_kinds('down', 32, w(256, 128), 128, 128) == (_lib.PACK_S6FWD, _lib.CONV_S2S6)
     assert modconv.fwd_kinds('down', 32, w(512, 512), 8, 8) == (_lib.PACK_FWD, _lib.CONV_S2)

@@ -1,0 +1,107 @@
+"""TE_CONV_T2S6: the transposed 3x3 / stride 2 convolution on the bf16 matrix pipe (csrc/t2s6.hip: body cells, three bf16 pieces per
+fp32 operand, six exact piece products per multiply-add, fp32 accumulation; last output row / column through the fp32 kernel from the
+plain copy of the weights in the same packed buffer) against fp64 torch and against the fp32 kernel (TE_CONV_T2) - both weight layouts
+(forward of the generator's up-sampling layers, conv_transpose2d(stride 2) of ModulatedConv2d.forward, model_spatial_query.py:310-321;
+data gradient of the discriminator's down-sampling convolutions, :765-779), style scale at staging, demodulation scale / bias /
+leaky-ReLU epilogue, image borders (the halo row above / column left of the image, the last output row and column), single- and
+multi-tile images, the range sweep, non-finite inputs, the selection rule.  Pinned at the bar of the fp32 kernels: 5e-6 against fp64."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from transeditor_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+SHAPES = [(2, 32, 64, 8, 16), (3, 96, 192, 24, 32), (1, 48, 64, 16, 48), (2, 160, 128, 8, 16), (1, 512, 512, 16, 16), (2, 128, 256, 32, 64),
+          (4, 64, 64, 8, 16)]
+
+
+@pytest.mark.parametrize('B,K,M,H,W', SHAPES)
+def test_split_bf16_transposed_conv_vs_fp64(B, K, M, H, W):
+    assert _lib.t2s6_ok(B, K, M, H, W)
+    x = synth.normal((B, K, H, W), f't6.x.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f't6.w.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)          # model layout [Co, Ci, 3, 3]
+    isc = (1 + 0.3 * synth.normal((B, K), 't6.isc')).to(DEV)
+    osc = (1 + 0.3 * synth.normal((B, M), 't6.osc')).to(DEV)
+    ws = 0.83
+    want = F.conv_transpose2d(x.double() * isc.double()[:, :, None, None], (w.double() * ws).transpose(0, 1), stride=2) * osc.double()[:, :, None, None]
+    got = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_T6FWD, ws), _lib.CONV_T2S6, M, H, W, isc, osc)
+    direct = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD, ws), _lib.CONV_T2, M, H, W, isc, osc)
+    assert got.shape == (B, M, 2 * H + 1, 2 * W + 1)
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    print(f'split-bf16 transposed {K}->{M} @{H}x{W}: max {rel_err(got, want):.2e} (fp32 kernel {rel_err(direct, want):.2e}), L2 {l2(got):.2e} ({l2(direct):.2e})')
+    assert rel_err(got, want) < 5e-6
+    assert l2(got) < 2.5 * l2(direct) + 1e-7
+    # the border rows / columns on their own (the halo of the body tiles and the two fp32 regions)
+    for sl in ((slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(2 * H - 1, None)),
+               (slice(None), slice(None), slice(None), slice(0, 2)), (slice(None), slice(None), slice(None), slice(2 * W - 1, None))):
+        assert rel_err(got[sl], want[sl]) < 5e-6
+    # the launch as data gradient of the strided kind: from M to K channels on the swapped layout (weight [Co = M, Ci = K, 3, 3])
+    if _lib.t2s6_ok(B, M, K, H, W):
+        g = synth.normal((B, M, H, W), f't6.g.{M}.{H}').to(DEV)
+        want_g = F.conv_transpose2d(g.double(), w.double() * ws, stride=2)
+        got_g = _lib.conv(g, _lib.conv_pack(w, _lib.PACK_T6SWAP, ws), _lib.CONV_T2S6, K, H, W)
+        assert rel_err(got_g, want_g) < 5e-6
+
+
+@pytest.mark.parametrize('act', [0, 3, 4])
+def test_split_bf16_transposed_conv_epilogue(act):
+    B, K, M, H, W = 2, 64, 128, 8, 32
+    x = synth.normal((B, K, H, W), 't6.ex').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 't6.ew') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 't6.ei')).to(DEV), (1 + 0.3 * synth.normal((B, M), 't6.eo')).to(DEV)
+    bias = synth.normal((M,), 't6.eb').to(DEV)
+    a = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_T6FWD), _lib.CONV_T2S6, M, H, W, isc, osc, bias, act)
+    b = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_T2, M, H, W, isc, osc, bias, act)
+    pre = F.conv_transpose2d(x.double() * isc.double()[:, :, None, None], w.double().transpose(0, 1), stride=2) * osc.double()[:, :, None, None] \
+        + bias.double()[None, :, None, None]
+    keep = (pre.abs() > 1e-5) if act else torch.ones_like(pre, dtype=torch.bool)
+    assert rel_err(a * keep, b * keep) < 5e-6
+
+
+@pytest.mark.parametrize('scale', [1e-30, 1e-15, 1e+15, 1e+30])
+def test_split_bf16_transposed_conv_scale_sweep(scale):
+    B, K, M, H, W = 2, 64, 128, 8, 32
+    x = (synth.normal((B, K, H, W), 't6.sx') * math.sqrt(scale)).to(DEV)
+    w = (synth.normal((M, K, 3, 3), 't6.sw') / (3 * math.sqrt(K)) * math.sqrt(scale)).to(DEV)
+    want = F.conv_transpose2d(x.double(), w.double().transpose(0, 1), stride=2)
+    got = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_T6FWD), _lib.CONV_T2S6, M, H, W)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 5e-6
+
+
+def test_split_bf16_transposed_conv_non_finite_inputs_propagate_like_the_fp32_kernel():
+    B, K, M, H, W = 2, 32, 64, 8, 32
+    x = synth.normal((B, K, H, W), 't6.nx').to(DEV)
+    w = (synth.normal((M, K, 3, 3), 't6.nw') / (3 * math.sqrt(K))).to(DEV)
+    w = torch.where(w.abs() < 1e-3, torch.full_like(w, 1e-3), w)
+    clean = _lib.conv(x, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_T2, M, H, W)
+    xp = x.clone()
+    for b, k, y, xx, v in [(0, 3, 5, 17, float('inf')), (0, 7, 0, 0, float('-inf')), (1, 30, 7, 31, float('nan')), (1, 0, 3, 15, float('inf')),
+                           (0, 16, 4, 16, float('nan'))]:
+        xp[b, k, y, xx] = v
+    got = _lib.conv(xp, _lib.conv_pack(w, _lib.PACK_T6FWD), _lib.CONV_T2S6, M, H, W)
+    direct = _lib.conv(xp, _lib.conv_pack(w, _lib.PACK_FWD), _lib.CONV_T2, M, H, W)
+    expect = ~torch.isfinite(direct)
+    assert int(expect.sum()) > 0
+    assert torch.equal(~torch.isfinite(got), expect)
+    assert rel_err(got[~expect], clean[~expect]) < 5e-6
+
+
+def test_split_bf16_transposed_selection():
+    from transeditor_amd.op import modconv
+    e = torch.empty
+    assert modconv.fwd_kinds('up', 16, e(128, 256, 3, 3), 128, 128) == (_lib.PACK_T6FWD, _lib.CONV_T2S6)
+    assert modconv.bwd_kinds('down', 32, e(256, 128, 3, 3), 128, 128) == (_lib.PACK_T6SWAP, _lib.CONV_T2S6)
+    assert modconv.fwd_kinds('up', 16, e(512, 512, 3, 3), 8, 8) == (_lib.PACK_FWD, _lib.CONV_T2)
+    old = modconv.USE_SPLIT_T2
+    try:
+        modconv.USE_SPLIT_T2 = False
+        assert modconv.fwd_kinds('up', 16, e(128, 256, 3, 3), 128, 128) == (_lib.PACK_FWD, _lib.CONV_T2)
+    finally:
+        modconv.USE_SPLIT_T2 = old

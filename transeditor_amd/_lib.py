@@ -13,8 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
 _lib = None
 
-CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6, CONV_S2S6 = 0, 1, 2, 3, 4, 5, 6
-PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD, PACK_S6FWD, PACK_S6SWAP = 0, 1, 2, 3, 4, 5, 6, 7, 8
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6, CONV_S2S6, CONV_T2S6 = 0, 1, 2, 3, 4, 5, 6, 7
+(PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD, PACK_S6FWD, PACK_S6SWAP, PACK_T6FWD,
+ PACK_T6SWAP) = range(11)
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
@@ -42,6 +43,7 @@ _SIGNATURES = {
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_form': (C.c_int, [_I]),
     'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_conv_t2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -341,6 +343,11 @@ def s2s6_ok(B, K, M, H, W):
     return bool(lib().te_conv_s2s6_supported(B, K, M, H, W))
 
 
+def t2s6_ok(B, K, M, H, W):
+    """does TE_CONV_T2S6 (the transposed stride-2 convolution on the bf16 matrix pipe) cover this problem?  H, W = input (low-res) size"""
+    return bool(lib().te_conv_t2s6_supported(B, K, M, H, W))
+
+
 def wino6_form(form=-1):
     """kernel form of TE_CONV_3X3W6: 1 = ping-pong (default), 0 = block-phase; returns the previous value (-1: query only)"""
     return int(lib().te_conv_wino6_form(form))
@@ -352,7 +359,7 @@ def wino6_ok(B, K, M, H, W):
 
 
 def conv_out_shape(kind, B, M, H, W):
-    if kind == CONV_T2:
+    if kind in (CONV_T2, CONV_T2S6):
         return (B, M, 2 * H + 1, 2 * W + 1)
     return (B, M, H, W)
 

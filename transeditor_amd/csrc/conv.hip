@@ -750,6 +750,8 @@ __global__ __launch_bounds__(256) void conv_finalize_kernel(float* __restrict__ 
 // ------------------------------------------------------------------------------------------ weight packing
 // up to 64 (weight, layout) jobs in one launch: the packed layouts of a whole model are refreshed right after an optimiser step
 // (blockIdx.y = job) instead of one tiny launch per layer at first use
+// TE_PACK_T6FWD / T6SWAP: [split fragment-order layout, 27 K M bf16][plain layout 9 Kp Mp floats]; offset of the second part in floats
+__host__ __device__ inline int64_t t6_plain_offset(int K, int M) { return ((((int64_t)27 * K * M + 1) / 2) + 3) / 4 * 4; }
 struct PackJob { float* wp; const float* w; float wscale; int kind, Ci, ntap, K, M, Kp, Mp; };
 struct PackJobs { PackJob j[64]; };
 // Tiled through LDS (round 4): a block takes a 32 (co) x 32 (ci) x taps tile.  The model layout [Co][Ci][tap] is read in rows of
@@ -762,7 +764,8 @@ constexpr int PT = 32;
 template <int T>
 __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
     constexpr int RL = PT * T + 1, NE = PT * PT * T;
-    const bool fwd = q.kind == TE_PACK_FWD || q.kind == TE_PACK_WFWD || q.kind == TE_PACK_W6FWD || q.kind == TE_PACK_S6FWD;
+    const bool fwd = q.kind == TE_PACK_FWD || q.kind == TE_PACK_WFWD || q.kind == TE_PACK_W6FWD || q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD;
+    const bool t6 = q.kind == TE_PACK_T6FWD || q.kind == TE_PACK_T6SWAP;      // split layout + plain layout behind it
     const int Co = fwd ? q.M : q.K, Ci = fwd ? q.K : q.M;              // real extents of the source along co / ci
     const int CoP = fwd ? q.Mp : q.Kp, CiP = fwd ? q.Kp : q.Mp;        // padded extents of the packed layout (zero filled)
     const int tiles_i = (CiP + PT - 1) / PT, tiles_c = (CoP + PT - 1) / PT;
@@ -807,12 +810,12 @@ __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
                 const size_t ps = (size_t)12 * MT * 512;
                 dst[at] = (unsigned short)h; dst[at + ps] = (unsigned short)mm; dst[at + 2 * ps] = (unsigned short)ll;
             }
-        } else if (T == 9 && (q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_S6SWAP)) {
+        } else if (T == 9 && (q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_S6SWAP || t6)) {
             // the taps as stored, every value split into three bf16 pieces, MFMA fragment order (s2s6.hip):
             // S6[k / 16][piece][tap][m / 32][lane = m % 32 + 32 * (k % 16 / 8)][k % 8]; forward: m = co, k = ci; swap: m = ci, k = co
-            const bool wf = q.kind == TE_PACK_S6FWD;
+            const bool wf = q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD;
             unsigned short* dst = reinterpret_cast<unsigned short*>(q.wp);
-            const int MT = q.Mp >> 5;
+            const int MT = q.M >> 5;
             for (int e = threadIdx.x; e < PT * PT * 9; e += 256) {
                 const int j = e & 7, ml = (e >> 3) & 31, kh = (e >> 8) & 1, st = (e >> 9) & 1, tap = e >> 10;
                 const int kl = st * 16 + kh * 8 + j;                                    // k inside the tile
@@ -833,6 +836,20 @@ __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
                 const size_t at = slot * 512 + (size_t)((m & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
                 const size_t ps = (size_t)9 * MT * 512;
                 dst[at] = (unsigned short)h; dst[at + ps] = (unsigned short)mm; dst[at + 2 * ps] = (unsigned short)ll;
+            }
+            if (t6) {      // TE_PACK_T6FWD / T6SWAP: the plain layout of the same weights behind the split one (thin fp32 regions of TE_CONV_T2S6)
+                float* wp2 = q.wp + t6_plain_offset(q.K, q.M);
+                for (int e = threadIdx.x; e < NE; e += 256) {
+                    if (fwd) {
+                        const int r = e % PT, x = e / PT, ii = x % PT, tap = x / PT;
+                        const int co = c0 + r, ci = i0 + ii;
+                        if (co < CoP && ci < CiP) wp2[((size_t)tap * q.Kp + ci) * q.Mp + co] = tile[r * RL + ii * T + tap];
+                    } else {
+                        const int ii = e % PT, x = e / PT, r = x % PT, tap = x / PT;
+                        const int co = c0 + r, ci = i0 + ii;
+                        if (co < CoP && ci < CiP) wp2[((size_t)tap * q.Kp + co) * q.Mp + ci] = tile[r * RL + ii * T + tap];
+                    }
+                }
             }
         } else if (T == 9 && (q.kind == TE_PACK_WFWD || q.kind == TE_PACK_WDGRAD)) {
             // Winograd F(2,3) weight transform (wino.hip): U[((k / 8 * 3 + ky) * 4 + c) * 8 + k % 8][m] = sum_kx G[c][kx] w(.., ky, kx),
@@ -881,11 +898,13 @@ inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 struct PackDims { int K, M, Kp, Mp, ntap; };
 inline bool pack_is_wino6(int kind_pack) { return kind_pack == TE_PACK_W6FWD || kind_pack == TE_PACK_W6DGRAD; }
 inline bool pack_is_s6(int kind_pack) { return kind_pack == TE_PACK_S6FWD || kind_pack == TE_PACK_S6SWAP; }
+inline bool pack_is_t6(int kind_pack) { return kind_pack == TE_PACK_T6FWD || kind_pack == TE_PACK_T6SWAP; }
 inline bool pack_is_wino(int kind_pack) { return kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_WDGRAD || pack_is_wino6(kind_pack); }
 inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     PackDims d;
     d.ntap = ksize * ksize;
-    const bool fwd = kind_pack == TE_PACK_FWD || kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_W6FWD || kind_pack == TE_PACK_S6FWD;
+    const bool fwd = kind_pack == TE_PACK_FWD || kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_W6FWD || kind_pack == TE_PACK_S6FWD ||
+                     kind_pack == TE_PACK_T6FWD;
     d.M = fwd ? Co : Ci;
     d.K = fwd ? Ci : Co;
     if (pack_is_wino(kind_pack) || pack_is_s6(kind_pack)) {          // U[K/8][ky][component][8][M]: no padding (K % 8 == 0, M % 128 == 0 are required)
@@ -1069,6 +1088,7 @@ extern "C" int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize
     const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
     // (the split layouts: 3 pieces x 12 x K x M bf16 = 18 K M floats)
     if (pack_is_s6(kind_pack)) return ((int64_t)27 * d.Kp * d.Mp + 1) / 2;          // 3 pieces x 9 taps x K x M bf16
+    if (pack_is_t6(kind_pack)) return t6_plain_offset(d.K, d.M) + (int64_t)d.ntap * d.Kp * d.Mp;
     return (int64_t)(pack_is_wino6(kind_pack) ? 18 : (pack_is_wino(kind_pack) ? 12 : d.ntap)) * d.Kp * d.Mp;
 }
 
@@ -1107,7 +1127,10 @@ static int pack_launch(const char* what, int n, float* const* wp, const float* c
             const int e = base + i;
             TE_REQUIRE(wp[e] && w[e], TE_ERR_NULL, "%s: NULL pointer in job %d", what, e);
             TE_REQUIRE(Co[e] > 0 && Ci[e] > 0 && (ksize[e] == 1 || ksize[e] == 3), TE_ERR_SHAPE, "%s: bad dims in job %d", what, e);
-            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 8, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 10, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(!pack_is_t6(kind_pack[e]) || (ksize[e] == 3 && (kind_pack[e] == TE_PACK_T6FWD ? (Co[e] % 32 == 0 && Ci[e] % 16 == 0)
+                                                                                                    : (Ci[e] % 32 == 0 && Co[e] % 16 == 0))),
+                       TE_ERR_UNSUPPORTED, "te_conv_pack_weights: the split layouts of TE_CONV_T2S6 need a 3x3 weight with M %% 32 == 0 and K %% 16 == 0");
             TE_REQUIRE(!pack_is_s6(kind_pack[e]) || (ksize[e] == 3 && (kind_pack[e] == TE_PACK_S6FWD ? (Co[e] % 32 == 0 && Ci[e] % 16 == 0)
                                                                                                     : (Ci[e] % 32 == 0 && Co[e] % 16 == 0))),
                        TE_ERR_UNSUPPORTED, "te_conv_pack_weights: the split layouts of TE_CONV_S2S6 need a 3x3 weight with M %% 32 == 0 and K %% 16 == 0");
@@ -1177,8 +1200,8 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
 }
 
 extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
-    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 6) return TE_ERR_SHAPE;
-    if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6) return 1;
+    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 7) return TE_ERR_SHAPE;
+    if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6 || kind == TE_CONV_T2S6) return 1;
     return conv_plan(kind, B, K, M, H, W).ksplit;
 }
 
@@ -1186,11 +1209,11 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
                                const float* bias, const float* res, const float* mask_ref, float mask_gain, int act, int kind,
                                int B, int K, int M, int H, int W, te_stream_t stream_) {
     TE_REQUIRE(out && in && wp, TE_ERR_NULL, "te_conv_f32: out/in/wp is NULL");
-    TE_REQUIRE(!(res || mask_ref) || kind != TE_CONV_T2, TE_ERR_UNSUPPORTED,
+    TE_REQUIRE(!(res || mask_ref) || (kind != TE_CONV_T2 && kind != TE_CONV_T2S6), TE_ERR_UNSUPPORTED,
                "te_conv_res_f32: no residual / mask epilogue for the transposed kind");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
-    TE_REQUIRE(kind >= 0 && kind <= 6, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
+    TE_REQUIRE(kind >= 0 && kind <= 7, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     hipStream_t s = (hipStream_t)stream_;
     if (kind == TE_CONV_3X3W) return te_wino_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);
     if (kind == TE_CONV_3X3W6) return te_wino6_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);
@@ -1198,6 +1221,19 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
     ConvArgs a{};
     a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
+    if (kind == TE_CONV_T2S6) {
+        // body cells on the bf16 pipe; the last output row and column (cells i = H, j = W) as two thin regions of the fp32 kernel,
+        // from the plain copy of the weights behind the split layout (TE_PACK_T6FWD / TE_PACK_T6SWAP)
+        int rc = te_t2s6_launch(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
+        if (rc) return rc;
+        a.wp = wp + t6_plain_offset(K, M);
+        a.ws = nullptr; a.ksplit = 1; a.kchunk = a.Kp;
+        a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
+        const int r[2][4] = {{0, W, H + 1, 1}, {H, 0, 1, W}};
+        rc = launch_regions<TE_CONV_T2>(a, r, 2, s, conv_plan(TE_CONV_T2, B, K, M, H, W).tc);
+        if (rc) return rc;
+        return te::launch_status("te_conv_f32(TE_CONV_T2S6)");
+    }
     const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
     const int tc = pl.tc;
     a.ksplit = pl.ksplit; a.kchunk = pl.kchunk;

@@ -33,3 +33,7 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
 // kind TE_CONV_S2S6, weights packed TE_PACK_S6FWD / TE_PACK_S6SWAP in MFMA fragment order
 int te_s2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                    const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s);
+// csrc/t2s6.hip: body cells of the transposed 3x3 / stride 2 convolution on the bf16 matrix pipe; kind TE_CONV_T2S6 (conv.hip adds the
+// last output row / column through the fp32 kernel), weights packed TE_PACK_T6FWD / TE_PACK_T6SWAP
+int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
+                   int B, int K, int M, int H, int W, hipStream_t s);

@@ -1,0 +1,291 @@
+// T2 on the bf16 matrix pipe (round 5, kind TE_CONV_T2S6): the transposed 3x3 / stride 2 convolution  in [B,K,H,W] -> out [B,M,2H+1,2W+1]
+// - the generator's up-sampling layers (conv_transpose2d(stride 2, pad 0) of ModulatedConv2d.forward, model_spatial_query.py:310-321)
+// and the data gradient of the discriminator's down-sampling convolutions (:765-779) - with every fp32 operand split into three bf16
+// pieces and six exact piece products per multiply-add accumulated in fp32 (wino6.hip / s2s6.hip: fp32-equivalent results).
+//
+// Polyphase form, as conv_mfma_kernel<TE_CONV_T2>: output pixel (2 i + a, 2 j + b) of cell (i, j) receives the taps with ky = a, kx = b
+// (mod 2) - 4 + 2 + 2 + 1 = 9 tap products per input pixel, no zero insertion - into FOUR accumulator tiles (one per phase); a tap with
+// ky = 2 (kx = 2) reads the input one row up (one column left).  This kernel covers the BODY cells [0, H) x [0, W), i.e. output rows
+// 0 .. 2H - 1 and columns 0 .. 2W - 1; the last output row and column (cells i = H / j = W, which only see taps with ky = 2 / kx = 2)
+// are two thin regions of the fp32 kernel, launched behind it from the fp32 copy of the weights that the packed buffer carries along
+// (TE_PACK_T6FWD / TE_PACK_T6SWAP = split fragment-order layout of s2s6.hip + TE_PACK_FWD / TE_PACK_SWAP layout; conv.hip).
+//
+// Structure = s2s6.hip (ping-pong form, read wino6.hip's header): block 512 threads, cell tile 64 output channels x 8 rows x 16 columns,
+// two half tiles of 4 cell rows (5 input rows x 17 columns each with the halo), wave (wm, wrl) of a group = 32 channels x cell rows
+// {2 wrl, 2 wrl + 1} x 16 columns x 4 phases (64 accumulator registers); 54 MFMAs per wave and stage of 16 input channels; the staging
+// arithmetic of a half (200 items: one per thread) rides behind the multiplying wave's own MFMAs; weights 54 KB per stage by LDS-DMA
+// in two halves (taps 0-4 / 5-8).  Input tile in LDS: T[piece][row 5][k half][24 columns (17 used)][8 bf16] - two rows are 48 chunks,
+// a multiple of 16, so the two cell rows of a B fragment never collide (conflict-free ds_read_b128).
+#include "conv_common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WT = 512, GT = 256, KC = 16, BM = 64;
+constexpr int TH = 8, TWC = 16, PH = 4;                       // cell tile 8 x 16, half tile 4 cell rows
+constexpr int IR = PH + 1, IC = TWC + 1;                      // input rows / columns of a half tile (with the halo): 5 x 17
+constexpr int CW = 24;                                        // chunks per (row, k half): 17 used
+constexpr int NTAP = 9;
+constexpr int U_SLOTS = 3 * NTAP * 2;                         // 54 fragment slots of 1 KB
+constexpr int TP_PLANE = IR * 2 * CW * 4;                     // dwords of one piece of a half tile: 960
+constexpr int TP_DWORDS = 3 * TP_PLANE;                       // 2 880 dwords = 11.25 KB
+constexpr int NG = (IC + 3) / 4;                              // 4-column groups per input row: 5 (the last one holds column 16 only)
+constexpr int N_ITEMS = IR * NG * 8;                          // (row, column group, channel pair) items of a half: 200 (one per thread)
+constexpr int N_SLOT = 1 + 16;                                // arithmetic slots: scale + 4 positions x 4 steps
+constexpr int SLOT0 = 24;                                     // MFMA behind which the program starts (54 per phase)
+constexpr int UA_TAPS = 5;                                    // taps 0-4: weight half a (30 slots), taps 5-8: half b (24 slots)
+
+struct T2Args {
+    float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; int act;
+    int B, K, M, H, W, Ho, Wo, ntiles, mblocks, tiles_x, tiles_y, nt8;
+};
+
+__device__ __forceinline__ void t2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep the role branches scalar
+    const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wrl = wq & 1, gt = tid & (GT - 1);
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + U_SLOTS * 1024) + grp * TP_DWORDS;      // this group's half tile
+    const u32x4* tl4 = reinterpret_cast<const u32x4*>(tl);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tq = jx / p.mblocks, mb = jx % p.mblocks;
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TWC, y0 = ty * TH, yh = y0 + PH * grp;
+    const size_t iplane = (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;
+    const float* inb = p.in + (size_t)b * p.K * iplane;
+    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+
+    f32x16 acc[4];                                     // one tile per output phase (a, b) = (ky & 1, kx & 1)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // staging geometry of this group's half: ONE item per thread, e = gt < 200 -> (column group cg = e % 5, channel pair q = (e / 5) % 8,
+    // row = e / 40); the item covers input columns x0 - 1 + 4 cg .. + 3 of input row yh - 1 + row, channels 2 q and 2 q + 1 of the stage.
+    // Branch-free edges (wino6.hip): the four floats are always loaded from inside the row - one column later at the left image
+    // border (column -1 does not exist), three columns earlier in the last group (only its first column, x0 + 15, belongs to the
+    // tile) - and the vector is patched when the item is scaled; the row above the image (yh = 0) is loaded from row 0 and zeroed.
+    const bool live = gt < N_ITEMS;
+    const int ee = live ? gt : 0;
+    const int cg = ee % NG, q = (ee / NG) & 7, row = ee / (NG * 8);
+    const bool left = x0 == 0 && cg == 0, last_col = cg == NG - 1, rowout = yh - 1 + row < 0;
+    const int gy = rowout ? 0 : yh - 1 + row;
+    const unsigned g_off = (unsigned)((2 * q * p.H + gy) * p.W + x0 - 1 + 4 * cg + (left ? 1 : 0) - (last_col ? 3 : 0));
+    const int l_off = ((row * 2 + (q >> 2)) * CW + 4 * cg) * 4 + (q & 3);          // + position * 4 + piece * TP_PLANE
+    const unsigned q2 = 2u * q;
+    const int MT = p.M >> 5;
+    f32x4 rin[2];
+    float rsc[2] = {1.f, 1.f};
+    const int nstage = p.K / KC;
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const float* base = inb + ((size_t)s * KC + h2) * iplane;
+            if (iscb) rsc[h2] = (iscb + s * KC + h2)[q2];
+            rin[h2] = *reinterpret_cast<const f32x4u*>(base + g_off);
+        }
+    };
+    // weight half `uh` of stage s: uh = 0: taps 0-4 (30 slots: 8 / 8 / 7 / 7 per wave), uh = 1: taps 5-8 (24 slots: 6 per wave)
+    auto issue_u = [&](int uh, int s) {
+        const u32x4* us = p.U + (size_t)s * 27 * MT * 64;
+        const int ntap = uh ? NTAP - UA_TAPS : UA_TAPS, tap0 = uh ? UA_TAPS : 0, n = ntap * 6;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int j = wq + 4 * r;                                          // slot of this half: (piece, tap, M tile)
+            if (j >= n) break;
+            const int piece = j / (ntap * 2), rem = j % (ntap * 2), tap = tap0 + (rem >> 1), mt = rem & 1;
+            const int pt = piece * NTAP + tap;
+            const u32x4* g = us + ((size_t)pt * MT + 2 * mb + mt) * 64 + (unsigned)lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ul + (pt * 2 + mt) * 64), 16, 0, 0);
+        }
+    };
+    // ---- the staging arithmetic as a program of 17 slots behind the MFMAs of the multiplying phase (wino6.hip):
+    //   slot 0: edge patch + style scale;  slots 1 + 4 c + j: position c of the item, the four steps of the three-piece split
+    unsigned res[4][3];
+    float te = 0.f, to = 0.f, fe = 0.f, fo = 0.f;
+    auto arith = [&](int k) {
+        if (k < 0) {
+        } else if (k == 0) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[h2];
+                if (left) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }        // loaded from column 0: position 0 is column -1
+                if (last_col) v[0] = v[3];                                               // loaded three columns early
+                if (rowout) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                rin[h2] = v * rsc[h2];
+                asm volatile("" : "+v"(rin[h2]));
+            }
+        } else if (k < N_SLOT) {
+            const int c = (k - 1) >> 2, j = (k - 1) & 3;
+            if (j == 0) {
+                te = rin[0][c]; to = rin[1][c];                              // even / odd channel of the pair at position c
+                const f32x2 t = {te, to};
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[c][0] = h;
+                fe = __builtin_bit_cast(float, h << 16);
+                fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
+                asm volatile("" : "+v"(res[c][0]));
+            } else if (j == 1) {
+                te -= fe; to -= fo;
+            } else if (j == 2) {
+                const f32x2 t = {te, to};
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[c][1] = m;
+                fe = __builtin_bit_cast(float, m << 16);
+                fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
+                asm volatile("" : "+v"(res[c][1]));
+            } else {
+                te -= fe; to -= fo;
+                const f32x2 t = {te, to};
+                res[c][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                asm volatile("" : "+v"(res[c][2]));
+            }
+            asm volatile("" : "+v"(te), "+v"(to), "+v"(fe), "+v"(fo));        // (pin the step here: see wino6.hip)
+        }
+    };
+    auto write_res = [&]() {
+        if (!live) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > 0 && last_col) continue;                             // (columns 17..19 do not exist in the tile)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) tl[l_off + c * 4 + pc * TP_PLANE] = res[c][pc];
+        }
+    };
+    const int rr = l31 >> 4, jj = l31 & 15;
+    // B operand of tap (ky, kx), piece pc: chunk ((2 wrl + rr + 1 - (ky == 2)) * 2 + half) * CW + jj + 1 - (kx == 2) + pc * TP_PLANE / 4
+    const int b_chunk = ((2 * wrl + rr + 1) * 2 + half) * CW + jj + 1;
+    const int a_chunk = wm * 64 + lane;                                 // + (piece * 9 + tap) * 128
+
+    // prologue: every group splits and writes its half of stage 0 and fetches stage 1; group 0 brings in the whole weight image
+    issue(0);
+    if (grp == 0) { issue_u(0, 0); issue_u(1, 0); }
+#pragma unroll
+    for (int k = 0; k < N_SLOT; ++k) arith(k);
+    write_res();
+    issue(1);
+    t2_wait_vm();
+    t2_barrier();
+    const int nphase = 2 * nstage;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const bool last = ph == nphase - 1;
+        if ((ph & 1) == grp) {
+            // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of the stage after (rin -> res)
+            bf16x8 av[2][3], bv[2][3];
+            auto rd1 = [&](int t, int slot, int qq) {
+                const int ky = t / 3, kx = t % 3;
+                if (qq < 3) av[slot][qq] = __builtin_bit_cast(bf16x8, ul[a_chunk + (qq * NTAP + t) * 128]);
+                else bv[slot][qq - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk - (ky == 2 ? 2 * CW : 0) - (kx == 2 ? 1 : 0) + (qq - 3) * (TP_PLANE / 4)]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq) rd1(0, 0, qq);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int slot = t & 1, c = ((t / 3) & 1) * 2 + ((t % 3) & 1);          // output phase of the tap
+                if (t == UA_TAPS - 1) t2_barrier();    // mid-phase barrier: in front of tap 4's MFMAs (operands read) and of the first read of half b
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < 6; ++qq) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[qq]], bv[slot][PB[qq]], acc[c], 0, 0, 0);
+                    if (t + 1 < NTAP && qq < 3) { rd1(t + 1, slot ^ 1, 2 * qq); rd1(t + 1, slot ^ 1, 2 * qq + 1); }
+                    arith(t * 6 + qq - SLOT0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
+            const int cs = (ph + 1) >> 1;
+            const bool work = cs >= 1 && cs < nstage;
+            const bool fetch = cs >= 1 && cs + 1 < nstage;
+            if (work) {
+                // group 1: DMA of weight half b first, then the fetch, and a COUNTED wait that covers the DMA only (s2s6.hip)
+                if (grp == 1) issue_u(1, cs);
+                __builtin_amdgcn_sched_barrier(0);
+                if (fetch) issue(cs + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                write_res();
+                if (grp == 1) {
+                    if (!fetch) t2_wait_vm();
+                    else if (iscb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+            }
+            t2_barrier();
+            if (work && grp == 0) { issue_u(0, cs); t2_wait_vm(); }
+        }
+        if (!last) t2_barrier();
+    }
+    // epilogue: demodulation scale, bias, leaky ReLU; phases (a, 0) and (a, 1) of a cell are adjacent output columns: one 8-byte store
+    const int mbase = mb * BM + wm * 32;
+    const int ci = yh + 2 * wrl + rr, cj = x0 + jj;
+    const size_t off0 = ((size_t)b * p.M + mbase) * oplane + (size_t)(2 * ci) * p.Wo + 2 * cj;
+    const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+    float scv[16], biv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+        scv[r] = p.osc ? p.osc[(size_t)b * p.M + mbase + dm] : 1.f;
+        biv[r] = p.bias ? p.bias[mbase + dm] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v0 = acc[a * 2][r] * scv[r] + biv[r], v1 = acc[a * 2 + 1][r] * scv[r] + biv[r];
+            if (p.act >= 3) {
+                v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+                v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
+            }
+            f32x2 v; v[0] = v0; v[1] = v1;
+            *reinterpret_cast<f32x2u*>(p.out + off0 + (size_t)dm * oplane + (size_t)a * p.Wo) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int te_conv_t2s6_supported(int B, int K, int M, int H, int W) {
+    if (!(B > 0 && K >= 32 && K % KC == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TWC && W % TWC == 0)) return 0;
+    return ((int64_t)M * (2 * H + 1) * (2 * W + 1) * 4 < 0x7FFFFFFF && (int64_t)K * H * W * 4 < 0x7FFFFFFF &&
+            (int64_t)B * (H / TH) * (W / TWC) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
+}
+
+// the body cells [0, H) x [0, W) of the transposed convolution (output rows 0 .. 2H - 1, columns 0 .. 2W - 1); conv.hip adds the last
+// output row and column as two thin regions of the fp32 kernel
+int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
+                   int B, int K, int M, int H, int W, hipStream_t s) {
+    TE_REQUIRE(te_conv_t2s6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
+               "te_conv_f32(TE_CONV_T2S6): needs K %% 16 == 0 (>= 32), M %% 64 == 0, H %% 8 == 0, W %% 16 == 0 (te_conv_t2s6_supported)");
+    TE_REQUIRE((reinterpret_cast<uintptr_t>(U) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
+               "te_conv_f32(TE_CONV_T2S6): 16-byte aligned packed weights required");
+    T2Args a{};
+    a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
+    a.B = B; a.K = K; a.M = M; a.H = H; a.W = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
+    a.tiles_x = W / TWC; a.tiles_y = H / TH; a.mblocks = M / BM;
+    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
+    const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
+    const size_t lds = (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)t2s6_kernel, 160 * 1024);
+    t2s6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    return te::launch_status("te_conv_f32(TE_CONV_T2S6)");
+}

@@ -338,11 +338,14 @@ def fwd_kinds(kind, B, w, H, W):
             return _lib.PACK_WFWD, _lib.CONV_3X3W
     if kind == 'down' and USE_SPLIT_BF16 and USE_SPLIT_S2 and _lib.s2s6_ok(B, w.shape[1], w.shape[0], H, W):
         return _lib.PACK_S6FWD, _lib.CONV_S2S6          # the stride-2 convolution on the bf16 matrix pipe (csrc/s2s6.hip)
+    if kind == 'up' and USE_SPLIT_BF16 and USE_SPLIT_T2 and _lib.t2s6_ok(B, w.shape[1], w.shape[0], H, W):
+        return _lib.PACK_T6FWD, _lib.CONV_T2S6          # the transposed stride-2 convolution likewise (csrc/t2s6.hip)
     return _lib.PACK_FWD, _KIND[kind]
 
 
 # TE_SPLIT_S2=0: the stride-2 launches stay on the fp32 matrix instructions while the 3x3 stride-1 ones keep the split form (A/B)
 USE_SPLIT_S2 = os.environ.get('TE_SPLIT_S2', '1') != '0'
+USE_SPLIT_T2 = os.environ.get('TE_SPLIT_T2', '1') != '0'
 
 
 def bwd_kinds(kind, B, w, H, W):
@@ -354,6 +357,8 @@ def bwd_kinds(kind, B, w, H, W):
             return _lib.PACK_WDGRAD, _lib.CONV_3X3W
     if kind == 'up' and USE_SPLIT_BF16 and USE_SPLIT_S2 and _lib.s2s6_ok(B, w.shape[0], w.shape[1], H, W):
         return _lib.PACK_S6SWAP, _lib.CONV_S2S6         # adjoint of the transposed kind = the strided one, from Co to Ci channels
+    if kind == 'down' and USE_SPLIT_BF16 and USE_SPLIT_T2 and _lib.t2s6_ok(B, w.shape[0], w.shape[1], H, W):
+        return _lib.PACK_T6SWAP, _lib.CONV_T2S6         # adjoint of the strided kind = the transposed one, from Co to Ci channels
     ck = {'up': _lib.CONV_S2, 'down': _lib.CONV_T2}.get(kind)          # adjoint of the transposed / strided kind
     return _bwd_pack_kind(kind), (ck if ck is not None else _KIND[kind])
 

@@ -74,7 +74,7 @@ class _ResBlock(Function):
         h, w_ = (yb.shape[2] - 1) // 2, (yb.shape[3] - 1) // 2
         pk2, ck2 = fwd_kinds('down', x.shape[0], w2, h, w_)     # (the split-bf16 form of the strided convolution where it applies)
         if front:
-            wp2, wp2b = packed2(w2, pk2, _bwd_pack_kind('down'), s2)
+            wp2, wp2b = packed2(w2, pk2, bwd_kinds('down', x.shape[0], w2, h, w_)[0], s2)     # (the layout _dgrad_raw's launch will ask for)
         else:
             wp2, wp2b = packed(w2, pk2, s2), None
         act2 = 3 if abs(_SQRT2 * gain - _SQRT2) < 1e-6 else 4
