@@ -36,12 +36,23 @@ def main():
     xl = torch.randn(B, 256, 128, 128, device=DEV)
     wu = torch.randn(128, 256, 3, 3, device=DEV) / 48
     iscu = torch.rand(B, 256, device=DEV) + 0.5
-    wpu = _lib.conv_pack(wu, _lib.PACK_FWD)
+    from transeditor_amd.op.modconv import bwd_kinds
+    pku, cku = fwd_kinds('up', B, wu, 128, 128)                                        # the forms the model runs (split-bf16 where they apply)
+    wpu = _lib.conv_pack(wu, pku)
     for _ in range(REP):
-        t = _lib.conv(xl, wpu, _lib.CONV_T2, 128, 128, 128, iscu, osc)                 # T2 fwd -> [B,128,257,257]
-    wps = _lib.conv_pack(wu, _lib.PACK_SWAP)
+        t = _lib.conv(xl, wpu, cku, 128, 128, 128, iscu, osc)                          # T2 fwd -> [B,128,257,257]
+    pks, cks = bwd_kinds('up', B, wu, 128, 128)
+    wps = _lib.conv_pack(wu, pks)
     for _ in range(REP):
-        _lib.conv(t, wps, _lib.CONV_S2, 256, 128, 128, osc, iscu)                      # S2 (dgrad of T2)
+        _lib.conv(t, wps, cks, 256, 128, 128, osc, iscu)                               # S2 (dgrad of T2)
+    if cku != _lib.CONV_T2:                                                            # the fp32 kernels at the same shapes
+        wpu32 = _lib.conv_pack(wu, _lib.PACK_FWD)
+        for _ in range(REP):
+            _lib.conv(xl, wpu32, _lib.CONV_T2, 128, 128, 128, iscu, osc)
+    if cks != _lib.CONV_S2:
+        wps32 = _lib.conv_pack(wu, _lib.PACK_SWAP)
+        for _ in range(REP):
+            _lib.conv(t, wps32, _lib.CONV_S2, 256, 128, 128, osc, iscu)
     for _ in range(REP):
         _lib.wgrad_slabs(t, xl, _lib.CONV_T2, 128, 128)                                # wgrad T2
     k = torch.tensor([1., 3., 3., 1.], device=DEV)

@@ -7,11 +7,13 @@ import json
 import re
 import sys
 
-KEEP = ('conv_mfma', 'wino3x3', 'wino6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
+KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
 # algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
 ALG = {
     'wino6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),       # algorithmic (direct-form) FLOPs
     'wino6p_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the ping-pong form, round 5)
+    's2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    't2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
