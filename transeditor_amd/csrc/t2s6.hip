@@ -73,14 +73,15 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-    // staging geometry of this group's half: ONE item per thread, e = gt < 200 -> (column group cg = e % 5, channel pair q = (e / 5) % 8,
+    // staging geometry of this group's half: ONE item per thread, e = gt < 200 -> (pair-in-chunk e % 4, column group cg = (e / 4) % 5, k half (e / 20) % 2,
     // row = e / 40); the item covers input columns x0 - 1 + 4 cg .. + 3 of input row yh - 1 + row, channels 2 q and 2 q + 1 of the stage.
     // Branch-free edges (wino6.hip): the four floats are always loaded from inside the row - one column later at the left image
     // border (column -1 does not exist), three columns earlier in the last group (only its first column, x0 + 15, belongs to the
     // tile) - and the vector is patched when the item is scaled; the row above the image (yh = 0) is loaded from row 0 and zeroed.
     const bool live = gt < N_ITEMS;
     const int ee = live ? gt : 0;
-    const int cg = ee % NG, q = (ee / NG) & 7, row = ee / (NG * 8);
+    // (pair-in-chunk fastest over the lanes: four lanes fill one 16-byte chunk - at most two lanes of a write group share a bank)
+    const int dq = ee & 3, rest = ee >> 2, cg = rest % NG, q = ((rest / NG) & 1) * 4 + dq, row = rest / (NG * 2);
     const bool left = x0 == 0 && cg == 0, last_col = cg == NG - 1, rowout = yh - 1 + row < 0;
     const int gy = rowout ? 0 : yh - 1 + row;
     const unsigned g_off = (unsigned)((2 * q * p.H + gy) * p.W + x0 - 1 + 4 * cg + (left ? 1 : 0) - (last_col ? 3 : 0));
