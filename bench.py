@@ -236,7 +236,8 @@ PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6', 'conv3x3_fp32_winograd
                'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
                'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
                'convT2_256to128_at128_b16': 't2s6_kernel', 'convS2_128to256_at128_b16': 's2s6_kernel',
-               'convT2_fp32_kernel_same_shape': 'conv_mfma_kernel<1', 'convS2_fp32_kernel_same_shape': 'conv_mfma_kernel<2',
+               'convT2_fp32_kernel_same_shape': 'conv_mfma_kernel<1, 0, true, false, 2, true', 'convS2_fp32_kernel_same_shape': 'conv_mfma_kernel<2',
+               'convT2_last_row_and_column_fp32_regions': 'conv_mfma_kernel<1, 0, true, false, 2, false',
                'wgradT2_256x128_at128_b16': 'wgrad_mfma_kernel<1'}
 
 

@@ -17,7 +17,7 @@ ALG = {
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
-    'conv_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'conv_mfma_kernel<1, 0, true, false, 2, true': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wgrad_mfma_kernel<1': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'blur44_kernel<1': dict(flops=0, bytes=16 * 128 * (257 * 257 + 2 * 256 * 256) * 4),       # AG: g + ref (256^2) -> 257^2
