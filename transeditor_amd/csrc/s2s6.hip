@@ -201,7 +201,10 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    s2_wait_vm();
+    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 12 loads, 6 without style scales - stays in flight)
+        if (iscb) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     s2_barrier();
     const int nphase = 2 * nstage;
     for (int ph = 0; ph < nphase; ++ph) {

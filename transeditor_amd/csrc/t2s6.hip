@@ -179,7 +179,10 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    t2_wait_vm();
+    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 4 loads, 2 without style scales - stays in flight)
+        if (iscb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
     t2_barrier();
     const int nphase = 2 * nstage;
     for (int ph = 0; ph < nphase; ++ph) {

@@ -478,7 +478,12 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    w6p_wait_vm();
+    // (only the weight DMA has to have landed at the barrier: a COUNTED wait in group 0 leaves the fetch of stage 1 - 8 loads, 6 without
+    //  style scales - in flight; waiting for it too cost every block one HBM latency, ~2 of the ~8 us a block spends outside its stages)
+    if (grp == 0) {
+        if (iscb) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
     w6p_barrier();
     const int nphase = 2 * nstage;
     if (W6P_PRIO == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
