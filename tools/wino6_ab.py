@@ -28,7 +28,7 @@ def rel2(a, b):
 
 def main():
     print('variant', os.environ.get('VARIANT', 'product'), flush=True)
-    small = [(2, 32, 64, 8, 32), (3, 96, 192, 24, 32), (2, 64, 64, 16, 64), (1, 32, 128, 40, 96), (2, 160, 64, 8, 64), (1, 48 * 2, 64, 32, 32)]
+    small = [(40, 32, 64, 8, 32), (2, 32, 64, 8, 32), (3, 96, 192, 24, 32), (2, 64, 64, 16, 64), (1, 32, 128, 40, 96), (2, 160, 64, 8, 64), (1, 48 * 2, 64, 32, 32)]
     big = [(16, 128, 128, 256, 256), (16, 256, 256, 128, 128), (16, 512, 512, 64, 64), (16, 512, 512, 32, 32)]
     bad = 0
     only_big = bool(os.environ.get('ONLY_BIG'))      # tuning variants: timing at the four large shapes only
