@@ -1199,6 +1199,27 @@ static ConvPlan conv_plan(int kind, int B, int K, int M, int H, int W) {
     return pl;
 }
 
+// a non-blocking side stream + fork / join events per (host thread, device): the autograd engine's backward threads call the ABI
+// concurrently, each gets its own.  Created on first use, never destroyed (they live as long as the process).
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; bool ok; };
+static SideStream* side_stream() {
+    static const bool enabled = getenv("TE_T2_SIDE_STREAM") && atoi(getenv("TE_T2_SIDE_STREAM")) != 0;      // OFF by default, see te_conv_res_f32
+    if (!enabled) return nullptr;
+    constexpr int MAXDEV = 16;
+    static thread_local SideStream tab[MAXDEV] = {};
+    static thread_local bool tried[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    if (!tried[dev]) {
+        tried[dev] = true;
+        SideStream& t = tab[dev];
+        t.ok = hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return tab[dev].ok ? &tab[dev] : nullptr;
+}
+
 extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
     if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 7) return TE_ERR_SHAPE;
     if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6 || kind == TE_CONV_T2S6) return 1;
@@ -1223,15 +1244,35 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     if (kind == TE_CONV_T2S6) {
         // body cells on the bf16 pipe; the last output row and column (cells i = H, j = W) as two thin regions of the fp32 kernel,
-        // from the plain copy of the weights behind the split layout (TE_PACK_T6FWD / TE_PACK_T6SWAP)
-        int rc = te_t2s6_launch(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
-        if (rc) return rc;
+        // from the plain copy of the weights behind the split layout (TE_PACK_T6FWD / TE_PACK_T6SWAP).  The thin launch is a few dozen
+        // blocks that each walk the whole channel loop (130 - 150 us of latency for < 1 GFLOP: 28 % of a 128-channel launch,
+        // tools/block_overhead_probe.py); it writes other output pixels than the body, so it runs on a SIDE stream of this host thread,
+        // forked from and joined back into the caller's stream with events (also legal inside a stream capture), concurrently with
+        // the body kernel - OPT-IN (TE_T2_SIDE_STREAM=1).  Measured (round 5, same box, alternating runs): the launch alone gains 3 - 11 %
+        // (168 / 172 / 172 / 97 against 163 / 164 / 155 / 89 TFLOP/s at the four large shapes), the training iteration LOSES 2 % (118.5 /
+        // 119.6 against 121.4 / 122.1 img/s: three more runtime calls per launch on a host thread that is already the pacemaker of the
+        // short kernels around it).  Default: both launches on the caller's stream, one after the other.
         a.wp = wp + t6_plain_offset(K, M);
         a.ws = nullptr; a.ksplit = 1; a.kchunk = a.Kp;
         a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
         const int r[2][4] = {{0, W, H + 1, 1}, {H, 0, 1, W}};
-        rc = launch_regions<TE_CONV_T2>(a, r, 2, s, conv_plan(TE_CONV_T2, B, K, M, H, W).tc);
-        if (rc) return rc;
+        const int tc = conv_plan(TE_CONV_T2, B, K, M, H, W).tc;
+        SideStream* side = side_stream();
+        int rc;
+        if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {
+            rc = launch_regions<TE_CONV_T2>(a, r, 2, side->stream, tc);
+            const hipError_t e1 = hipEventRecord(side->join, side->stream);
+            const int rc2 = te_t2s6_launch(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
+            const hipError_t e2 = hipStreamWaitEvent(s, side->join, 0);       // (join even if a launch failed: the stream stays consistent)
+            if (rc) return rc;
+            if (rc2) return rc2;
+            if (e1 != hipSuccess || e2 != hipSuccess) return te::fail((int)(e1 != hipSuccess ? e1 : e2), "te_conv_f32(TE_CONV_T2S6): side-stream join failed");
+        } else {
+            rc = te_t2s6_launch(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s);
+            if (rc) return rc;
+            rc = launch_regions<TE_CONV_T2>(a, r, 2, s, tc);
+            if (rc) return rc;
+        }
         return te::launch_status("te_conv_f32(TE_CONV_T2S6)");
     }
     const ConvPlan pl = conv_plan(kind, B, K, M, H, W);
