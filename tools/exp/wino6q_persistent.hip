@@ -12,14 +12,18 @@
 //     What it would take: the epilogue out of line (an s_setpc call or a separate tail phase with its own register budget), or a
 //     zero-C first MFMA per item instead of the zeroing.  Per-block overhead it was after: 14.7 % of an 8-stage launch, 4.1 % of a
 //     32-stage one (tools/block_overhead_probe.py).
+// Second attempt (the kernel below): the phase body in TWO instances - boundary phases (0 and 2 nstage - 1 of an item) with the
+// epilogue / decode code, hot inner phases without (needs #include <type_traits>).  Still bit-identical, still slow: 141 / 177 / 201 /
+// 208 TFLOP/s, and already 1.7x slower on launches whose blocks have ONE item - the cost is per phase, not per item.  The function is
+// 9 200 lines of ISA (wino6p_kernel: 4 000), i.e. beyond the 64 KB instruction cache two CUs share, while the two waves of every SIMD sit in
+// different regions of it (multiplying stream / staging): the suspect is instruction fetch, not the data path.  A persistent form
+// needs the item-boundary code OUT of line (real calls for decode and the epilogue) and the prologue's copy of the arithmetic program gone.
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Round 5: the PERSISTENT ping-pong form (wino6q_kernel, form 2).  A block of wino6p_kernel spends ~8 us outside its stages (first
-// fetch at HBM latency, 72 KB weight DMA, group 1's stores, launch): 14.7 % of a launch whose blocks have 8 stages (128 channels),
-// 4.1 % at 32 (tools/block_overhead_probe.py).  Here a block keeps its CU and walks a list of (tile, M block) items: the software
-// pipeline simply continues across the item boundary - while the last stages of item k are multiplied, stage 0 of item k + 1 is fetched,
-// transformed and written, its weight halves arrive on the usual schedule - and an item's stores happen at the start of its group's
-// next staging phase, in the shadow of the partner's multiplying phase.  Geometry of the even / odd items of the block's list lives in
-// two register sets; everything else (phases, barriers, DMA protocol, arithmetic program) is wino6p_kernel's.
+// Round 5: the PERSISTENT ping-pong form (wino6q_kernel, form 2; header of tools/exp/wino6q_persistent.hip for the first attempt).
+// A block keeps its CU and walks a list of (tile, M block) items; the software pipeline continues across the item boundary (while the
+// last stages of item k are multiplied, stage 0 of item k + 1 is fetched, transformed and written, its weight halves arrive on the
+// usual schedule) and an item's stores happen in its group's next staging phase.  The phase body exists in TWO instances: the
+// boundary phases (0 and 2 nstage - 1 of an item) carry the epilogue / decode code, the hot inner phases do not.
 __global__ __launch_bounds__(WT, 2) void wino6q_kernel(const Wino6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -254,67 +258,81 @@ __global__ __launch_bounds__(WT, 2) void wino6q_kernel(const Wino6Args p) {
     }
     w6p_barrier();
     const int nphase = 2 * nstage;
-    for (int k = 0; k < n_items; ++k) {
-        for (int ph = 0; ph < nphase; ++ph) {
-            const bool last = k == n_items - 1 && ph == nphase - 1;
-            if ((ph & 1) == grp) {
-                // ---- multiply this group's half of stage ph / 2 of item k; behind the MFMAs: the arithmetic of the stage in rin (the next
-                // stage of this item or stage 0 of the next one; at the very end it runs on stale registers and is never written)
-                bf16x8 av[2][3], bv[2][3];
-                auto rd1 = [&](int g, int slot, int q) {
-                    const int ky = g >> 2, c = g & 3;
-                    if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((q * 3 + ky) * 4 + c) * 128]);
-                    else bv[slot][q - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk + (((q - 3) * 4 + c) * PR + ky) * 2 * NP]);
-                };
-                constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+    // one phase of the pipeline.  EPI (compile time): this instance may end an item - store it, decode the item after next; the
+    // instance of the hot inner phases (1 .. 2 nstage - 2) has no such code, so its register allocation is wino6p_kernel's
+    auto run_phase = [&](int k, int ph, auto EPI) {
+        constexpr bool with_epi = decltype(EPI)::value;
+        const bool last = k == n_items - 1 && ph == nphase - 1;
+        if ((ph & 1) == grp) {
+            // ---- multiply this group's half of stage ph / 2 of item k; behind the MFMAs: the arithmetic of the stage in rin
+            bf16x8 av[2][3], bv[2][3];
+            auto rd1 = [&](int g, int slot, int q) {
+                const int ky = g >> 2, c = g & 3;
+                if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((q * 3 + ky) * 4 + c) * 128]);
+                else bv[slot][q - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk + (((q - 3) * 4 + c) * PR + ky) * 2 * NP]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
 #pragma unroll
-                for (int q = 0; q < 6; ++q) rd1(0, 0, q);
-                __builtin_amdgcn_s_setprio(1);
+            for (int q = 0; q < 6; ++q) rd1(0, 0, q);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int g = 0; g < 12; ++g) {
-                    const int slot = g & 1, c = g & 3;
-                    if (g == 5) w6p_barrier();             // mid-phase barrier
+            for (int g = 0; g < 12; ++g) {
+                const int slot = g & 1, c = g & 3;
+                if (g == 5) w6p_barrier();             // mid-phase barrier
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
+                    if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
+                    arith(g * 6 + q - W6P_SLOT0);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
-                        if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
-                        arith(g * 6 + q - W6P_SLOT0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
-                __builtin_amdgcn_s_setprio(0);
-            } else {
-                // ---- stage.  csl = local stage being staged; csl == nstage means stage 0 of the NEXT item (group 0 in its last phase of
-                // an item); group 1 stages stage 0 of item k >= 1 in phase 0 (stage 0 of item 0 was the prologue's)
-                const int csl = (ph + 1) >> 1;
-                const int it = k + (csl == nstage ? 1 : 0), sl = csl == nstage ? 0 : csl;
-                const bool work = it < n_items && !(it == 0 && sl == 0);
-                int fit = it, fl = sl + 1;
-                if (fl == nstage) { fit = it + 1; fl = 0; }
-                const bool fetch = work && fit < n_items;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // ---- stage.  csl = local stage being staged; csl == nstage means stage 0 of the NEXT item (group 0 in its last phase of
+            // an item); group 1 stages stage 0 of item k >= 1 in phase 0 (stage 0 of item 0 was the prologue's)
+            const int csl = (ph + 1) >> 1;
+            const int it = k + (csl == nstage ? 1 : 0), sl = csl == nstage ? 0 : csl;
+            const bool work = it < n_items && !(it == 0 && sl == 0);
+            int fit = it, fl = sl + 1;
+            if (fl == nstage) { fit = it + 1; fl = 0; }
+            const bool fetch = work && fit < n_items;
+            if (grp == 1 && work) issue_u(1, it & 1, sl);
+            if (work) {
+                if (grp == 0 && fetch) issue(fit & 1, fl);
+                __builtin_amdgcn_sched_barrier(0);
+                write_res();
+                if (grp == 1) w6p_wait_vm();
+            }
+            w6p_barrier();
+            if (work && grp == 0) { issue_u(0, it & 1, sl); w6p_wait_vm(); }
+            if constexpr (with_epi) {
                 // an item just ended for this group (group 0: its last multiplying phase was the previous one of item k; group 1: of item
-                // k - 1): store it - in the shadow of the partner's multiplying phase - and decode the item after next into its register set
+                // k - 1): store it LATE in the staging phase (the split pieces have left their registers, group 0's fetch and DMA have
+                // landed, group 1's fetch is not in flight yet) and decode the item after next into its register set
                 const bool epi = grp == 0 ? csl == nstage : (ph == 0 && k >= 1);
                 const int ek = grp == 0 ? k : k - 1;
-                if (grp == 1 && work) issue_u(1, it & 1, sl);
-                if (work) {
-                    if (grp == 0 && fetch) issue(fit & 1, fl);
-                    __builtin_amdgcn_sched_barrier(0);
-                    write_res();
-                    if (grp == 1) w6p_wait_vm();
-                }
-                w6p_barrier();
-                if (work && grp == 0) { issue_u(0, it & 1, sl); w6p_wait_vm(); }
-                // (the stores of the finished item LATE in the staging phase: the split pieces have left their registers, group 0's fetch and
-                //  DMA have landed - its vmcnt(0) - and group 1's fetch is not in flight yet, so the epilogue's loads wait for nothing)
                 if (epi) {
                     epilogue(ek & 1);
                     if (ek + 2 < n_items) decode(ek + 2, ek & 1);
                 }
-                if (fetch && grp == 1) issue(fit & 1, fl);
             }
-            if (!last) w6p_barrier();
+            if (fetch && grp == 1) issue(fit & 1, fl);
+        }
+        if (!last) w6p_barrier();
+    };
+    // phases 0 and 2 nstage - 1 of every item run the instance WITH the item-boundary code, the phases between them the one without
+    {
+        int k = 0, ph = 0;
+        while (k < n_items) {
+            if (ph == 0 || ph == nphase - 1) {
+                run_phase(k, ph, std::true_type{});
+                if (++ph == nphase) { ph = 0; ++k; }
+            } else {
+#pragma nounroll
+                for (; ph < nphase - 1; ++ph) run_phase(k, ph, std::false_type{});
+            }
         }
     }
     // group 1 finished the last item in the last phase (group 0 stored it inside the loop)

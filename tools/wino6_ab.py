@@ -43,10 +43,11 @@ def main():
         u6 = _lib.conv_pack(w, _lib.PACK_W6FWD, 0.83)
         f6 = lambda: _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, isc, osc, bias, 3)
         out = {}
-        for form in (0, 1):
+        forms = (0, 1, 2) if os.environ.get('FORM2') else (0, 1)
+        for form in forms:
             _lib.wino6_form(form)
             out[form] = f6()
-        same = torch.equal(out[0], out[1])
+        same = all(torch.equal(out[0], out[f]) for f in forms)
         bad += 0 if same else 1
         msg = f'B{B} {K}->{M} @{H}x{W}: forms bit-identical {same}'
         if not same:
@@ -58,10 +59,12 @@ def main():
             msg += f' | vs fp64 (L2): ping-pong {rel2(out[1], want):.2e}, block-phase {rel2(out[0], want):.2e}'
         flops = 2.0 * 9 * K * M * H * W * B
         t = {}
-        for form in (0, 1, 0, 1):
+        for form in forms + forms:
             _lib.wino6_form(form)
             t[form] = min(t.get(form, 1e9), timeit(f6, n=20))
         msg += f' | block-phase {t[0] * 1e3:8.1f} us {flops / t[0] / 1e9:6.1f} TF/s, ping-pong {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s'
+        if 2 in t:
+            msg += f', persistent {t[2] * 1e3:8.1f} us {flops / t[2] / 1e9:6.1f} TF/s'
         print(msg, flush=True)
     # epilogue stages (residual + mask, no activation / activation) and the data-gradient packing, small shapes, both forms
     for B, K, M, H, W in ([] if only_big else [(2, 64, 128, 16, 32), (1, 32, 64, 8, 96)]):
