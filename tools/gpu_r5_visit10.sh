@@ -1,5 +1,9 @@
-timeout 120 python tools/t2s6_check.py 2>&1 | grep -v amdgpu | grep "^B16\|^B32\|swap\|FAIL"
-echo "== side stream off"; TE_T2_SIDE_STREAM=0 timeout 120 python tools/t2s6_check.py 2>&1 | grep "^B16\|^B32\|FAIL"
-timeout 300 python -m pytest tests/test_gpu_t2s6.py tests/test_gpu_inference.py tests/test_gpu_determinism.py -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -3
-for f in 1 0 1 0; do TE_T2_SIDE_STREAM=$f timeout 300 python bench.py --gpus 1 --steps 16 --warmup 3 --no-sub --no-cpu-baseline --no-pmc 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('side=$f', round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['per_kernel']['convT2']['tflops'],1))"; done
+#!/bin/bash
+# fetch issued by the multiplying role (wino6p, s2s6, t2s6): correctness, A/B timing, phase profiles
+mkdir -p gpurun_out
+( timeout 600 python -m pytest tests/test_gpu_winograd.py tests/test_gpu_s2s6.py tests/test_gpu_t2s6.py -q --no-header -p no:cacheprovider -x ) > gpurun_out/r5v10_tests.log 2>&1
+echo "tests rc=$?"; tail -3 gpurun_out/r5v10_tests.log
+( timeout 200 python tools/wino6_ab.py; timeout 200 python tools/s2s6_check.py; timeout 200 python tools/t2s6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r5v10_checks.log
+grep -E "MISMATCH|BAD|bad|B16|B32" gpurun_out/r5v10_checks.log | cut -c1-260
+( timeout 200 python tools/s2s6_phase_prof.py st_prof; timeout 200 python tools/w6p_phase_prof.py w6p_prof ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r5v10_prof.log
+cat gpurun_out/r5v10_prof.log

@@ -27,6 +27,7 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -45,6 +46,15 @@ constexpr int N_SLOT = P_IN + 16 * P_IN;                      // arithmetic slot
 constexpr int SLOT0 = NTAP * 6 - N_SLOT;                      // the program starts behind MFMA 3
 constexpr int UA_TAPS = 5;                                    // taps 0-4: weight half a (30 slots), taps 5-8: half b (24 slots)
 
+#ifdef S2_PROF       // experimental builds: per-wave cycle counts of the phases, read back with te_debug_s2s6_prof (tools/s2s6_phase_prof.py)
+__device__ unsigned long long te_s2s6_prof_buf[2048 * 8 * 8];
+#define S2_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define S2_ACC(i, a, b) pc[i] += (b) - (a)
+#else
+#define S2_T(v)
+#define S2_ACC(i, a, b)
+#endif
+
 struct S2Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; const float* res;
     const float* mref; float mgain; int act;
@@ -54,6 +64,9 @@ struct S2Args {
 __device__ __forceinline__ void s2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void s2_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ISC: the launch carries style scales (a template parameter: `if (p.isc)` around the scale loads was one of the conditional updates of
+// the fetch registers that made the compiler keep two copies of them - see fetch_item and profiles/experiments/r05_s2s6_phase_profile.log)
+template <bool ISC>
 __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
     const int x0 = tx * TWO, y0 = ty * TH, yh = y0 + PH * grp;
     const size_t iplane = (size_t)p.Hi * p.Wi, oplane = (size_t)p.H * p.W;
     const float* inb = p.in + (size_t)b * p.K * iplane;
-    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
 
     // two accumulators: `acc` takes the h x h products (the bulk of every multiply-add), `accl` the five small ones (together 2^-8
     // of it).  All 54 MFMAs of a stage into one register would round the running sum 54 times per stage where the fp32 kernel rounds
@@ -105,20 +118,27 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
     }
     const int MT = p.M >> 5;
     f32x4 rin[P_IN][2];
-    float rsc[P_IN][2];
+    f32x2 rsc[P_IN];               // style scales of the item's channel pair
 #pragma unroll
-    for (int i = 0; i < P_IN; ++i) { rsc[i][0] = 1.f; rsc[i][1] = 1.f; }
+    for (int i = 0; i < P_IN; ++i) rsc[i] = f32x2{1.f, 1.f};
     const int nstage = p.K / KC;
-    auto issue = [&](int s) {
+    // fetch of stage s, item by item.  Inside the loop it is issued by the MULTIPLYING role, each item right behind the last slot of the
+    // arithmetic that reads its registers, so that the fetch registers are written and read in one role only (wino6.hip, fetch_item)
+    auto fetch_scales = [&](int s) {
+        if (ISC) {
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const float* base = inb + ((size_t)s * KC + h2) * iplane;
-#pragma unroll
-            for (int i = 0; i < P_IN; ++i) {
-                if (iscb) rsc[i][h2] = (iscb + s * KC + h2)[q2[i]];
-                rin[i][h2] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
-            }
+            for (int i = 0; i < P_IN; ++i) rsc[i] = *reinterpret_cast<const f32x2u*>(iscb + s * KC + q2[i]);
         }
+    };
+    auto fetch_item = [&](int i, int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+            rin[i][h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * iplane + g_off[i]);
+    };
+    auto issue = [&](int s) {
+        fetch_scales(s);
+#pragma unroll
+        for (int i = 0; i < P_IN; ++i) fetch_item(i, s);
     };
     // weight half `uh` of stage s: uh = 0: taps 0-4 (30 slots: 8 / 8 / 7 / 7 per wave), uh = 1: taps 5-8 (24 slots: 6 per wave)
     auto issue_u = [&](int uh, int s) {
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
             for (int h2 = 0; h2 < 2; ++h2) {
                 f32x4 v = rin[k][h2];
                 if (last_col[k]) v[0] = v[3];                 // (loaded three columns early; positions 1..3 are never written)
-                rin[k][h2] = v * rsc[k][h2];
+                rin[k][h2] = ISC ? v * rsc[k][h2] : v;
                 asm volatile("" : "+v"(rin[k][h2]));
             }
         } else if (k < N_SLOT) {
@@ -201,17 +221,23 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 12 loads, 6 without style scales - stays in flight)
-        if (iscb) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 9 loads, 6 without style scales - stays in flight)
+        if (ISC) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
     s2_barrier();
     const int nphase = 2 * nstage;
+#ifdef S2_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ph = 0; ph < nphase; ++ph) {
         const bool last = ph == nphase - 1;
+        S2_T(t0);
         if ((ph & 1) == grp) {
             // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of the stage after (rin -> res)
             bf16x8 av[2][3], bv[2][3];
+            const int fs2 = min((ph >> 1) + 2, nstage - 1);
             auto rd1 = [&](int t, int slot, int q) {
                 const int ky = t / 3, kx = t % 3;
                 if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + (q * NTAP + t) * 128]);
@@ -224,43 +250,77 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 const int slot = t & 1;
+#ifdef S2_PROF
+                if (t == UA_TAPS - 1) { S2_T(ta); s2_barrier(); S2_T(tb); S2_ACC(0, t0, ta); S2_ACC(1, ta, tb); pc[2] -= tb; }
+#else
                 if (t == UA_TAPS - 1) s2_barrier();    // mid-phase barrier: in front of tap 4's MFMAs (operands read) and of the first read of half b
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
+#ifndef ST_SKIP_MFMA     // (experiment switches ST_*: timing decomposition only, results are wrong)
                     if (q < 5) accl = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], accl, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc, 0, 0, 0);
+#endif
                     if (t + 1 < NTAP && q < 3) { rd1(t + 1, slot ^ 1, 2 * q); rd1(t + 1, slot ^ 1, 2 * q + 1); }
+#ifndef ST_NO_ARITH
                     arith(t * 6 + q - SLOT0);
+#endif
+#ifndef ST_NO_FETCH
+                    {   // the fetch of the stage after next: an item's loads right behind the last slot that reads its registers
+                        const int k = t * 6 + q - SLOT0;
+                        if (k == P_IN - 1) fetch_scales(fs2);
+#pragma unroll
+                        for (int i = 0; i < P_IN; ++i)
+                            if (k == P_IN + 16 * i + 12) fetch_item(i, fs2);
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+#ifdef S2_PROF
+            { asm volatile("s_nop 0" ::: "memory"); S2_T(tc); pc[2] += tc; }
+#endif
         } else {
             // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
             const int cs = (ph + 1) >> 1;
             const bool work = cs >= 1 && cs < nstage;
-            const bool fetch = cs >= 1 && cs + 1 < nstage;
-            if (work) {
-                // group 1: DMA of weight half b first, then the fetch of the next stage, and a COUNTED wait that covers the DMA only
-                // (the 6 + 6 loads - 6 without style scales - behind it stay in flight: loads return in issue order); the arithmetic
-                // that consumes the fetch starts at MFMA 3 of the next phase, so it needs the whole staging phase to land
-                if (grp == 1) issue_u(1, cs);
-                __builtin_amdgcn_sched_barrier(0);
-                if (fetch) issue(cs + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                write_res();
-                if (grp == 1) {
-                    if (!fetch) s2_wait_vm();
-                    else if (iscb) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                }
-            }
+            // group 1 renews weight half b in front of the mid-phase barrier (the partner reads it right behind): DMA first, the LDS
+            // writes of this half tile in its shadow, then the wait for the DMA; group 0 renews half a behind the barrier.  The LDS
+            // writes are unconditional: in group 1's first phase they repeat what the prologue wrote, in group 0's last phase they
+            // put stale results in a tile nobody reads any more.
+#ifndef ST_NO_DMA
+            if (work && grp == 1) issue_u(1, cs);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef ST_NO_DSW
+            write_res();
+#endif
+            if (work && grp == 1) s2_wait_vm();
+            S2_T(ta);
             s2_barrier();
+            S2_T(tb);
+#ifndef ST_NO_DMA
             if (work && grp == 0) { issue_u(0, cs); s2_wait_vm(); }
+#endif
+            S2_T(tc);
+            S2_ACC(3, t0, ta); S2_ACC(4, ta, tb); S2_ACC(5, tb, tc);
         }
+        S2_T(t8);
         if (!last) s2_barrier();
+        S2_T(t9);
+        S2_ACC(6, t8, t9);
     }
+#ifdef S2_PROF
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* d = te_s2s6_prof_buf + ((size_t)blockIdx.x * 8 + wid) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = pc[i];
+        d[6] = pc[6] | ((__builtin_amdgcn_s_memrealtime() - rstart) << 40);
+        d[7] = ((unsigned long long)nstage << 48) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFFFull);
+    }
+#endif
     // epilogue: the direct kernel's stages (demodulation scale, bias, leaky ReLU, residual, mask)
     const int mbase = mb * BM + wm * 32;
     const size_t off0 = ((size_t)b * p.M + mbase) * oplane + (size_t)(yh + 2 * wrl + rr) * p.W + x0 + jj;
@@ -295,6 +355,12 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
 
 }  // namespace
 
+#ifdef S2_PROF
+extern "C" int te_debug_s2s6_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_s2s6_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int te_conv_s2s6_supported(int B, int K, int M, int H, int W) {
     if (!(B > 0 && K >= 32 && K % KC == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TWO && W % TWO == 0)) return 0;
     return ((int64_t)K * (2 * H + 1) * (2 * W + 1) * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TWO) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
@@ -315,8 +381,13 @@ int te_s2s6_launch(float* out, const float* in, const float* U, const float* isc
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
     const size_t lds = (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
-    static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)s2s6_kernel, 160 * 1024);
-    s2s6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    static std::atomic<uint64_t> attr_done{0}, attr_done_sc{0};
+    if (isc) {
+        te::allow_big_lds(attr_done_sc, (const void*)s2s6_kernel<true>, 160 * 1024);
+        s2s6_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    } else {
+        te::allow_big_lds(attr_done, (const void*)s2s6_kernel<false>, 160 * 1024);
+        s2s6_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    }
     return te::launch_status("te_conv_f32(TE_CONV_S2S6)");
 }

@@ -41,6 +41,15 @@ constexpr int N_SLOT = 1 + 16;                                // arithmetic slot
 constexpr int SLOT0 = 24;                                     // MFMA behind which the program starts (54 per phase)
 constexpr int UA_TAPS = 5;                                    // taps 0-4: weight half a (30 slots), taps 5-8: half b (24 slots)
 
+#ifdef T2_PROF       // experimental builds: per-wave cycle counts of the phases, read back with te_debug_t2s6_prof (tools/s2s6_phase_prof.py)
+__device__ unsigned long long te_t2s6_prof_buf[2048 * 8 * 8];
+#define T2_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define T2_ACC(i, a, b) pc[i] += (b) - (a)
+#else
+#define T2_T(v)
+#define T2_ACC(i, a, b)
+#endif
+
 struct T2Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; int act;
     int B, K, M, H, W, Ho, Wo, ntiles, mblocks, tiles_x, tiles_y, nt8;
@@ -49,6 +58,8 @@ struct T2Args {
 __device__ __forceinline__ void t2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ISC: the launch carries style scales (template parameter; see s2s6.hip)
+template <bool ISC>
 __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     const int x0 = tx * TWC, y0 = ty * TH, yh = y0 + PH * grp;
     const size_t iplane = (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;
     const float* inb = p.in + (size_t)b * p.K * iplane;
-    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
 
     f32x16 acc[4];                                     // one tile per output phase (a, b) = (ky & 1, kx & 1)
 #pragma unroll
@@ -89,16 +100,18 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     const unsigned q2 = 2u * q;
     const int MT = p.M >> 5;
     f32x4 rin[2];
-    float rsc[2] = {1.f, 1.f};
+    f32x2 rsc = {1.f, 1.f};
     const int nstage = p.K / KC;
-    auto issue = [&](int s) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const float* base = inb + ((size_t)s * KC + h2) * iplane;
-            if (iscb) rsc[h2] = (iscb + s * KC + h2)[q2];
-            rin[h2] = *reinterpret_cast<const f32x4u*>(base + g_off);
-        }
+    // fetch of stage s.  Inside the loop it is issued by the MULTIPLYING role, right behind the last slot of the arithmetic that reads
+    // the registers, so that the fetch registers are written and read in one role only (wino6.hip, fetch_item)
+    auto fetch_scales = [&](int s) {
+        if (ISC) rsc = *reinterpret_cast<const f32x2u*>(iscb + s * KC + q2);
     };
+    auto fetch_item = [&](int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) rin[h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * iplane + g_off);
+    };
+    auto issue = [&](int s) { fetch_scales(s); fetch_item(s); };
     // weight half `uh` of stage s: uh = 0: taps 0-4 (30 slots: 8 / 8 / 7 / 7 per wave), uh = 1: taps 5-8 (24 slots: 6 per wave)
     auto issue_u = [&](int uh, int s) {
         const u32x4* us = p.U + (size_t)s * 27 * MT * 64;
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
                 if (left) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }        // loaded from column 0: position 0 is column -1
                 if (last_col) v[0] = v[3];                                               // loaded three columns early
                 if (rowout) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-                rin[h2] = v * rsc[h2];
+                rin[h2] = ISC ? v * rsc[h2] : v;
                 asm volatile("" : "+v"(rin[h2]));
             }
         } else if (k < N_SLOT) {
@@ -179,17 +192,23 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 4 loads, 2 without style scales - stays in flight)
-        if (iscb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 3 loads, 2 without style scales - stays in flight)
+        if (ISC) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
     t2_barrier();
     const int nphase = 2 * nstage;
+#ifdef T2_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pstart = __builtin_readcyclecounter(), rstart = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ph = 0; ph < nphase; ++ph) {
         const bool last = ph == nphase - 1;
+        T2_T(t0);
         if ((ph & 1) == grp) {
             // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of the stage after (rin -> res)
             bf16x8 av[2][3], bv[2][3];
+            const int fs2 = min((ph >> 1) + 2, nstage - 1);
             auto rd1 = [&](int t, int slot, int qq) {
                 const int ky = t / 3, kx = t % 3;
                 if (qq < 3) av[slot][qq] = __builtin_bit_cast(bf16x8, ul[a_chunk + (qq * NTAP + t) * 128]);
@@ -202,40 +221,69 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 const int slot = t & 1, c = ((t / 3) & 1) * 2 + ((t % 3) & 1);          // output phase of the tap
+#ifdef T2_PROF
+                if (t == UA_TAPS - 1) { T2_T(ta); t2_barrier(); T2_T(tb); T2_ACC(0, t0, ta); T2_ACC(1, ta, tb); pc[2] -= tb; }
+#else
                 if (t == UA_TAPS - 1) t2_barrier();    // mid-phase barrier: in front of tap 4's MFMAs (operands read) and of the first read of half b
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int qq = 0; qq < 6; ++qq) {
+#ifndef ST_SKIP_MFMA     // (experiment switches ST_*: timing decomposition only, results are wrong)
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[qq]], bv[slot][PB[qq]], acc[c], 0, 0, 0);
+#endif
                     if (t + 1 < NTAP && qq < 3) { rd1(t + 1, slot ^ 1, 2 * qq); rd1(t + 1, slot ^ 1, 2 * qq + 1); }
+#ifndef ST_NO_ARITH
                     arith(t * 6 + qq - SLOT0);
+#endif
+#ifndef ST_NO_FETCH
+                    if (t * 6 + qq - SLOT0 == 0) fetch_scales(fs2);          // the fetch of the stage after next (see fetch_item)
+                    if (t * 6 + qq - SLOT0 == 13) fetch_item(fs2);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+#ifdef T2_PROF
+            { asm volatile("s_nop 0" ::: "memory"); T2_T(tc); pc[2] += tc; }
+#endif
         } else {
             // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
             const int cs = (ph + 1) >> 1;
             const bool work = cs >= 1 && cs < nstage;
-            const bool fetch = cs >= 1 && cs + 1 < nstage;
-            if (work) {
-                // group 1: DMA of weight half b first, then the fetch, and a COUNTED wait that covers the DMA only (s2s6.hip)
-                if (grp == 1) issue_u(1, cs);
-                __builtin_amdgcn_sched_barrier(0);
-                if (fetch) issue(cs + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                write_res();
-                if (grp == 1) {
-                    if (!fetch) t2_wait_vm();
-                    else if (iscb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                }
-            }
+            // group 1 renews weight half b in front of the mid-phase barrier: DMA first, the LDS writes of this half tile in its shadow,
+            // then the wait for the DMA; group 0 renews half a behind the barrier.  The LDS writes are unconditional (s2s6.hip).
+#ifndef ST_NO_DMA
+            if (work && grp == 1) issue_u(1, cs);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef ST_NO_DSW
+            write_res();
+#endif
+            if (work && grp == 1) t2_wait_vm();
+            T2_T(ta);
             t2_barrier();
+            T2_T(tb);
+#ifndef ST_NO_DMA
             if (work && grp == 0) { issue_u(0, cs); t2_wait_vm(); }
+#endif
+            T2_T(tc);
+            T2_ACC(3, t0, ta); T2_ACC(4, ta, tb); T2_ACC(5, tb, tc);
         }
+        T2_T(t8);
         if (!last) t2_barrier();
+        T2_T(t9);
+        T2_ACC(6, t8, t9);
     }
+#ifdef T2_PROF
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* d = te_t2s6_prof_buf + ((size_t)blockIdx.x * 8 + wid) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = pc[i];
+        d[6] = pc[6] | ((__builtin_amdgcn_s_memrealtime() - rstart) << 40);
+        d[7] = ((unsigned long long)nstage << 48) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFFFull);
+    }
+#endif
     // epilogue: demodulation scale, bias, leaky ReLU; phases (a, 0) and (a, 1) of a cell are adjacent output columns: one 8-byte store
     const int mbase = mb * BM + wm * 32;
     const int ci = yh + 2 * wrl + rr, cj = x0 + jj;
@@ -266,6 +314,12 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 
 }  // namespace
 
+#ifdef T2_PROF
+extern "C" int te_debug_t2s6_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_t2s6_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int te_conv_t2s6_supported(int B, int K, int M, int H, int W) {
     if (!(B > 0 && K >= 32 && K % KC == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TWC && W % TWC == 0)) return 0;
     return ((int64_t)M * (2 * H + 1) * (2 * W + 1) * 4 < 0x7FFFFFFF && (int64_t)K * H * W * 4 < 0x7FFFFFFF &&
@@ -289,7 +343,13 @@ int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
     const size_t lds = (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)t2s6_kernel, 160 * 1024);
-    t2s6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    if (isc) {
+        static std::atomic<uint64_t> attr_done_sc{0};
+        te::allow_big_lds(attr_done_sc, (const void*)t2s6_kernel<true>, 160 * 1024);
+        t2s6_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    } else {
+        te::allow_big_lds(attr_done, (const void*)t2s6_kernel<false>, 160 * 1024);
+        t2s6_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+    }
     return te::launch_status("te_conv_f32(TE_CONV_T2S6)");
 }

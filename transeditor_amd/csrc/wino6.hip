@@ -32,6 +32,7 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -333,6 +334,11 @@ __device__ unsigned long long te_w6p_prof_buf[2048 * 8 * 8];
 __device__ __forceinline__ void w6p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void w6p_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ISC: the launch carries style scales.  A template parameter, and the fetch of the staging role is unconditional (clamped to the last
+// stage): with `if (iscb)` / `if (fetch)` around the loads the compiler kept two copies of the 26 fetch registers and moved them twice per
+// staging phase - ~40 vector-ALU instructions in the wave whose instructions cost 10 - 27 cycles each (found in s2s6.hip's phase
+// profile, profiles/experiments/r05_s2s6_phase_profile.log; the ISA of the staging role now has no register move at all).
+template <bool ISC>
 __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
     const int x0 = tx * TW, y0 = ty * TH, yh = y0 + PH * grp;
     const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
-    const float* iscb = p.isc ? p.isc + (size_t)b * p.K : nullptr;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
     const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
 
     f32x16 acc[4];
@@ -375,17 +381,26 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const size_t plane = (size_t)p.H * p.W;
     const int MT = p.M >> 5;
     f32x4 rin[P_IN][2];
-    float rsc[2] = {1.f, 1.f};     // style scales of this thread's channel pair (the same pair for its three items: 256 % 128 == 0)
+    f32x2 rsc = {1.f, 1.f};        // style scales of this thread's channel pair (the same pair for its three items: 256 % 128 == 0)
     const int nstage = p.K / KC;
-    // (uniform base pointer + unsigned 32-bit per-thread offset: the scalar-base addressing form, no 64-bit address registers)
+    // fetch of stage s, item by item (uniform base pointer + unsigned 32-bit per-thread offset: the scalar-base addressing form, no
+    // 64-bit address registers).  Inside the loop the fetch is issued by the MULTIPLYING role, each item right behind the last slot of
+    // the arithmetic that reads its registers: the fetch registers are then written and read in one role only.  Issued by the staging
+    // role - as the first ping-pong versions did - they came out of the register allocator as two sets with 12 - 18 64-bit moves per
+    // staging phase between them (and with them conditional on `fetch`, twice that), in the wave whose vector-ALU instructions cost
+    // 10 - 27 cycles each; found in s2s6.hip's phase profile, profiles/experiments/r05_s2s6_phase_profile.log.
+    auto fetch_scales = [&](int s) {
+        if (ISC) rsc = *reinterpret_cast<const f32x2u*>(iscb + s * KC + q2);
+    };
+    auto fetch_item = [&](int i, int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+            rin[i][h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * plane + g_off[i]);
+    };
     auto issue = [&](int s) {
+        fetch_scales(s);
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const float* base = inb + ((size_t)s * KC + h2) * plane;
-            if (iscb) rsc[h2] = (iscb + s * KC + h2)[q2];          // (uniform branch around the load: no select, no wait at the join)
-#pragma unroll
-            for (int i = 0; i < P_IN; ++i) rin[i][h2] = *reinterpret_cast<const f32x4u*>(base + g_off[i]);
-        }
+        for (int i = 0; i < P_IN; ++i) fetch_item(i, s);
     };
     // weight half `uh` of stage s: 36 fragment slots (3 pieces x 6 (tap row, component) groups x 2 M tiles), 9 per wave of the group
     auto issue_u = [&](int uh, int s) {
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
                     if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }        // loaded one column early: element 3 is column W
                     if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                 }
-                rin[k][h2] = v * rsc[h2];
+                rin[k][h2] = ISC ? v * rsc[h2] : v;
                 asm volatile("" : "+v"(rin[k][h2]));
             }
         } else if (k < N_SLOT) {
@@ -478,10 +493,10 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     for (int k = 0; k < N_SLOT; ++k) arith(k);
     write_res();
     issue(1);
-    // (only the weight DMA has to have landed at the barrier: a COUNTED wait in group 0 leaves the fetch of stage 1 - 8 loads, 6 without
+    // (only the weight DMA has to have landed at the barrier: a COUNTED wait in group 0 leaves the fetch of stage 1 - 7 loads, 6 without
     //  style scales - in flight; waiting for it too cost every block one HBM latency, ~2 of the ~8 us a block spends outside its stages)
     if (grp == 0) {
-        if (iscb) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (ISC) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
     w6p_barrier();
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
             // (in a group's last multiplying phase the arithmetic runs on the stale registers of the last fetch and its results are never
             //  written: ONE copy of the MFMA stream instead of two with their own register allocation and 64 moves between them)
             bf16x8 av[2][3], bv[2][3];
+            const int fs2 = min((ph >> 1) + 2, nstage - 1);
             auto rd1 = [&](int g, int slot, int q) {
                 const int ky = g >> 2, c = g & 3;
                 if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((q * 3 + ky) * 4 + c) * 128]);
@@ -526,6 +542,14 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
 #ifndef W6_SKIP_COMMIT
                     arith(g * 6 + q - W6P_SLOT0);
 #endif
+                    {   // the fetch of the stage after next, item by item behind the last slot that reads the item's registers
+                        constexpr int LASTQ = 71 - W6P_SLOT0;                      // slot of the last MFMA
+                        const int k = g * 6 + q - W6P_SLOT0;
+                        if (k == P_IN - 1) fetch_scales(fs2);
+#pragma unroll
+                        for (int i = 0; i < P_IN; ++i)
+                            if (k == (P_IN + 16 * i + 12 < LASTQ ? P_IN + 16 * i + 12 : LASTQ)) fetch_item(i, fs2);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -537,26 +561,20 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
             // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
             const int cs = (ph + 1) >> 1;
             const bool work = cs >= 1 && cs < nstage;
-            const bool fetch = cs >= 1 && cs + 1 < nstage;
-            if (work) {
-                // group 1 renews Ub in front of the mid-phase barrier (the partner reads it right behind): DMA first, the LDS writes
-                // of this half tile in its shadow, then the wait for the DMA; its fetch of the next stage goes BEHIND the barrier, where
-                // this group has nothing else to do (waiting for those loads too - their HBM latency - in front of the barrier cost the
-                // multiplying partner ~1 000 cycles per stage: profiles/experiments/r05_w6p_phase_profile.log).  Group 0 fetches first
-                // (its DMA comes behind the barrier).
-                if (grp == 1) issue_u(1, cs);
-                else if (fetch) issue(cs + 1);
-                __builtin_amdgcn_sched_barrier(0);
+            // group 1 renews Ub in front of the mid-phase barrier (the partner reads it right behind): DMA first, the LDS writes of
+            // this half tile in its shadow, then the wait for the DMA; group 0 renews Ua behind the barrier.  (The fetch of the next
+            // stage is not issued here any more: see fetch_item.)  The LDS writes are unconditional: in group 1's first phase they
+            // repeat what the prologue wrote, in group 0's last phase they put stale results in a tile nobody reads any more.
+            if (grp == 1 && work) issue_u(1, cs);
+            __builtin_amdgcn_sched_barrier(0);
 #ifndef W6_SKIP_COMMIT
-                write_res();
+            write_res();
 #endif
-                if (grp == 1) w6p_wait_vm();
-            }
+            if (grp == 1 && work) w6p_wait_vm();
             W6P_T(ta);
             w6p_barrier();
             W6P_T(tb);
-            if (work && grp == 0) { issue_u(0, cs); w6p_wait_vm(); }
-            if (fetch && grp == 1) issue(cs + 1);
+            if (grp == 0 && work) { issue_u(0, cs); w6p_wait_vm(); }
             W6P_T(tc);
             W6P_ACC(3, t0, ta); W6P_ACC(4, ta, tb); W6P_ACC(5, tb, tc);
         }
@@ -659,9 +677,14 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
     if (g_w6_form.load(std::memory_order_relaxed) == 1) {
         const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
-        static std::atomic<uint64_t> attr_done_p{0};
-        te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel, 160 * 1024);
-        wino6p_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+        static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0};
+        if (isc) {
+            te::allow_big_lds(attr_done_ps, (const void*)wino6p_kernel<true>, 160 * 1024);
+            wino6p_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+        } else {
+            te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel<false>, 160 * 1024);
+            wino6p_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+        }
     } else {
         const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;
         static std::atomic<uint64_t> attr_done{0};
