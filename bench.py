@@ -68,7 +68,10 @@ def _arithmetic_switches():
     """what `dtype: "f32"` stands on in this run: fp32 tensors and accumulation everywhere; which launches form their products on the
     bf16 pipe (three-piece split, fp32-equivalent) and in which kernel form"""
     from transeditor_amd.op import modconv
+    from transeditor_amd import _lib
     return {'split_bf16': bool(modconv.USE_WINOGRAD and modconv.USE_SPLIT_BF16),
+            'split_bf16_strided': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_S2), 'split_bf16_transposed': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_T2),
+            'split_bf16_weight_gradient_3x3': bool(_lib.wgrad_split()),
             'split_bf16_kernel_form': {1: 'ping-pong (wino6p_kernel)', 0: 'block-phase (wino6_kernel)'}.get(_w6_form(), None)}
 
 
@@ -144,9 +147,13 @@ class KernelTimer:
             s.record()
             out = orig_wgrad(g, x, kind, H, W, *a, **k)
             e.record()
-            # (the pair form of the 3x3 weight gradient: 12/18 of the direct form's multiply-adds, as above)
-            timer.records.append(('wgrad_' + names[kind], flops, s, e,
-                                  flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0), 0.0))
+            # (the pair form of the 3x3 weight gradient: 12/18 of the direct form's multiply-adds, as above; csrc/wgrad6.hip runs the
+            #  pair form as six bf16 piece products per multiply-add: 4x the algorithmic FLOPs on the bf16 pipe, none on the fp32 one)
+            split = bool(_lib.wgrad_split() and _lib.wgrad_split_ok(kind, g.shape[1], x.shape[1], H, W))
+            ex32 = 0.0 if split else flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0)
+            timer.records.append(('wgrad_' + names[kind], flops, s, e, ex32, 4.0 * flops if split else 0.0))
+            if split:
+                timer.records.append(('wgrad_conv3x3_split_bf16', flops, s, e, ex32, 4.0 * flops))
             return out
 
         _lib.conv, _lib.wgrad_slabs = conv, wgrad

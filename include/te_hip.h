@@ -241,6 +241,14 @@ int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W);
  * a kernel row from four products per pair - 1-D Winograd F(3,2) - i.e. 2/3 of the direct form's multiply-adds on the matrix
  * pipe for the same slabs), else 0.  Only a report for FLOP accounting (bench.py): results and slab layout do not depend on it. */
 int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W);
+/* Round 5: the 3x3 correlation on the bf16 matrix pipe (csrc/wgrad6.hip: pair form, every fp32 operand split into three bf16 pieces,
+ * six exact piece products per multiply-add, fp32 accumulation - fp32-equivalent slabs, same layout, same reducers).
+ * te_wgrad_split_supported: 1 where it applies (kind TE_CONV_3X3, Co % 64 == 0, Ci % 64 == 0, W % 32 == 0).
+ * te_wgrad_split_bf16(0 | 1): process-wide switch (environment TE_SPLIT_WGRAD at load time), returns the previous value; any other
+ * argument only queries.  With the switch on, te_wgrad_f32 / te_wgrad_group_f32 take the kernel where it applies and the fp32
+ * kernel elsewhere. */
+int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W);
+int te_wgrad_split_bf16(int on);
 int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H,
                  int W, int S, te_stream_t stream);
 /* GROUPED form for the PLAIN (unmodulated) weight gradient of small images: NB consecutive samples share one slab

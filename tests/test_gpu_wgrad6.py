@@ -1,0 +1,121 @@
+"""The weight-gradient correlation of the 3x3 convolutions on the bf16 matrix pipe (csrc/wgrad6.hip: pair form F(3,2), three bf16 pieces per
+fp32 operand, six exact piece products per multiply-add, fp32 accumulation) against fp64 torch and against the fp32 kernel (same slabs,
+wgrad.hip) - reference: autograd of F.conv2d(groups = B) in ModulatedConv2d.forward, model_spatial_query.py:318-333.  Shapes: one and
+several 32-column tiles, chunk boundaries inside a column (S > 1), image borders on all sides, several channel blocks, the grouped form
+(samples share a slab), the three gradients of the reducer on top of the slabs, the range sweep, the selection rule and the switch.
+Pinned at the bar of the fp32 kernels: 5e-6 against fp64."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from transeditor_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+SHAPES = [(2, 64, 64, 8, 32), (3, 128, 64, 13, 64), (1, 64, 192, 40, 96), (4, 64, 64, 5, 32), (2, 128, 128, 32, 32), (1, 64, 64, 1, 32),
+          (2, 64, 128, 2, 64), (1, 192, 64, 3, 32)]
+
+
+@pytest.fixture(autouse=True)
+def _restore_switch():
+    old = _lib.wgrad_split()
+    yield
+    _lib.wgrad_split(old)
+
+
+def _fp64_corr(g, x):
+    B, Co, Ci = g.shape[0], g.shape[1], x.shape[1]
+    return torch.stack([torch.nn.grad.conv2d_weight(x[b:b + 1].double(), (Co, Ci, 3, 3), g[b:b + 1].double(), padding=1)
+                        for b in range(B)]).reshape(B, Co, Ci, 9)
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', SHAPES)
+def test_split_bf16_weight_gradient_slabs_vs_fp64(B, Co, Ci, H, W):
+    assert _lib.wgrad_split_ok(_lib.CONV_3X3, Co, Ci, H, W)
+    g = synth.normal((B, Co, H, W), f'wg6.g.{Co}.{H}').to(DEV)
+    x = synth.normal((B, Ci, H, W), f'wg6.x.{Ci}.{H}').to(DEV)
+    want = _fp64_corr(g, x)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
+    assert got.shape == ref.shape                       # same slab count, same layout: the reducers do not know which kernel ran
+    got, ref = got.sum(1), ref.sum(1)
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    print(f'split-bf16 weight gradient {Ci}->{Co} @{H}x{W} B{B}: max {rel_err(got, want):.2e} (fp32 kernel {rel_err(ref, want):.2e}), '
+          f'L2 {l2(got):.2e} ({l2(ref):.2e})')
+    assert rel_err(got, want) < 5e-6
+    assert l2(got) < 2.5 * l2(ref) + 1e-7               # fp32-equivalent: the yardstick of the other split kernels
+
+
+def test_split_bf16_weight_gradient_long_reduction_vs_fp32_kernel():
+    """a chunk of several thousand steps per accumulator (the 128-channel layer of FFHQ-256 at batch 2): against the fp32 kernel"""
+    B, Co, Ci, H, W = 2, 128, 128, 256, 256
+    g = synth.normal((B, Co, H, W), 'wg6.lg').to(DEV)
+    x = synth.normal((B, Ci, H, W), 'wg6.lx').to(DEV)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W).sum(1)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W).sum(1)
+    want = _fp64_corr(g[:1, :64], x[:1, :64])           # fp64 for one 64 x 64 channel block of sample 0
+    e_split, e_ref = rel_err(got[:1, :64, :64], want), rel_err(ref[:1, :64, :64], want)
+    print(f'long reduction: split vs fp32 kernel {rel_err(got, ref):.2e}; vs fp64 (one block): split {e_split:.2e}, fp32 kernel {e_ref:.2e}')
+    assert rel_err(got, ref) < 5e-6
+    assert e_split < 5e-6 and e_split < 2.5 * e_ref + 1e-7
+
+
+def test_split_bf16_weight_gradient_grouped_and_reduced():
+    """the grouped form (NB samples per slab, the discriminator's plain gradient) and the reducer's three gradients on the split slabs"""
+    B, Co, Ci, H, W = 8, 128, 128, 32, 32
+    g = synth.normal((B, Co, H, W), 'wg6.gg').to(DEV)
+    x = synth.normal((B, Ci, H, W), 'wg6.gx').to(DEV)
+    w = (synth.normal((Co, Ci, 3, 3), 'wg6.w') / (3 * math.sqrt(Ci))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, Ci), 'wg6.i')).to(DEV), (1 + 0.3 * synth.normal((B, Co), 'wg6.o')).to(DEV)
+    out = {}
+    for on in (0, 1):
+        _lib.wgrad_split(on)
+        grouped = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W, group=True)
+        slabs = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
+        out[on] = (grouped.sum((0, 1)),) + tuple(_lib.wgrad_reduce(slabs, w, 0.7, isc, osc, True, True, True))
+    want_plain = _fp64_corr(g, x).sum(0)
+    assert rel_err(out[1][0].reshape(Co, Ci, 9), want_plain) < 5e-6
+    for a, b, name in zip(out[1][1:], out[0][1:], ('dW', 'd isc', 'd osc')):
+        print(f'reducer on split slabs, {name}: vs fp32 slabs {rel_err(a, b):.2e}')
+        assert rel_err(a, b) < 5e-6
+
+
+@pytest.mark.parametrize('scale', [1e-30, 1e-12, 1.0, 1e12, 1e18])
+def test_split_bf16_weight_gradient_range(scale):
+    """operands from 1e-30 to 1e18: the split keeps 24 mantissa bits wherever the pieces stay normal bf16 numbers (they share fp32's
+    exponent range), and products that overflow fp32 overflow in both kernels"""
+    B, Co, Ci, H, W = 1, 64, 64, 8, 32
+    g = (synth.normal((B, Co, H, W), 'wg6.rg') * scale).to(DEV)
+    x = synth.normal((B, Ci, H, W), 'wg6.rx').to(DEV)
+    want = _fp64_corr(g, x)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W).sum(1)
+    assert torch.isfinite(got).all()
+    tol = 5e-6 if scale >= 1e-12 else 2e-2               # (1e-30: the low pieces are bf16 subnormals / flushed, as in the forward kernels)
+    assert rel_err(got, want) < tol
+
+
+def test_split_bf16_weight_gradient_selection_and_switch():
+    ok = _lib.wgrad_split_ok
+    assert ok(_lib.CONV_3X3, 128, 128, 256, 256) and ok(_lib.CONV_3X3, 512, 64, 4, 32)
+    assert not ok(_lib.CONV_3X3, 96, 128, 32, 32) and not ok(_lib.CONV_3X3, 128, 32, 32, 32)      # whole 64-channel blocks only
+    assert not ok(_lib.CONV_3X3, 128, 128, 16, 16) and not ok(_lib.CONV_3X3, 128, 128, 32, 48)    # whole 32-column tiles only
+    assert not ok(_lib.CONV_T2, 128, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
+    old = _lib.wgrad_split(0)
+    assert _lib.wgrad_split() == 0 and _lib.wgrad_split(1) == 0 and _lib.wgrad_split() == 1
+    _lib.wgrad_split(old)
+    # a shape the kernel does not cover runs the fp32 kernel whatever the switch says: identical slabs
+    g = synth.normal((2, 96, 16, 16), 'wg6.sg').to(DEV)
+    x = synth.normal((2, 64, 16, 16), 'wg6.sx').to(DEV)
+    _lib.wgrad_split(1)
+    a = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, 16, 16)
+    _lib.wgrad_split(0)
+    b = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, 16, 16)
+    assert torch.equal(a, b)

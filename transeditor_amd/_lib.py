@@ -48,6 +48,8 @@ _SIGNATURES = {
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
     'te_wgrad_pair_form': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_wgrad_split_supported': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_wgrad_split_bf16': (C.c_int, [_I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_group_plan': (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P]),
     'te_wgrad_group_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -407,6 +409,16 @@ def wgrad_slabs(g, x, kind, H, W, group=False):
     slabs = torch.empty(B, S, Co, Ci, taps, device=g.device, dtype=g.dtype)
     _check(lib().te_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), kind, B, Co, Ci, H, W, S, _stream()), 'te_wgrad_f32')
     return slabs
+
+
+def wgrad_split(on=-1):
+    """switch of the split-bf16 weight-gradient kernel (csrc/wgrad6.hip): 0 / 1 sets it, returns the previous value (-1: query only)"""
+    return int(lib().te_wgrad_split_bf16(on))
+
+
+def wgrad_split_ok(kind, Co, Ci, H, W):
+    """does the split-bf16 weight-gradient kernel cover this problem?  (taken only while wgrad_split() is on)"""
+    return bool(lib().te_wgrad_split_supported(kind, Co, Ci, H, W))
 
 
 def wgrad_pair_form(kind, Co, Ci, H, W):

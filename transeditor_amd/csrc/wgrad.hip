@@ -943,12 +943,16 @@ extern "C" int te_wgrad_f32(float* slabs, const float* g, const float* x, int ki
     return wgrad_launch(slabs, g, x, kind, B, Co, Ci, H, W, S, 1, stream_);
 }
 
+// csrc/wgrad6.hip: the 3x3 correlation on the bf16 matrix pipe (three-piece split, fp32-equivalent); 1 = launched, 0 = not applicable
+int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB, hipStream_t s);
+
 static int wgrad_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB,
                         te_stream_t stream_) {
     TE_REQUIRE(slabs && g && x, TE_ERR_NULL, "te_wgrad_f32: NULL pointer");
     TE_REQUIRE(B > 0 && Co > 0 && Ci > 0 && H > 0 && W > 0 && S > 0, TE_ERR_SHAPE, "te_wgrad_f32: bad dims");
     TE_REQUIRE((int64_t)B * S <= 0x7FFFFFFF && te::cdiv(Co, QCH) <= 65535 && te::cdiv(Ci, QCH) <= 65535, TE_ERR_SHAPE,
                "te_wgrad_f32: grid too large");
+    if (te_wgrad6_launch(slabs, g, x, kind, B, Co, Ci, H, W, S, NB, (hipStream_t)stream_) == 1) return te::launch_status("te_wgrad_f32");
     WgArgs a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB;
     a.Hx = H; a.Wx = W;

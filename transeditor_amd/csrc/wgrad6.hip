@@ -1,0 +1,319 @@
+// Weight-gradient correlation of the 3x3 / stride 1 / pad 1 convolutions on the bf16 matrix pipe (round 5): the same slabs as
+// wgrad_mfma_kernel<TE_CONV_3X3, 4, true> of wgrad.hip -
+//     slab[b][s][co][ci][ky][kx] = sum over the cells (y, x) of chunk s of sample b   g[b, co, y, x] * x[b, ci, y + ky - 1, x + kx - 1]
+// (reference: the autograd of F.conv2d(groups = B) in ModulatedConv2d.forward, model_spatial_query.py:318-333; the per-sample scales are
+// applied by te_wgrad_reduce_f32, which is unchanged) - with every fp32 operand split into three bf16 pieces and six exact piece
+// products per multiply-add accumulated in fp32, as wino6.hip / s2s6.hip / t2s6.hip do for the forward and data-gradient passes
+// (same split, same product order "small terms first": fp32-equivalent results, tests/test_gpu_wgrad6.py).
+//
+// Pair form F(3,2) along x, as the fp32 kernel: for the pair (g0, g1) of the output gradient at columns (2p, 2p + 1) and the four
+// inputs e0..e3 at columns 2p - 1 .. 2p + 2 of one tap row,
+//     u = [g0, g0 + g1, g1 - g0, -g1]     t = [e0 - e2, e1 + e2, e2 - e1, e1 - e3]     m_j = sum over pairs u_j t_j
+//     dW[ky][0] = m0 + (m1 - m2) / 2      dW[ky][1] = (m1 + m2) / 2                   dW[ky][2] = (m1 - m2) / 2 + m3
+// (u2 carries the opposite sign of wgrad.hip's so that u1, u2 and t1, t2 are the SAME expressions of the staged registers in both
+// staging roles).  The reduction runs over PAIRS: one v_mfma_f32_32x32x16_bf16 consumes the 16 pairs of a 32-cell row segment, and a
+// step (one row segment) is 4 components x 3 tap rows x 6 piece products = 72 MFMAs per wave into twelve 32 x 32 accumulators.
+//
+// Block = 256 threads = 4 waves, ONE PER SIMD (192 accumulator registers + operands need the 512-register budget), tile 64 output x 64
+// input channels, wave (wco, wci) owns 32 x 32 of it.  A block walks the steps (sample of the group, 32-column tile, row) of its chunk
+// in sweeps down a column tile; the transformed and split operands live in LDS as six 24 KB images
+//     [piece 3][component 4][k half 2][channel 64][8 bf16]        (one conflict-free ds_read_b128 per MFMA operand)
+// - two for the gradient rows (double buffer) and a ring of four for the input rows (a step reads rows y - 1, y, y + 1 and row y + 2 is
+// being written), so an input row is transformed once per sweep, not once per tap row.  There is one role per wave and no idle
+// phase: while the 72 MFMAs of step y run, the wave's own vector ALU transforms and splits its share of the NEXT rows behind them
+// (waves 0-1: gradient row y + 1, waves 2-3: input row y + 2; a lane = 16 cells of one channel = whole 16-byte LDS elements) from
+// registers loaded during step y - 1, and the loads of the rows after that are issued at the head of the step: every global load
+// has a whole step (>= 2 300 cycles) to land.  One workgroup barrier per step.
+#include "conv_common.h"
+#include <atomic>
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WT = 256;                       // 4 waves
+constexpr int TC = 64;                        // channels per block, both sides
+constexpr int IMG = 3 * 4 * 2 * TC;           // 16-byte elements of one operand image: 1 536 (24 KB)
+constexpr int N_IMG = 6;                      // 2 gradient images + 4 input-row images
+constexpr unsigned OOBW = 0x80000000u;        // buffer offset beyond num_records: the load returns 0
+constexpr int NRAW = 18;                      // staged registers of a lane: columns c0 - 1 .. c0 + 16
+
+struct Wg6Args {
+    float* slabs; const float* g; const float* x;
+    int B, Co, Ci, H, W, S, NB, tiles_x;
+};
+
+__device__ __forceinline__ f32x4 buf_load4w(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void w6g_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef WG6_PROF      // experimental builds: cycle counts per wave (tools/wgrad6_check.py prof)
+__device__ unsigned long long te_wgrad6_prof_buf[2048 * 4 * 4];
+#endif
+
+__global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 32 x 32 tile
+    const bool role = (wid >> 1) != 0;                        // staging: false = gradient rows (waves 0, 1), true = input rows (2, 3)
+    const int kh = wid & 1;                                   //          k half = cells 16 kh .. 16 kh + 15 of the row segment; lane = channel
+
+    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;
+    const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned g_sample = (unsigned)(p.Co * plane * 4), x_sample = (unsigned)(p.Ci * plane * 4);      // bytes (host-checked < 2 GiB per group)
+    const __amdgpu_buffer_rsrc_t rs = role ? make_rsrc(p.x + (size_t)b * p.Ci * plane, x_sample * (unsigned)p.NB)
+                                           : make_rsrc(p.g + (size_t)b * p.Co * plane, g_sample * (unsigned)p.NB);
+    const unsigned my_sample = role ? x_sample : g_sample;
+    const unsigned chan_off = (unsigned)(((role ? ci0 : co0) + lane) * plane * 4);                         // bytes
+
+    f32x16 acc[12];                                           // [ky * 4 + component]
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- staging: raw registers -> 12 LDS elements (4 components x 3 pieces) of this lane's (channel, k half)
+    // rw[i] = column c0 - 1 + i of the row (c0 = first column of the lane's 16 cells); gradient rows: rw[0] = rw[17] = 0 (never used)
+    auto load_raw = [&](float (&rw)[NRAW], int bb, int cx, int row) {
+        const bool ok = (unsigned)row < (unsigned)p.H;
+        const int c0 = cx * 32 + 16 * kh;
+        const unsigned off = (unsigned)bb * my_sample + chan_off + (unsigned)((row * p.W + c0) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = buf_load4w(rs, ok ? off + 16u * q : OOBW);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rw[1 + 4 * q + e] = v[e];
+        }
+        rw[0] = buf_load(rs, (ok && role && c0 > 0) ? off - 4u : OOBW);
+        rw[17] = buf_load(rs, (ok && role && c0 + 16 < p.W) ? off + 64u : OOBW);
+    };
+    // one step of the split of unit (component j, dword d = pairs 2d, 2d + 1): the four steps of wino6.hip's slot program
+    unsigned pcs[3][4];                                       // [piece][dword] of the component in work
+    float v0 = 0.f, v1 = 0.f, f0 = 0.f, f1 = 0.f;
+    auto unit_step = [&](const float (&rw)[NRAW], int j, int d, int step) {
+        if (step == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int q = 2 * (2 * d + e);                // rw index of e0 of pair 2d + e
+                float v;
+                if (j == 0) v = (role ? rw[q] - rw[q + 2] : rw[q + 1]);
+                else if (j == 1) v = rw[q + 1] + rw[q + 2];
+                else if (j == 2) v = rw[q + 2] - rw[q + 1];
+                else v = (role ? rw[q + 1] - rw[q + 3] : -rw[q + 2]);
+                if (e == 0) v0 = v; else v1 = v;
+            }
+            const f32x2 t = {v0, v1};
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            pcs[0][d] = h;
+            f0 = __builtin_bit_cast(float, h << 16);
+            f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
+            asm volatile("" : "+v"(pcs[0][d]));
+        } else if (step == 1) {
+            v0 -= f0; v1 -= f1;
+        } else if (step == 2) {
+            const f32x2 t = {v0, v1};
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            pcs[1][d] = m;
+            f0 = __builtin_bit_cast(float, m << 16);
+            f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
+            asm volatile("" : "+v"(pcs[1][d]));
+        } else {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            pcs[2][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            asm volatile("" : "+v"(pcs[2][d]));
+        }
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));          // (pin the step where it is written: wino6.hip)
+    };
+    // element index of this lane inside an image: ((piece * 4 + j) * 2 + kh) * 64 + lane
+    const int w_elem = kh * TC + lane;
+    auto write_comp = [&](int img, int j) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            u32x4 v; v[0] = pcs[pc][0]; v[1] = pcs[pc][1]; v[2] = pcs[pc][2]; v[3] = pcs[pc][3];
+            lds[img * IMG + (pc * 4 + j) * 2 * TC + w_elem] = v;
+        }
+    };
+    auto stage_all = [&](const float (&rw)[NRAW], int img) {               // outside the MFMA stream (head of a sweep)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) unit_step(rw, j, d, st);
+            write_comp(img, j);
+        }
+    };
+    auto g_img = [&](int y) { return y & 1; };
+    auto x_img = [&](int y) { return 2 + (y & 3); };
+
+    const int sps = p.tiles_x * p.H;                          // steps of one sample
+    const int n_steps = sps * p.NB;
+    const int t_begin = (int)((int64_t)n_steps * s_chunk / p.S), t_end = (int)((int64_t)n_steps * (s_chunk + 1) / p.S);
+    const int a_elem = half * TC + wco * 32 + l31;            // + ((piece * 4 + j) * 2) * 64 + image * IMG
+    const int b_elem = half * TC + wci * 32 + l31;
+#ifdef WG6_PROF
+    unsigned long long pc_mult = 0, pc_head = 0, pc_bar = 0;
+    const unsigned long long pstart = __builtin_readcyclecounter();
+    int nstep_done = 0;
+#endif
+
+    float rw[NRAW], rn[NRAW];
+    for (int t = t_begin; t < t_end;) {
+        const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
+        const int n = min(p.H - ya, t_end - t), yb = ya + n;
+        t += n;
+#ifdef WG6_PROF
+        const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
+        // ---- head of a sweep: input rows ya - 1, ya, ya + 1 and gradient row ya, then the registers of the first step
+        {
+            float r0[NRAW], r1[NRAW];
+            load_raw(r0, bb, cx, role ? ya - 1 : -1);
+            load_raw(r1, bb, cx, role ? ya : -1);
+            load_raw(rn, bb, cx, role ? ya + 1 : ya);
+            load_raw(rw, bb, cx, role ? ya + 2 : ya + 1);
+            // (gradient role: the first two rounds write zeros to the image the third one fills - same lane, same elements, in order)
+            stage_all(r0, role ? x_img(ya - 1) : g_img(ya));
+            stage_all(r1, role ? x_img(ya) : g_img(ya));
+            stage_all(rn, role ? x_img(ya + 1) : g_img(ya));
+            // (a use of the first step's registers HERE: the compiler then waits for their loads at the end of the head; left pending
+            //  they put an `s_waitcnt vmcnt(5)` - one load of the step itself - in front of the arithmetic of every step of the loop)
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) asm volatile("" :: "v"(rw[i]));
+        }
+        w6g_barrier();
+#ifdef WG6_PROF
+        pc_head += __builtin_readcyclecounter() - th0;
+#endif
+        for (int y = ya; y < yb; ++y) {
+#ifdef WG6_PROF
+            const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
+            // registers of the step after next: input row y + 3 / gradient row y + 2 (a whole step to land)
+            load_raw(rn, bb, cx, role ? y + 3 : y + 2);
+            const int w_img = role ? x_img(y + 2) : g_img(y + 1);           // image this lane's results of the step go to
+            const int a_base = g_img(y) * IMG + a_elem;
+            int b_base[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) b_base[ky] = x_img(y - 1 + ky) * IMG + b_elem;
+            bf16x8 av[2][3], bv[2][3];
+            auto rd_a = [&](int j, int pc) { av[j & 1][pc] = __builtin_bit_cast(bf16x8, lds[a_base + (pc * 4 + j) * 2 * TC]); };
+            auto rd_b = [&](int gi, int pc) {
+                const int j = gi / 3, ky = gi % 3;
+                bv[gi & 1][pc] = __builtin_bit_cast(bf16x8, lds[b_base[ky] + (pc * 4 + j) * 2 * TC]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) { rd_a(0, pc); rd_b(0, pc); }
+#pragma unroll
+            for (int gi = 0; gi < 12; ++gi) {                                            // group = (component j, tap row ky)
+                const int j = gi / 3, ky = gi % 3;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+#ifndef WG6_SKIP_MFMA
+                    acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[gi & 1][PB[q]], acc[ky * 4 + j], 0, 0, 0);
+#endif
+                    if (gi + 1 < 12 && q < 3) {                                           // operands of the next group
+                        rd_b(gi + 1, q);
+                        if ((gi + 1) % 3 == 0) rd_a((gi + 1) / 3, q);
+                    }
+#ifndef WG6_SKIP_ARITH
+                    {   // the staging program: slot k = unit (k >> 2), step (k & 3); a component's three elements go to LDS behind its last step
+                        const int k = gi * 6 + q;
+                        if (k < 64) {
+                            unit_step(rw, k >> 4, (k >> 2) & 3, k & 3);
+                            if ((k & 15) == 15) write_comp(w_img, k >> 4);
+                        }
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#ifdef WG6_PROF
+            const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) rw[i] = rn[i];
+            w6g_barrier();
+#ifdef WG6_PROF
+            { const unsigned long long tm2 = __builtin_readcyclecounter(); pc_mult += tm1 - tm0; pc_bar += tm2 - tm1; ++nstep_done; }
+#endif
+        }
+    }
+#ifdef WG6_PROF
+    {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lane == 0 && lin < 2048) {
+            unsigned long long* d = te_wgrad6_prof_buf + ((size_t)lin * 4 + wid) * 4;
+            d[0] = pc_mult; d[1] = pc_head; d[2] = pc_bar;
+            d[3] = ((unsigned long long)nstep_done << 40) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFull);
+        }
+    }
+#endif
+
+    // ---- fold the twelve accumulators to the nine taps and write the slab tile: slab[b][s][co][ci][tap]
+    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
+    const int ci = ci0 + wci * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float* dst = sl + ((size_t)co * p.Ci + ci) * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float hs = 0.5f * (acc[4 * ky + 1][r] - acc[4 * ky + 2][r]);
+            dst[3 * ky + 0] = acc[4 * ky + 0][r] + hs;
+            dst[3 * ky + 1] = 0.5f * (acc[4 * ky + 1][r] + acc[4 * ky + 2][r]);
+            dst[3 * ky + 2] = hs + acc[4 * ky + 3][r];
+        }
+    }
+}
+
+// on by default; TE_SPLIT_WGRAD=0 (or TE_SPLIT_BF16=0, the switch of all split kernels) keeps the fp32 kernel - A/B measurements
+std::atomic<int> g_wg6_on{[] {
+    const char* e = getenv("TE_SPLIT_WGRAD");
+    if (e) return atoi(e) ? 1 : 0;
+    const char* a = getenv("TE_SPLIT_BF16");
+    return (a && atoi(a) == 0) ? 0 : 1;
+}()};
+
+}  // namespace
+
+#ifdef WG6_PROF
+extern "C" int te_debug_wgrad6_prof(void* host_dst, int64_t bytes) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(te_wgrad6_prof_buf), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// process-wide switch (0 / 1; anything else only queries): does te_wgrad_f32 / te_wgrad_group_f32 take this kernel where it applies?
+extern "C" int te_wgrad_split_bf16(int on) {
+    const int old = g_wg6_on.load(std::memory_order_relaxed);
+    if (on == 0 || on == 1) g_wg6_on.store(on, std::memory_order_relaxed);
+    return old;
+}
+
+extern "C" int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W) {
+    return (kind == TE_CONV_3X3 && Co > 0 && Ci > 0 && Co % TC == 0 && Ci % TC == 0 && H > 0 && W >= 32 && W % 32 == 0) ? 1 : 0;
+}
+
+// returns 1 when the launch was taken, 0 when the caller has to use the fp32 kernel, < 0 on error
+int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB, hipStream_t s) {
+    if (!g_wg6_on.load(std::memory_order_relaxed) || !te_wgrad_split_supported(kind, Co, Ci, H, W)) return 0;
+    if ((int64_t)NB * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;
+    if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return 0;
+    Wg6Args a{};
+    a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB; a.tiles_x = W / 32;
+    static std::atomic<uint64_t> attr_done{0};
+    te::allow_big_lds(attr_done, (const void*)wgrad6_kernel, 160 * 1024);
+    dim3 grid((unsigned)(B / NB * S), (unsigned)(Co / TC), (unsigned)(Ci / TC));
+    wgrad6_kernel<<<grid, WT, (size_t)N_IMG * IMG * 16, s>>>(a);
+    return 1;
+}
