@@ -151,9 +151,10 @@ class KernelTimer:
             #  pair form as six bf16 piece products per multiply-add: 4x the algorithmic FLOPs on the bf16 pipe, none on the fp32 one)
             split = bool(_lib.wgrad_split() and _lib.wgrad_split_ok(kind, g.shape[1], x.shape[1], H, W))
             ex32 = 0.0 if split else flops * (2.0 / 3.0 if _lib.wgrad_pair_form(kind, g.shape[1], x.shape[1], H, W) else 1.0)
-            timer.records.append(('wgrad_' + names[kind], flops, s, e, ex32, 4.0 * flops if split else 0.0))
+            ex16 = (4.0 if kind == _lib.CONV_3X3 else 6.0) * flops if split else 0.0      # (transposed kind: no pair form, 6 products)
+            timer.records.append(('wgrad_' + names[kind], flops, s, e, ex32, ex16))
             if split:
-                timer.records.append(('wgrad_conv3x3_split_bf16', flops, s, e, ex32, 4.0 * flops))
+                timer.records.append(('wgrad_' + names[kind] + '_split_bf16', flops, s, e, ex32, ex16))
             return out
 
         _lib.conv, _lib.wgrad_slabs = conv, wgrad

@@ -1,7 +1,8 @@
 """The weight-gradient correlation of the 3x3 convolutions on the bf16 matrix pipe (csrc/wgrad6.hip: pair form F(3,2), three bf16 pieces per
 fp32 operand, six exact piece products per multiply-add, fp32 accumulation) against fp64 torch and against the fp32 kernel (same slabs,
 wgrad.hip) - reference: autograd of F.conv2d(groups = B) in ModulatedConv2d.forward, model_spatial_query.py:318-333.  Shapes: one and
-several 32-column tiles, chunk boundaries inside a column (S > 1), image borders on all sides, several channel blocks, the grouped form
+several 32-column tiles, chunk boundaries inside a column (S > 1), image borders on all sides, several channel blocks, the transposed
+kind (TE_CONV_T2: the up- / down-sampling layers), the grouped form
 (samples share a slab), the three gradients of the reducer on top of the slabs, the range sweep, the selection rule and the switch.
 Pinned at the bar of the fp32 kernels: 5e-6 against fp64."""
 import math
@@ -87,6 +88,42 @@ def test_split_bf16_weight_gradient_grouped_and_reduced():
         assert rel_err(a, b) < 5e-6
 
 
+T_SHAPES = [(2, 64, 64, 8, 16), (3, 128, 64, 13, 32), (1, 64, 192, 20, 48), (4, 64, 64, 5, 16), (1, 64, 64, 1, 16), (2, 128, 128, 32, 32)]
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', T_SHAPES)
+def test_split_bf16_weight_gradient_transposed_kind_vs_fp64(B, Co, Ci, H, W):
+    """kind TE_CONV_T2: slab[co][ci][ky][kx] = sum g[co, 2i + ky, 2j + kx] x[ci, i, j] - the weight gradient of the generator's up-sampling
+    convolutions (model_spatial_query.py:310-321) and, with the two tensors swapped, of the discriminator's down-sampling ones (:765-779)"""
+    assert _lib.wgrad_split_ok(_lib.CONV_T2, Co, Ci, H, W)
+    g = synth.normal((B, Co, 2 * H + 1, 2 * W + 1), f'wg6t.g.{Co}.{H}').to(DEV)
+    x = synth.normal((B, Ci, H, W), f'wg6t.x.{Ci}.{H}').to(DEV)
+    want = torch.stack([torch.nn.grad.conv2d_weight(g[b:b + 1].double(), (Ci, Co, 3, 3), x[b:b + 1].double(), stride=2)
+                        for b in range(B)]).transpose(1, 2).reshape(B, Co, Ci, 9)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+    assert got.shape == ref.shape
+    got, ref = got.sum(1), ref.sum(1)
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    print(f'split-bf16 weight gradient, transposed kind {Ci}->{Co} @{H}x{W} B{B}: max {rel_err(got, want):.2e} (fp32 kernel '
+          f'{rel_err(ref, want):.2e}), L2 {l2(got):.2e} ({l2(ref):.2e})')
+    assert rel_err(got, want) < 5e-6
+    assert l2(got) < 2.5 * l2(ref) + 1e-7
+
+
+def test_split_bf16_weight_gradient_transposed_kind_long_reduction():
+    B, Co, Ci, H, W = 2, 128, 128, 128, 128
+    g = synth.normal((B, Co, 2 * H + 1, 2 * W + 1), 'wg6t.lg').to(DEV)
+    x = synth.normal((B, Ci, H, W), 'wg6t.lx').to(DEV)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W).sum(1)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W).sum(1)
+    assert rel_err(got, ref) < 5e-6
+
+
 @pytest.mark.parametrize('scale', [1e-30, 1e-12, 1.0, 1e12, 1e18])
 def test_split_bf16_weight_gradient_range(scale):
     """operands from 1e-30 to 1e18: the split keeps 24 mantissa bits wherever the pieces stay normal bf16 numbers (they share fp32's
@@ -107,7 +144,8 @@ def test_split_bf16_weight_gradient_selection_and_switch():
     assert ok(_lib.CONV_3X3, 128, 128, 256, 256) and ok(_lib.CONV_3X3, 512, 64, 4, 32)
     assert not ok(_lib.CONV_3X3, 96, 128, 32, 32) and not ok(_lib.CONV_3X3, 128, 32, 32, 32)      # whole 64-channel blocks only
     assert not ok(_lib.CONV_3X3, 128, 128, 16, 16) and not ok(_lib.CONV_3X3, 128, 128, 32, 48)    # whole 32-column tiles only
-    assert not ok(_lib.CONV_T2, 128, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
+    assert ok(_lib.CONV_T2, 128, 128, 32, 32) and ok(_lib.CONV_T2, 512, 512, 16, 16)
+    assert not ok(_lib.CONV_T2, 128, 128, 8, 8) and not ok(_lib.CONV_T2, 96, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
     old = _lib.wgrad_split(0)
     assert _lib.wgrad_split() == 0 and _lib.wgrad_split(1) == 0 and _lib.wgrad_split() == 1
     _lib.wgrad_split(old)

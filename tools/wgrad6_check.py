@@ -82,6 +82,38 @@ def main():
             torch.cuda.synchronize()
             msg += ' | ' + prof(B * out[1].shape[1] * (Co // 64) * (Ci // 64))
         print(msg, flush=True)
+    # ---- transposed kind: slab[co][ci][ky][kx] = sum g[co, 2i + ky, 2j + kx] x[ci, i, j]
+    small_t = [(2, 64, 64, 8, 16), (3, 128, 64, 13, 32), (1, 64, 192, 20, 48), (4, 64, 64, 5, 16), (1, 64, 64, 1, 16)]
+    big_t = [(16, 128, 128, 128, 128), (16, 256, 256, 64, 64), (16, 512, 512, 32, 32), (16, 512, 512, 16, 16), (32, 256, 128, 64, 64)]
+    for B, Co, Ci, H, W in small_t + ([] if os.environ.get('SMALL') else big_t):
+        assert _lib.wgrad_split_ok(_lib.CONV_T2, Co, Ci, H, W), (Co, Ci, H, W)
+        torch.manual_seed(0)
+        g = torch.randn(B, Co, 2 * H + 1, 2 * W + 1, device=DEV)
+        x = torch.randn(B, Ci, H, W, device=DEV)
+        out = {}
+        for on in (0, 1):
+            _lib.wgrad_split(on)
+            out[on] = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+        msg = f'T2 B{B} {Ci}->{Co} @{H}x{W} (S={out[0].shape[1]}):'
+        s0, s1 = out[0].sum(1), out[1].sum(1)
+        if B * Co * Ci * H * W <= 2 ** 26:
+            # fp64 reference: the weight gradient of a stride-2 convolution from g (the big image) to x's grid
+            want = torch.stack([torch.nn.grad.conv2d_weight(g[b:b + 1].double(), (Ci, Co, 3, 3), x[b:b + 1].double(), stride=2)
+                                for b in range(B)]).transpose(1, 2).reshape(B, Co, Ci, 9)
+            e1, e0 = rel(s1, want), rel(s0, want)
+            msg += f' vs fp64 (max / L2): split {e1:.2e} / {rel2(s1, want):.2e}, fp32 kernel {e0:.2e} / {rel2(s0, want):.2e}'
+            bad += 0 if e1 < 5e-6 else 1
+        else:
+            e = rel(s1, s0)
+            msg += f' vs fp32 kernel: {e:.2e} / {rel2(s1, s0):.2e}'
+            bad += 0 if e < 5e-6 else 1
+        flops = 2.0 * 9 * Co * Ci * H * W * B
+        t = {}
+        for on in (0, 1, 0, 1):
+            _lib.wgrad_split(on)
+            t[on] = min(t.get(on, 1e9), timeit(lambda: _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W), n=10))
+        msg += f' | split {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s, fp32 kernel {t[0] * 1e3:8.1f} us {flops / t[0] / 1e9:6.1f} TF/s'
+        print(msg, flush=True)
     # grouped form (samples share a slab): plain gradient of small images
     for B, Co, Ci, H, W in [(8, 128, 128, 32, 32), (32, 512, 512, 32, 32)]:
         g = torch.randn(B, Co, H, W, device=DEV)

@@ -32,6 +32,7 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WT = 256;                       // 4 waves
@@ -277,6 +278,204 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- transposed kind
+// TE_CONV_T2 (the weight gradient of the generator's up-sampling and - with the two tensors swapped - of the discriminator's
+// down-sampling convolutions, model_spatial_query.py:310-321 / :765-779):
+//     slab[b][s][co][ci][ky][kx] = sum over the cells (i, j)   g[b, co, 2 i + ky, 2 j + kx] * x[b, ci, i, j]        g: (2H+1) x (2W+1), x: H x W
+// Stride 2 decouples the taps (no Winograd form): the direct 9 taps x 6 piece products = 54 MFMAs per wave and step of 16 cells of a
+// row (the reduction runs over cells: one MFMA = 16 cells).  The A operand of tap (ky, kx) is a stride-2 subsequence of g row 2 i + ky -
+// even columns from j (kx = 0), odd columns (kx = 1), even columns from j + 1 (kx = 2) - so a g row lives in LDS as three COMPONENTS
+// x three pieces, [piece 3][component 3][k half 2][channel 64][8 bf16] = 18 KB, in a ring of five rows (a step reads rows 2i, 2i+1,
+// 2i+2 while rows 2i+3, 2i+4 are written: every g row is split once per sweep); the third component is the first one shifted by one
+// value, built from its packed pieces with v_alignbit, not split again.  x rows: [piece 3][k half 2][channel 64], double buffer.
+// Same block shape and pipeline as wgrad6_kernel: 4 waves, one per SIMD, 64 x 64 channels, the staging program of the next step
+// behind the MFMAs of the current one, loads a whole step ahead.  All four waves have the same staging work: one g unit (row
+// 2i + 3 + (wave >> 1), 8 cells = 17 columns, one channel per lane) and one x unit (waves 2, 3 repeat the x units of waves 0, 1).
+constexpr int GI = 3 * 3 * 2 * TC;            // elements of one g-row image: 1 152 (18 KB)
+constexpr int XI = 3 * 2 * TC;                // elements of one x-row image: 384 (6 KB)
+constexpr int NGR = 5;
+
+__global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 32 x 32 tile
+    const int rsel = wid >> 1, q = wid & 1;                   // staging: g row 2i + 3 + rsel, cells 8 q .. 8 q + 7 of the step; lane = channel
+
+    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;
+    const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
+    const int Hg = 2 * p.H + 1, Wg = 2 * p.W + 1;
+    const size_t gplane = (size_t)Hg * Wg, xplane = (size_t)p.H * p.W;
+    const float* gch = p.g + ((size_t)b * p.Co + co0 + lane) * gplane;       // this lane's channel of the group's first sample
+    const float* xch = p.x + ((size_t)b * p.Ci + ci0 + lane) * xplane;
+
+    f32x16 acc[9];                                            // [ky * 3 + kx]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // rows past the end are clamped to the last row (their registers are never used: no element of g or x is padding)
+    auto load_g = [&](float (&rg)[17], int bb, int cx, int grow) {
+        const float* src = gch + (size_t)bb * p.Co * gplane + (size_t)min(grow, Hg - 1) * Wg + 2 * (16 * cx + 8 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rg[4 * k + e] = v[e];
+        }
+        rg[16] = src[16];
+    };
+    auto load_x = [&](float (&rx)[8], int bb, int cx, int xrow) {
+        const float* src = xch + (size_t)bb * p.Ci * xplane + (size_t)min(xrow, p.H - 1) * p.W + 16 * cx + 8 * q;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rx[4 * k + e] = v[e];
+        }
+    };
+    // split of one packed pair of values in three steps; units 0..4: even columns of the g unit (pair d = columns 4d, 4d + 2; the
+    // last one holds column 16 alone), 5..8: odd columns (4d + 1, 4d + 3), 9..12: the x unit
+    unsigned pe[3][5], po[3][4], px[3][4];
+    float v0 = 0.f, v1 = 0.f, f0 = 0.f, f1 = 0.f;
+    auto unit_step = [&](const float (&rg)[17], const float (&rx)[8], int u, int step) {
+        unsigned& d0 = u < 5 ? pe[0][u] : (u < 9 ? po[0][u - 5] : px[0][u - 9]);
+        unsigned& d1 = u < 5 ? pe[1][u] : (u < 9 ? po[1][u - 5] : px[1][u - 9]);
+        unsigned& d2 = u < 5 ? pe[2][u] : (u < 9 ? po[2][u - 5] : px[2][u - 9]);
+        if (step == 0) {
+            if (u < 5) { v0 = rg[4 * u]; v1 = u < 4 ? rg[4 * u + 2] : 0.f; }
+            else if (u < 9) { v0 = rg[4 * (u - 5) + 1]; v1 = rg[4 * (u - 5) + 3]; }
+            else { v0 = rx[2 * (u - 9)]; v1 = rx[2 * (u - 9) + 1]; }
+            const f32x2 t = {v0, v1};
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d0 = h;
+            f0 = __builtin_bit_cast(float, h << 16);
+            f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
+            asm volatile("" : "+v"(d0));
+        } else if (step == 1) {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d1 = m;
+            f0 = __builtin_bit_cast(float, m << 16);
+            f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
+            asm volatile("" : "+v"(d1));
+        } else {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            d2 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            asm volatile("" : "+v"(d2));
+        }
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));
+    };
+    const int w_elem = q * TC + lane;             // + ((piece * 3 + component) * 2) * 64 (g) / (piece * 2) * 64 (x)
+    auto write_g = [&](int gimg, int comp, int pc) {          // component 0: even columns, 1: odd columns, 2: even columns from the second on
+        u32x4 v;
+        if (comp == 0) { v[0] = pe[pc][0]; v[1] = pe[pc][1]; v[2] = pe[pc][2]; v[3] = pe[pc][3]; }
+        else if (comp == 1) { v[0] = po[pc][0]; v[1] = po[pc][1]; v[2] = po[pc][2]; v[3] = po[pc][3]; }
+        else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) v[d] = __builtin_amdgcn_alignbit(pe[pc][d + 1], pe[pc][d], 16);
+        }
+        lds[gimg * GI + (pc * 3 + comp) * 2 * TC + w_elem] = v;
+    };
+    auto write_x = [&](int ximg, int pc) {
+        u32x4 v; v[0] = px[pc][0]; v[1] = px[pc][1]; v[2] = px[pc][2]; v[3] = px[pc][3];
+        lds[NGR * GI + ximg * XI + pc * 2 * TC + w_elem] = v;
+    };
+    // the staging program: slots 0..38 = 13 units x 3 steps, the writes of a finished group in the slot of its last step (the
+    // shifted component in slots 39..41)
+    auto stage_slot = [&](const float (&rg)[17], const float (&rx)[8], int k, int gimg, int ximg) {
+        if (k < 39) unit_step(rg, rx, k / 3, k % 3);
+        if (k == 14) { write_g(gimg, 0, 0); write_g(gimg, 0, 1); write_g(gimg, 0, 2); }
+        if (k == 26) { write_g(gimg, 1, 0); write_g(gimg, 1, 1); write_g(gimg, 1, 2); }
+        if (k == 38) { write_x(ximg, 0); write_x(ximg, 1); write_x(ximg, 2); }
+        if (k >= 39 && k < 42) write_g(gimg, 2, k - 39);
+    };
+
+    const int tiles_x = p.W / 16;
+    const int sps = tiles_x * p.H, n_steps = sps * p.NB;
+    const int t_begin = (int)((int64_t)n_steps * s_chunk / p.S), t_end = (int)((int64_t)n_steps * (s_chunk + 1) / p.S);
+    const int a_elem = half * TC + wco * 32 + l31;
+    const int b_elem = NGR * GI + half * TC + wci * 32 + l31;
+
+    float rg[17], rx[8], ng[17], nx[8];
+    for (int t = t_begin; t < t_end;) {
+        const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
+        const int n = min(p.H - ya, t_end - t), yb = ya + n;
+        t += n;
+        // ---- head of a sweep: g rows 2 ya .. 2 ya + 3 into ring slots 0..3, x row ya into buffer ya & 1, registers of the first step
+        {
+            float g0[17], g1[17];
+            load_g(g0, bb, cx, 2 * ya + rsel);
+            load_g(g1, bb, cx, 2 * ya + 2 + rsel);
+            load_x(nx, bb, cx, ya);
+            load_g(rg, bb, cx, 2 * ya + 3 + rsel);
+            load_x(rx, bb, cx, ya + 1);
+#pragma unroll
+            for (int k = 0; k < 42; ++k) stage_slot(g0, nx, k, rsel, ya & 1);
+#pragma unroll
+            for (int k = 0; k < 42; ++k) stage_slot(g1, nx, k, 2 + rsel, ya & 1);
+#pragma unroll
+            for (int i = 0; i < 17; ++i) asm volatile("" :: "v"(rg[i]));          // (wait for the first step's registers here: wgrad6_kernel)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(rx[i]));
+        }
+        w6g_barrier();
+        int s0 = 0;                                           // ring slot of g row 2 y
+        for (int y = ya; y < yb; ++y) {
+            load_g(ng, bb, cx, 2 * y + 5 + rsel);             // registers of the step after next
+            load_x(nx, bb, cx, y + 2);
+            int wslot = s0 + 3 + rsel; wslot -= wslot >= NGR ? NGR : 0;
+            int a_base[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { int sl = s0 + ky; sl -= sl >= NGR ? NGR : 0; a_base[ky] = sl * GI + a_elem; }
+            const int b_base = b_elem + (y & 1) * XI;
+            bf16x8 av[2][3], bx[3];
+            auto rd_a = [&](int tp, int pc) {
+                const int ky = tp / 3, kx = tp % 3;
+                av[tp & 1][pc] = __builtin_bit_cast(bf16x8, lds[a_base[ky] + (pc * 3 + kx) * 2 * TC]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) { bx[pc] = __builtin_bit_cast(bf16x8, lds[b_base + pc * 2 * TC]); rd_a(0, pc); }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < 6; ++qq) {
+#ifndef WG6_SKIP_MFMA
+                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tp & 1][PA[qq]], bx[PB[qq]], acc[tp], 0, 0, 0);
+#endif
+                    if (tp + 1 < 9 && qq < 3) rd_a(tp + 1, qq);
+#ifndef WG6_SKIP_ARITH
+                    stage_slot(rg, rx, tp * 6 + qq, wslot, (y + 1) & 1);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 17; ++i) rg[i] = ng[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rx[i] = nx[i];
+            s0 += 2; s0 -= s0 >= NGR ? NGR : 0;
+            w6g_barrier();
+        }
+    }
+
+    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
+    const int ci = ci0 + wci * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float* dst = sl + ((size_t)co * p.Ci + ci) * 9;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) dst[tp] = acc[tp][r];
+    }
+}
+
 // on by default; TE_SPLIT_WGRAD=0 (or TE_SPLIT_BF16=0, the switch of all split kernels) keeps the fp32 kernel - A/B measurements
 std::atomic<int> g_wg6_on{[] {
     const char* e = getenv("TE_SPLIT_WGRAD");
@@ -284,6 +483,9 @@ std::atomic<int> g_wg6_on{[] {
     const char* a = getenv("TE_SPLIT_BF16");
     return (a && atoi(a) == 0) ? 0 : 1;
 }()};
+
+// TE_SPLIT_WGRAD_T2=0: the transposed kind alone stays on the fp32 kernel (A/B measurements)
+std::atomic<int> g_wg6t_on{[] { const char* e = getenv("TE_SPLIT_WGRAD_T2"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 
 }  // namespace
 
@@ -301,19 +503,29 @@ extern "C" int te_wgrad_split_bf16(int on) {
 }
 
 extern "C" int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W) {
-    return (kind == TE_CONV_3X3 && Co > 0 && Ci > 0 && Co % TC == 0 && Ci % TC == 0 && H > 0 && W >= 32 && W % 32 == 0) ? 1 : 0;
+    if (!(Co > 0 && Ci > 0 && Co % TC == 0 && Ci % TC == 0 && H > 0)) return 0;
+    if (kind == TE_CONV_3X3) return (W >= 32 && W % 32 == 0) ? 1 : 0;
+    if (kind == TE_CONV_T2) return (W >= 16 && W % 16 == 0) ? 1 : 0;
+    return 0;
 }
 
 // returns 1 when the launch was taken, 0 when the caller has to use the fp32 kernel, < 0 on error
 int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB, hipStream_t s) {
     if (!g_wg6_on.load(std::memory_order_relaxed) || !te_wgrad_split_supported(kind, Co, Ci, H, W)) return 0;
-    if ((int64_t)NB * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;
     if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return 0;
     Wg6Args a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB; a.tiles_x = W / 32;
+    dim3 grid((unsigned)(B / NB * S), (unsigned)(Co / TC), (unsigned)(Ci / TC));
+    if (kind == TE_CONV_T2) {
+        if (!g_wg6t_on.load(std::memory_order_relaxed)) return 0;
+        static std::atomic<uint64_t> attr_done_t{0};
+        te::allow_big_lds(attr_done_t, (const void*)wgrad6t_kernel, 160 * 1024);
+        wgrad6t_kernel<<<grid, WT, (size_t)(NGR * GI + 2 * XI) * 16, s>>>(a);
+        return 1;
+    }
+    if ((int64_t)NB * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)wgrad6_kernel, 160 * 1024);
-    dim3 grid((unsigned)(B / NB * S), (unsigned)(Co / TC), (unsigned)(Ci / TC));
     wgrad6_kernel<<<grid, WT, (size_t)N_IMG * IMG * 16, s>>>(a);
     return 1;
 }
