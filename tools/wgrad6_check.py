@@ -113,6 +113,11 @@ def main():
             _lib.wgrad_split(on)
             t[on] = min(t.get(on, 1e9), timeit(lambda: _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W), n=10))
         msg += f' | split {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s, fp32 kernel {t[0] * 1e3:8.1f} us {flops / t[0] / 1e9:6.1f} TF/s'
+        if os.environ.get('PROF'):
+            _lib.wgrad_split(1)
+            _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+            torch.cuda.synchronize()
+            msg += ' | ' + prof(B * out[1].shape[1] * (Co // 64) * (Ci // 64)).replace('2304', '1728')
         print(msg, flush=True)
     # grouped form (samples share a slab): plain gradient of small images
     for B, Co, Ci, H, W in [(8, 128, 128, 32, 32), (32, 512, 512, 32, 32)]:

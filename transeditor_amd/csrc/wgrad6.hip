@@ -52,6 +52,12 @@ __device__ __forceinline__ f32x4 buf_load4w(__amdgpu_buffer_rsrc_t r, unsigned o
 }
 __device__ __forceinline__ void w6g_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef WG6_ILV
+#define WG6_ILV 1    // 1: consecutive MFMAs on different accumulators (see the MFMA loop); 0: six in a row per accumulator (A/B)
+#endif
+#ifndef WG6_SLOT0
+#define WG6_SLOT0 0  // MFMA behind which the 64-slot staging program starts (72 MFMAs per step)
+#endif
 #ifdef WG6_PROF      // experimental builds: cycle counts per wave (tools/wgrad6_check.py prof)
 __device__ unsigned long long te_wgrad6_prof_buf[2048 * 4 * 4];
 #endif
@@ -97,6 +103,12 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     };
     // one step of the split of unit (component j, dword d = pairs 2d, 2d + 1): the four steps of wino6.hip's slot program
     unsigned pcs[3][4];                                       // [piece][dword] of the component in work
+    // (One unit advances per slot.  Instructions of the wave's own stream are not free - a step costs ~4.5 cycles per vector-ALU
+    //  instruction on top of the MFMAs' 35 - so the program is kept short: no register pins on the finished pieces (they cost a
+    //  move each), selects only where the two roles differ.  Bundling two units per slot - 32 full slots, 40 empty - measured 3 660
+    //  cycles per step against 3 430; the subtractions written as float2 came out scalar again: profiles/experiments/r05_wgrad6.log.)
+    // (v_pk_add_f32 for the two subtractions of a step - inline assembly on 64-bit register pairs - measured 4 094 cycles per step
+    //  against 3 430: packed fp32 is not faster here and drags hazard nops in)
     float v0 = 0.f, v1 = 0.f, f0 = 0.f, f1 = 0.f;
     auto unit_step = [&](const float (&rw)[NRAW], int j, int d, int step) {
         if (step == 0) {
@@ -115,7 +127,6 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
             pcs[0][d] = h;
             f0 = __builtin_bit_cast(float, h << 16);
             f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
-            asm volatile("" : "+v"(pcs[0][d]));
         } else if (step == 1) {
             v0 -= f0; v1 -= f1;
         } else if (step == 2) {
@@ -124,12 +135,10 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
             pcs[1][d] = m;
             f0 = __builtin_bit_cast(float, m << 16);
             f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
-            asm volatile("" : "+v"(pcs[1][d]));
         } else {
             v0 -= f0; v1 -= f1;
             const f32x2 t = {v0, v1};
             pcs[2][d] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
-            asm volatile("" : "+v"(pcs[2][d]));
         }
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));          // (pin the step where it is written: wino6.hip)
     };
@@ -142,15 +151,15 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
             lds[img * IMG + (pc * 4 + j) * 2 * TC + w_elem] = v;
         }
     };
+    // slot k of the staging program (64 slots): unit k >> 2 = (component k >> 4, dword (k >> 2) & 3), step k & 3; a component's three
+    // elements go to LDS behind its last step
+    auto stage_slot = [&](const float (&rw)[NRAW], int k, int img) {
+        unit_step(rw, k >> 4, (k >> 2) & 3, k & 3);
+        if ((k & 15) == 15) write_comp(img, k >> 4);
+    };
     auto stage_all = [&](const float (&rw)[NRAW], int img) {               // outside the MFMA stream (head of a sweep)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int st = 0; st < 4; ++st) unit_step(rw, j, d, st);
-            write_comp(img, j);
-        }
+        for (int k = 0; k < 64; ++k) stage_slot(rw, k, img);
     };
     auto g_img = [&](int y) { return y & 1; };
     auto x_img = [&](int y) { return 2 + (y & 3); };
@@ -205,6 +214,43 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
             int b_base[3];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) b_base[ky] = x_img(y - 1 + ky) * IMG + b_elem;
+#if WG6_ILV
+            // MFMA order inside a component: product q of the three tap rows in turn, so that consecutive MFMAs write DIFFERENT
+            // accumulators (an accumulator is touched every third instruction; each one still sees its six products in the order
+            // mm, hl, lh, hm, mh, hh).  Six in a row into one accumulator ran at ~48 cycles per MFMA instead of 32.
+            bf16x8 av[2][3], bv[2][3][3];
+            auto rd_a = [&](int j, int pc) { av[j & 1][pc] = __builtin_bit_cast(bf16x8, lds[a_base + (pc * 4 + j) * 2 * TC]); };
+            auto rd_b = [&](int j, int ky, int pc) { bv[j & 1][ky][pc] = __builtin_bit_cast(bf16x8, lds[b_base[ky] + (pc * 4 + j) * 2 * TC]); };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                rd_a(0, pc);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) rd_b(0, ky, pc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 18; ++m) {
+                    const int q = m / 3, ky = m % 3;
+#ifndef WG6_SKIP_MFMA
+                    acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[j & 1][ky][PB[q]], acc[ky * 4 + j], 0, 0, 0);
+#endif
+                    if (j + 1 < 4 && m < 12) {                                            // operands of the next component: 12 reads
+                        if (m < 3) rd_a(j + 1, m);
+                        else rd_b(j + 1, (m - 3) / 3, (m - 3) % 3);
+                    }
+#ifndef WG6_SKIP_ARITH
+                    {   // the staging program: slot k = unit (k >> 2), step (k & 3); a component's three elements go to LDS behind its last step
+                        const int k = j * 18 + m - WG6_SLOT0;
+                        if (k >= 0 && k < 64) stage_slot(rw, k, w_img);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
             bf16x8 av[2][3], bv[2][3];
             auto rd_a = [&](int j, int pc) { av[j & 1][pc] = __builtin_bit_cast(bf16x8, lds[a_base + (pc * 4 + j) * 2 * TC]); };
             auto rd_b = [&](int gi, int pc) {
@@ -229,16 +275,14 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
                     }
 #ifndef WG6_SKIP_ARITH
                     {   // the staging program: slot k = unit (k >> 2), step (k & 3); a component's three elements go to LDS behind its last step
-                        const int k = gi * 6 + q;
-                        if (k < 64) {
-                            unit_step(rw, k >> 4, (k >> 2) & 3, k & 3);
-                            if ((k & 15) == 15) write_comp(w_img, k >> 4);
-                        }
+                        const int k = gi * 6 + q - WG6_SLOT0;
+                        if (k >= 0 && k < 64) stage_slot(rw, k, w_img);
                     }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
 #ifdef WG6_PROF
             const unsigned long long tm1 = __builtin_readcyclecounter();
 #endif
@@ -307,8 +351,11 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
     const int Hg = 2 * p.H + 1, Wg = 2 * p.W + 1;
     const size_t gplane = (size_t)Hg * Wg, xplane = (size_t)p.H * p.W;
-    const float* gch = p.g + ((size_t)b * p.Co + co0 + lane) * gplane;       // this lane's channel of the group's first sample
-    const float* xch = p.x + ((size_t)b * p.Ci + ci0 + lane) * xplane;
+    // addresses = uniform 64-bit base (scalar registers) + this lane's 32-bit byte offset (its channel): the scalar-base form of the
+    // global loads, no 64-bit vector arithmetic in the step
+    const float* gblk = p.g + ((size_t)b * p.Co + co0) * gplane;             // channel block of the group's first sample
+    const float* xblk = p.x + ((size_t)b * p.Ci + ci0) * xplane;
+    const unsigned g_lane = (unsigned)(lane * gplane * 4), x_lane = (unsigned)(lane * xplane * 4);       // bytes (host-checked < 2 GiB)
 
     f32x16 acc[9];                                            // [ky * 3 + kx]
 #pragma unroll
@@ -318,20 +365,20 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
 
     // rows past the end are clamped to the last row (their registers are never used: no element of g or x is padding)
     auto load_g = [&](float (&rg)[17], int bb, int cx, int grow) {
-        const float* src = gch + (size_t)bb * p.Co * gplane + (size_t)min(grow, Hg - 1) * Wg + 2 * (16 * cx + 8 * q);
+        const char* src = reinterpret_cast<const char*>(gblk + (size_t)bb * p.Co * gplane + (size_t)min(grow, Hg - 1) * Wg + 2 * (16 * cx + 8 * q));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 4 * k);
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 16 * k + g_lane);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rg[4 * k + e] = v[e];
         }
-        rg[16] = src[16];
+        rg[16] = *reinterpret_cast<const float*>(src + 64 + g_lane);
     };
     auto load_x = [&](float (&rx)[8], int bb, int cx, int xrow) {
-        const float* src = xch + (size_t)bb * p.Ci * xplane + (size_t)min(xrow, p.H - 1) * p.W + 16 * cx + 8 * q;
+        const char* src = reinterpret_cast<const char*>(xblk + (size_t)bb * p.Ci * xplane + (size_t)min(xrow, p.H - 1) * p.W + 16 * cx + 8 * q);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 4 * k);
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 16 * k + x_lane);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rx[4 * k + e] = v[e];
         }
@@ -353,7 +400,6 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
             d0 = h;
             f0 = __builtin_bit_cast(float, h << 16);
             f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
-            asm volatile("" : "+v"(d0));
         } else if (step == 1) {
             v0 -= f0; v1 -= f1;
             const f32x2 t = {v0, v1};
@@ -361,12 +407,10 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
             d1 = m;
             f0 = __builtin_bit_cast(float, m << 16);
             f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
-            asm volatile("" : "+v"(d1));
         } else {
             v0 -= f0; v1 -= f1;
             const f32x2 t = {v0, v1};
             d2 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
-            asm volatile("" : "+v"(d2));
         }
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));
     };
@@ -401,11 +445,19 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     const int a_elem = half * TC + wco * 32 + l31;
     const int b_elem = NGR * GI + half * TC + wci * 32 + l31;
 
+#ifdef WG6_PROF
+    unsigned long long pc_mult = 0, pc_head = 0, pc_bar = 0;
+    const unsigned long long pstart = __builtin_readcyclecounter();
+    int nstep_done = 0;
+#endif
     float rg[17], rx[8], ng[17], nx[8];
     for (int t = t_begin; t < t_end;) {
         const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
         const int n = min(p.H - ya, t_end - t), yb = ya + n;
         t += n;
+#ifdef WG6_PROF
+        const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
         // ---- head of a sweep: g rows 2 ya .. 2 ya + 3 into ring slots 0..3, x row ya into buffer ya & 1, registers of the first step
         {
             float g0[17], g1[17];
@@ -424,8 +476,14 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
             for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(rx[i]));
         }
         w6g_barrier();
+#ifdef WG6_PROF
+        pc_head += __builtin_readcyclecounter() - th0;
+#endif
         int s0 = 0;                                           // ring slot of g row 2 y
         for (int y = ya; y < yb; ++y) {
+#ifdef WG6_PROF
+            const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
             load_g(ng, bb, cx, 2 * y + 5 + rsel);             // registers of the step after next
             load_x(nx, bb, cx, y + 2);
             int wslot = s0 + 3 + rsel; wslot -= wslot >= NGR ? NGR : 0;
@@ -456,14 +514,30 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#ifdef WG6_PROF
+            const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (int i = 0; i < 17; ++i) rg[i] = ng[i];
 #pragma unroll
             for (int i = 0; i < 8; ++i) rx[i] = nx[i];
             s0 += 2; s0 -= s0 >= NGR ? NGR : 0;
             w6g_barrier();
+#ifdef WG6_PROF
+            { const unsigned long long tm2 = __builtin_readcyclecounter(); pc_mult += tm1 - tm0; pc_bar += tm2 - tm1; ++nstep_done; }
+#endif
         }
     }
+#ifdef WG6_PROF
+    {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lane == 0 && lin < 2048) {
+            unsigned long long* d = te_wgrad6_prof_buf + ((size_t)lin * 4 + wid) * 4;
+            d[0] = pc_mult; d[1] = pc_head; d[2] = pc_bar;
+            d[3] = ((unsigned long long)nstep_done << 40) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFull);
+        }
+    }
+#endif
 
     float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
     const int ci = ci0 + wci * 32 + l31;
