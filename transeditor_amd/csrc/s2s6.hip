@@ -178,7 +178,6 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
                 res[i][c][0] = h;
                 fe = __builtin_bit_cast(float, h << 16);
                 fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[i][c][0]));
             } else if (j == 1) {
                 te -= fe; to -= fo;
             } else if (j == 2) {
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
                 res[i][c][1] = m;
                 fe = __builtin_bit_cast(float, m << 16);
                 fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[i][c][1]));
             } else {
                 te -= fe; to -= fo;
                 const f32x2 t = {te, to};

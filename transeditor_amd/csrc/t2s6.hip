@@ -152,7 +152,6 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
                 res[c][0] = h;
                 fe = __builtin_bit_cast(float, h << 16);
                 fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[c][0]));
             } else if (j == 1) {
                 te -= fe; to -= fo;
             } else if (j == 2) {
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
                 res[c][1] = m;
                 fe = __builtin_bit_cast(float, m << 16);
                 fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[c][1]));
             } else {
                 te -= fe; to -= fo;
                 const f32x2 t = {te, to};

@@ -355,7 +355,10 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const int x0 = tx * TW, y0 = ty * TH, yh = y0 + PH * grp;
     const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
     const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
-    const bool edge = (x0 == 0) || (x0 + TW == p.W) || (y0 == 0) || (y0 + TH == p.H);      // block-uniform
+    // block-uniform edge flags: interior tiles skip the patches of arith() by scalar branches (an empty asm statement inside each
+    // branch keeps the compiler from turning them back into 96 selects per phase that every tile pays: a vector-ALU instruction in
+    // the MFMA stream costs ~4.5 cycles, profiles/experiments/r05_wgrad6.log)
+    const bool has_left = x0 == 0, has_right = x0 + TW == p.W, has_rowout = (yh == 0) || (yh + PH == p.H);
 
     f32x16 acc[4];
 #pragma unroll
@@ -432,10 +435,17 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 f32x4 v = rin[k][h2];
-                if (edge) {
-                    const int f = e_flag[k];
+                const int f = e_flag[k];
+                if (has_left) {
+                    asm volatile("" ::: "memory");
                     if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }        // loaded from column 0: element 0 is column -1
+                }
+                if (has_right) {
+                    asm volatile("" ::: "memory");
                     if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }        // loaded one column early: element 3 is column W
+                }
+                if (has_rowout) {
+                    asm volatile("" ::: "memory");
                     if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                 }
                 rin[k][h2] = ISC ? v * rsc[h2] : v;
@@ -453,7 +463,6 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
                 res[i][c][0] = h;
                 fe = __builtin_bit_cast(float, h << 16);
                 fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[i][c][0]));
             } else if (j == 1) {
                 te -= fe; to -= fo;
             } else if (j == 2) {
@@ -462,7 +471,6 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
                 res[i][c][1] = m;
                 fe = __builtin_bit_cast(float, m << 16);
                 fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
-                asm volatile("" : "+v"(res[i][c][1]));
             } else {
                 te -= fe; to -= fo;
                 const f32x2 t = {te, to};
