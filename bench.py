@@ -56,7 +56,10 @@ def _arithmetic_note():
         return ('fp32 in, fp32 out, fp32 accumulation everywhere.  The 3x3 stride-1 convolutions with K % 32 == 0, M % 64 == 0 form their '
                 'products on the bf16 matrix pipe from a three-piece split of every fp32 operand (x = h + m + l, 24 mantissa bits; six '
                 'exact piece products per multiply, the dropped ones below 2^-24): fp32-equivalent - measured deviation from fp64 BELOW '
-                "the fp32-MFMA Winograd kernel's at every tested shape (tests/test_gpu_winograd.py, profiles/r04_pytest_gpu.log).  "
+                "the fp32-MFMA Winograd kernel's at every tested shape (tests/test_gpu_winograd.py, profiles/r04_pytest_gpu.log).  Round 5: "
+                'the strided / transposed 3x3 convolutions (csrc/s2s6.hip, t2s6.hip) and the weight gradients of the 3x3 and transposed '
+                'kinds (csrc/wgrad6.hip; Co % 64 == 0, Ci % 64 == 0) take the same split form - tests/test_gpu_s2s6.py, test_gpu_t2s6.py, '
+                "test_gpu_wgrad6.py hold them to the fp32 kernels' 5e-6 bar against fp64.  "
                 'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere (same-box A/B of this line, round 4: 115.9 against 101.8 '
                 'img/s, profiles/r04_bench_quick_split_bf16_{on,off}.json).')
     return 'fp32 matrix / vector instructions everywhere (TE_SPLIT_BF16=0)'
@@ -207,8 +210,9 @@ class KernelTimer:
                 'peaks': {'bf16_mfma_dense': PEAK_BF16_TFLOPS, 'fp32_mfma': PEAK_FP32_TFLOPS},
                 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
                 'kernel': ('wino6p_kernel' if _w6_form() == 1 else 'wino6_kernel') +
-                          ' (v_mfma_f32_32x32x16_bf16, three-piece split) / wino3x3_kernel / conv_mfma_kernel / '
-                          'wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2), all 3x3 kinds',
+                          ' / s2s6_kernel / t2s6_kernel / wgrad6_kernel / wgrad6t_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / '
+                          'wino3x3_kernel / conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2) where the split kernels do '
+                          'not apply; all 3x3 kinds',
                 'dominant_kernel': dominant,
                 'executed_tflops': executed, 'executed_bf16_tflops': executed16, 'executed_frac': ex_frac,
                 'achieved_algorithmic': ach, 'algorithmic_vs_fp32_peak': ach / PEAK_FP32_TFLOPS,
@@ -219,8 +223,12 @@ class KernelTimer:
                                  'pipe (csrc/wino6.hip: every fp32 operand split into three bf16 pieces, six exact piece products '
                                  'accumulated in fp32 - fp32-equivalent results, deviation from fp64 not larger than the fp32 MFMA '
                                  "chain's, tests/test_gpu_winograd.py): executed_bf16_tflops = 4 x their algorithmic FLOPs, priced "
-                                 'against the 2516 TFLOP/s dense bf16 peak.  frac prices the MFMA work actually ISSUED on the pipe it '
-                                 'was issued on',
+                                 'against the 2516 TFLOP/s dense bf16 peak (the strided / transposed kinds and the transposed weight '
+                                 'gradient, which have no Winograd form: 6 x; the pair-form 3x3 weight gradient of csrc/wgrad6.hip: 4 x).  '
+                                 'frac prices the MFMA work actually ISSUED on the pipe it was issued on - moving a launch from the fp32 '
+                                 'pipe (peak 157.3) to the bf16 pipe (peak 2516 for 4 - 6 x the FLOPs) makes it faster AND lowers frac: '
+                                 'under dense bf16 MFMA work the part is power-limited at ~1 000 - 1 150 TFLOP/s executed (clock 1.45 - '
+                                 '1.75 GHz), profiles/experiments/r05_w6p_phase_profile.log',
                 'kernel_time_share': share,
                 'algorithmic_gflop_per_step': gflop / steps,
                 'whole_step_tflops': gflop / 1e3 / wall_s if wall_s else None,
@@ -242,11 +250,11 @@ PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE 
               ('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'))
 PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6', 'conv3x3_fp32_winograd_kernel_same_shape': 'wino3x3_kernel',
                'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
-               'wgrad3x3_128x128_at256_b16': 'wgrad_mfma_kernel<0',
+               'wgrad3x3_128x128_at256_b16': 'wgrad6_kernel', 'wgrad3x3_fp32_kernel_same_shape': 'wgrad_mfma_kernel<0',
                'convT2_256to128_at128_b16': 't2s6_kernel', 'convS2_128to256_at128_b16': 's2s6_kernel',
                'convT2_fp32_kernel_same_shape': 'conv_mfma_kernel<1, 0, true, false, 2, true', 'convS2_fp32_kernel_same_shape': 'conv_mfma_kernel<2',
                'convT2_last_row_and_column_fp32_regions': 'conv_mfma_kernel<1, 0, true, false, 2, false',
-               'wgradT2_256x128_at128_b16': 'wgrad_mfma_kernel<1'}
+               'wgradT2_256x128_at128_b16': 'wgrad6t_kernel', 'wgradT2_fp32_kernel_same_shape': 'wgrad_mfma_kernel<1'}
 
 
 def live_counters(timeout_s=150):

@@ -20,7 +20,7 @@ rm -rf gpurun_out/pmc
 bash tools/pmc_round.sh > gpurun_out/${TAG}_pmc_round.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc gpurun_out/${TAG} > gpurun_out/${TAG}_pmc_summary_stdout.txt 2>&1
 rm -f gpurun_out/pmc/*.db gpurun_out/pmc/*.csv
-( timeout 120 python tools/wino6_ab.py; timeout 120 python tools/s2s6_check.py; timeout 120 python tools/t2s6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_split_kernels_check.log
+( timeout 120 python tools/wino6_ab.py; timeout 120 python tools/s2s6_check.py; timeout 120 python tools/t2s6_check.py; timeout 200 python tools/wgrad6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_split_kernels_check.log
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/${TAG}_bench_n1.json").read().strip().splitlines()[-1])

@@ -30,7 +30,12 @@ def main():
         for _ in range(REP):
             _lib.conv(x, wpd, _lib.CONV_3X3, 128, 256, 256, isc, osc, bias, 3)        # the direct kernel at the same shape (small layers run it)
     for _ in range(REP):
-        sl = _lib.wgrad_slabs(y, x, _lib.CONV_3X3, 256, 256)                           # wgrad 3x3
+        sl = _lib.wgrad_slabs(y, x, _lib.CONV_3X3, 256, 256)                           # wgrad 3x3 (split-bf16 kernel where the switch is on)
+    if _lib.wgrad_split():
+        _lib.wgrad_split(0)
+        for _ in range(REP):
+            _lib.wgrad_slabs(y, x, _lib.CONV_3X3, 256, 256)                            # the fp32 pair-form kernel at the same shape
+        _lib.wgrad_split(1)
     for _ in range(REP):
         _lib.wgrad_reduce(sl, w.reshape(128, 128, 9), 1.0, isc, osc, True, True, True)
     xl = torch.randn(B, 256, 128, 128, device=DEV)
@@ -55,6 +60,11 @@ def main():
             _lib.conv(t, wps32, _lib.CONV_S2, 256, 128, 128, osc, iscu)
     for _ in range(REP):
         _lib.wgrad_slabs(t, xl, _lib.CONV_T2, 128, 128)                                # wgrad T2
+    if _lib.wgrad_split():
+        _lib.wgrad_split(0)
+        for _ in range(REP):
+            _lib.wgrad_slabs(t, xl, _lib.CONV_T2, 128, 128)                            # the fp32 kernel at the same shape
+        _lib.wgrad_split(1)
     k = torch.tensor([1., 3., 3., 1.], device=DEV)
     k = torch.outer(k, k) / 16
     for _ in range(REP):

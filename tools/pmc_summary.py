@@ -16,6 +16,8 @@ ALG = {
     't2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
+    'wgrad6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # split-bf16 weight gradient (round 5)
+    'wgrad6t_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'conv_mfma_kernel<1, 0, true, false, 2, true': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
