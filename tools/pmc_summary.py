@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
+KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 'wgrad6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
 # algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
 ALG = {
     'wino6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),       # algorithmic (direct-form) FLOPs
