@@ -60,8 +60,8 @@ def _arithmetic_note():
                 'the strided / transposed 3x3 convolutions (csrc/s2s6.hip, t2s6.hip) and the weight gradients of the 3x3 and transposed '
                 'kinds (csrc/wgrad6.hip; Co % 64 == 0, Ci % 64 == 0) take the same split form - tests/test_gpu_s2s6.py, test_gpu_t2s6.py, '
                 "test_gpu_wgrad6.py hold them to the fp32 kernels' 5e-6 bar against fp64.  "
-                'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere (same-box A/B of this line, round 4: 115.9 against 101.8 '
-                'img/s, profiles/r04_bench_quick_split_bf16_{on,off}.json).')
+                'TE_SPLIT_BF16=0 runs the fp32 matrix instructions everywhere (same-box A/B of this line, round 5: 137.3 against 103.8 '
+                'img/s, profiles/r05_bench_quick_split_bf16_{on,off}.json).')
     return 'fp32 matrix / vector instructions everywhere (TE_SPLIT_BF16=0)'
 
 
