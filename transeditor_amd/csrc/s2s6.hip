@@ -55,6 +55,10 @@ __device__ unsigned long long te_s2s6_prof_buf[2048 * 8 * 8];
 #define S2_ACC(i, a, b)
 #endif
 
+#ifndef DMA_PRIO
+#define DMA_PRIO 0         // experiment: the staging wave raises its priority while it issues the weight DMA (wino6.hip)
+#endif
+
 struct S2Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; const float* res;
     const float* mref; float mgain; int act;
@@ -289,7 +293,9 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
             // writes are unconditional: in group 1's first phase they repeat what the prologue wrote, in group 0's last phase they
             // put stale results in a tile nobody reads any more.
 #ifndef ST_NO_DMA
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
             if (work && grp == 1) issue_u(1, cs);
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #ifndef ST_NO_DSW
@@ -300,7 +306,12 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
             s2_barrier();
             S2_T(tb);
 #ifndef ST_NO_DMA
-            if (work && grp == 0) { issue_u(0, cs); s2_wait_vm(); }
+            if (work && grp == 0) {
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
+                issue_u(0, cs);
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                s2_wait_vm();
+            }
 #endif
             S2_T(tc);
             S2_ACC(3, t0, ta); S2_ACC(4, ta, tb); S2_ACC(5, tb, tc);

@@ -50,6 +50,10 @@ __device__ unsigned long long te_t2s6_prof_buf[2048 * 8 * 8];
 #define T2_ACC(i, a, b)
 #endif
 
+#ifndef DMA_PRIO
+#define DMA_PRIO 0         // experiment: the staging wave raises its priority while it issues the weight DMA (wino6.hip)
+#endif
+
 struct T2Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; int act;
     int B, K, M, H, W, Ho, Wo, ntiles, mblocks, tiles_x, tiles_y, nt8;
@@ -252,7 +256,9 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
             // group 1 renews weight half b in front of the mid-phase barrier: DMA first, the LDS writes of this half tile in its shadow,
             // then the wait for the DMA; group 0 renews half a behind the barrier.  The LDS writes are unconditional (s2s6.hip).
 #ifndef ST_NO_DMA
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
             if (work && grp == 1) issue_u(1, cs);
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #ifndef ST_NO_DSW
@@ -263,7 +269,12 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
             t2_barrier();
             T2_T(tb);
 #ifndef ST_NO_DMA
-            if (work && grp == 0) { issue_u(0, cs); t2_wait_vm(); }
+            if (work && grp == 0) {
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
+                issue_u(0, cs);
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                t2_wait_vm();
+            }
 #endif
             T2_T(tc);
             T2_ACC(3, t0, ta); T2_ACC(4, ta, tb); T2_ACC(5, tb, tc);

@@ -328,6 +328,9 @@ __device__ unsigned long long te_w6p_prof_buf[2048 * 8 * 8];
 #ifndef W6P_SLOT0
 #define W6P_SLOT0 21         // MFMA slot behind which the staging arithmetic starts (72 slots, the program has 51): the fetch it
 #endif                       // consumes is issued half a phase earlier by group 1
+#ifndef DMA_PRIO
+#define DMA_PRIO 0         // experiment: the staging wave raises its priority while it issues the weight DMA
+#endif
 #ifndef W6P_PRIO
 #define W6P_PRIO 1           // 1: a wave raises its priority while it multiplies (+1 - 1.5 % over 0); 3: static priority for group 1 (-3 %)
 #endif
@@ -573,7 +576,9 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
             // this half tile in its shadow, then the wait for the DMA; group 0 renews Ua behind the barrier.  (The fetch of the next
             // stage is not issued here any more: see fetch_item.)  The LDS writes are unconditional: in group 1's first phase they
             // repeat what the prologue wrote, in group 0's last phase they put stale results in a tile nobody reads any more.
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
             if (grp == 1 && work) issue_u(1, cs);
+            if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef W6_SKIP_COMMIT
             write_res();
@@ -582,7 +587,12 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
             W6P_T(ta);
             w6p_barrier();
             W6P_T(tb);
-            if (grp == 0 && work) { issue_u(0, cs); w6p_wait_vm(); }
+            if (grp == 0 && work) {
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
+                issue_u(0, cs);
+                if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                w6p_wait_vm();
+            }
             W6P_T(tc);
             W6P_ACC(3, t0, ta); W6P_ACC(4, ta, tb); W6P_ACC(5, tb, tc);
         }
