@@ -67,6 +67,10 @@ def _arithmetic_note():
 
 
 
+ARITHMETIC_SHORT = ('fp32 tensors + fp32 accumulation; 3x3 products on the bf16 MFMA pipe from an exact 3-piece split of each fp32 '
+                    'operand (fp32-equivalent, <= fp32-MFMA error vs fp64); TE_SPLIT_BF16=0 = fp32 MFMA everywhere')
+
+
 def _arithmetic_switches():
     """what `dtype: "f32"` stands on in this run: fp32 tensors and accumulation everywhere; which launches form their products on the
     bf16 pipe (three-piece split, fp32-equivalent) and in which kernel form"""
@@ -75,6 +79,7 @@ def _arithmetic_switches():
     return {'split_bf16': bool(modconv.USE_WINOGRAD and modconv.USE_SPLIT_BF16),
             'split_bf16_strided': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_S2), 'split_bf16_transposed': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_T2),
             'split_bf16_weight_gradient_3x3': bool(_lib.wgrad_split()),
+            'arithmetic_short': ARITHMETIC_SHORT if modconv.USE_SPLIT_BF16 else 'fp32 MFMA / vector instructions everywhere',
             'split_bf16_kernel_form': {1: 'ping-pong (wino6p_kernel)', 0: 'block-phase (wino6_kernel)'}.get(_w6_form(), None)}
 
 
@@ -204,7 +209,8 @@ class KernelTimer:
                         'launches': dom['launches'], 'ms_per_step': dom['total_ms'] / steps,
                         'share_of_step': dom['total_ms'] * 1e-3 / wall_s if wall_s else None,
                         'achieved_algorithmic': dom['tflops'], 'achieved': dom['executed_bf16_tflops'], 'peak': PEAK_BF16_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': dom['executed_bf16_tflops'] / PEAK_BF16_TFLOPS}
+                        'unit': 'TFLOP/s', 'frac': dom['executed_bf16_tflops'] / PEAK_BF16_TFLOPS,
+                        'executed_factor': dom['executed_bf16_tflops'] / dom['tflops'] if dom['tflops'] else None}
         return {'bound': 'mfma', 'achieved': ex_frac * PEAK_BF16_TFLOPS, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex_frac,
                 'achieved_unit_note': 'bf16-pipe-equivalent executed TFLOP/s = executed_bf16_tflops + executed_tflops x (2516 / 157.3)',
                 'peaks': {'bf16_mfma_dense': PEAK_BF16_TFLOPS, 'fp32_mfma': PEAK_FP32_TFLOPS},
@@ -492,6 +498,8 @@ def cpu_baseline_train(size, config_batch=16):
                       f', once each, after a warm-up pass at batch 2 (D {t["d2"]:.1f} s, G {t["g2"]:.1f} s); the lazy regularisers at a reduced '
                       f'batch, scaled per image: R1 on 2 images {t["r1"]:.1f} s -> x{BC // 2}, path length on 1 image {t["path"]:.1f} s -> '
                       f'x{BC // 2}; Adam included; iteration = D + G + R1/16 + path/4 = {it:.1f} s',
+            'sample_short': f'oracle: one FFHQ-{size} G+D iteration, D+G once at batch {BC} after a batch-2 warm-up; R1 (2 img) and '
+                            f'path (1 img) scaled per image; {it:.0f} s/iteration',
             'batch': BC, 'seconds': {k: round(v, 3) for k, v in t.items()},
             'batch_scaling': {'generator_fwd_s_per_image_batch2': f2, 'generator_fwd_s_per_image_batch16': f16,
                               'iteration_images_per_sec_from_the_batch2_pass': 2 / (t['d2'] + t['g2'] + t['r1'] / 16 + t['path'] / 4),
@@ -625,7 +633,10 @@ def run_sampling(args, size, B, dev, base):
                          'cache_plus_hipgraph_img_s': B * args.steps / t_graph,
                          'ms_per_batch': {'training_path': 1e3 * t_plain / args.steps, 'cache': 1e3 * t_cache / args.steps,
                                           'graph': 1e3 * t_graph / args.steps}})
-    print(json.dumps(out), flush=True)
+    out['detail'] = write_detail(out)
+    line = json.loads(compact_line(out))
+    line['sampling'] = {k: _num(v) for k, v in out['sampling'].items() if not isinstance(v, dict)}
+    print(json.dumps(line, allow_nan=False, separators=(',', ':')), flush=True)
 
 
 class SubstepClock:
@@ -723,7 +734,7 @@ class Watchdog:
         msg = f'{what} did not complete within {seconds:.0f} s on rank {self.rank}'
         print(f'bench.py watchdog: {msg}', file=sys.stderr, flush=True)
         if self.rank == 0:
-            print(json.dumps(dict(self.base, value=None, ms_per_step=None, comm=dict(self.info, error=msg))), flush=True)
+            print(compact_line(dict(self.base, value=None, ms_per_step=None, comm=dict(self.info, error=msg))), flush=True)
         os._exit(3)
 
 
@@ -779,7 +790,7 @@ def comm_preflight(args, backend, world, rank, local_rank, dev):
         msg = f'{type(e).__name__}: {e}'
         print(f'bench.py: communication preflight failed on rank {rank}: {msg}', file=sys.stderr, flush=True)
         if rank == 0:
-            print(json.dumps(dict(base, value=None, ms_per_step=None, comm=dict(info, error=msg[:2000]))), flush=True)
+            print(compact_line(dict(base, value=None, ms_per_step=None, comm=dict(info, error=msg[:2000]))), flush=True)
         os._exit(3)
     return info, dog
 
@@ -958,9 +969,144 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+LINE_TARGET, LINE_LIMIT = 4096, 8192      # bytes of the ONE stdout line (the round-5 line was 24.9 KB and the driver's parser gave up)
+
+
+def _num(v, digits=5):
+    """a JSON-safe number: floats rounded to `digits` significant digits, NaN / +-Inf -> None"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        f = float(v)
+    except (TypeError, ValueError):
+        return None
+    if not math.isfinite(f):
+        return None
+    if f == 0.0:
+        return 0.0
+    return round(f, digits - 1 - int(math.floor(math.log10(abs(f)))))
+
+
+def _pick(d, keys):
+    return {k: _num(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_roofline(roof):
+    """the contract's roofline object for the DOMINANT kernel (the split-bf16 Winograd kernel: executed bf16-pipe FLOPs / launch time
+    against the dense bf16 MFMA peak), numbers only; `frac_all_launches` = the composite over every MFMA convolution launch"""
+    if not roof:
+        return None
+    dom = roof.get('dominant_kernel')
+    r = {'bound': roof.get('bound', 'mfma'), 'unit': 'TFLOP/s'}
+    if dom:
+        r.update(kernel=dom['kernel'], achieved=_num(dom['achieved']), peak=_num(dom['peak']), frac=_num(dom['frac']),
+                 achieved_algorithmic=_num(dom['achieved_algorithmic']), executed_per_algorithmic_flop=_num(dom.get('executed_factor')),
+                 launches=dom['launches'], ms_per_step=_num(dom['ms_per_step']), share_of_step=_num(dom['share_of_step']))
+    else:                                                            # (fp32 instructions everywhere: TE_SPLIT_BF16=0)
+        r.update(kernel='all 3x3 MFMA launches', achieved=_num(roof.get('achieved')), peak=_num(roof.get('peak')), frac=_num(roof.get('frac')),
+                 achieved_algorithmic=_num(roof.get('achieved_algorithmic')))
+    r.update(frac_all_launches=_num(roof.get('frac')), achieved_algorithmic_all_launches=_num(roof.get('achieved_algorithmic')),
+             mfma_time_share_of_step=_num(roof.get('kernel_time_share')), algorithmic_gflop_per_step=_num(roof.get('algorithmic_gflop_per_step')),
+             whole_step_algorithmic_tflops=_num(roof.get('whole_step_tflops')),
+             traffic=_num(roof.get('traffic'), 6), traffic_source=roof.get('traffic_source'))
+    top = (roof.get('counters') or {}).get('conv3x3_fwd_128to128_at256_b16')
+    if top:
+        r.update(traffic_over_algorithmic=_num(top.get('traffic_over_algorithmic')), traffic_algorithmic=_num(top.get('algorithmic_bytes'), 6))
+    r.update(mfma_util_pct=_num(roof.get('mfma_util_pct')), mhz=_num(roof.get('mhz')))
+    if roof.get('live_counters_error'):
+        r['counters_error'] = str(roof['live_counters_error'])[:120]
+    return {k: v for k, v in r.items() if v is not None}
+
+
+def compact_line(out):
+    """The ONE stdout line: the driver-contract keys, `config` (short workload string, switches as booleans), `roofline` (dominant
+    kernel, numbers only), `cpu_baseline`, `substeps`, `sub_benchmarks` (value + frac), `comm` (N > 1, numbers only).  Everything
+    else - per-kernel tables, counters, HBM-bound kernel list, notes - goes to bench_detail.json (write_detail).  Target <= 4 KB;
+    never above 8 KB: optional groups are dropped, in a fixed order, until it fits."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+    line = {k: _num(out.get(k), 7) for k in keep if k in out}
+    cfg = out.get('config') or {}
+    c = {'workload': str(cfg.get('workload', ''))[:300]}
+    for k in ('global_batch', 'parallelism', 'per_gpu_images_per_sec', 'split_bf16', 'split_bf16_strided', 'split_bf16_transposed',
+              'split_bf16_weight_gradient_3x3', 'split_bf16_narrow_channels'):
+        if k in cfg:
+            c[k] = _num(cfg[k])
+    if cfg.get('lazy_steps_in_window'):
+        c['lazy_steps_in_window'] = cfg['lazy_steps_in_window']
+    if 'arithmetic_short' in cfg:
+        c['arithmetic'] = str(cfg['arithmetic_short'])[:200]
+    line['config'] = c
+    roof = compact_roofline(out.get('roofline'))
+    if roof:
+        line['roofline'] = roof
+    cb = out.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = {**_pick(cb, ('value', 'unit', 'cores', 'kind')), 'sample': str(cb.get('sample_short') or cb.get('sample', ''))[:160],
+                                **_pick(cb, ('batch', 'cpu_model', 'host_threads')),
+                                'seconds': {k: _num(v, 4) for k, v in (cb.get('seconds') or {}).items()}}
+    ss = out.get('substeps')
+    if ss:
+        line['substeps'] = _pick(ss, ('d_ms', 'r1_ms', 'g_ms', 'path_ms', 'cadence_weighted_ms_per_iteration', 'cadence_weighted_images_per_sec_per_gpu'))
+    sub = out.get('sub_benchmarks')
+    if sub:
+        line['sub_benchmarks'] = {}
+        for name, v in sub.items():
+            rr = v.get('roofline') or {}
+            dom = rr.get('dominant_kernel') or {}
+            line['sub_benchmarks'][name] = {**_pick(v, ('value', 'unit', 'ms_per_step')), 'frac': _num(dom.get('frac', rr.get('frac'))),
+                                            'frac_all_launches': _num(rr.get('frac')),
+                                            'achieved_algorithmic_all_launches': _num(rr.get('achieved_algorithmic'))}
+    cm = out.get('comm')
+    if cm:
+        k = _pick(cm, ('backend', 'world_size', 'rccl_version', 'hip_version', 'preflight_allreduce_s', 'bytes_allreduced_per_iteration_per_gpu',
+                       'g_bytes_per_exchange', 'd_bytes_per_exchange', 'buckets_g', 'buckets_d', 'ms_per_iteration_with_exchange',
+                       'ms_per_iteration_without_exchange', 'exposed_comm_ms_per_iteration'))
+        iso = cm.get('isolated_allreduce_per_bucket_g') or []
+        if iso:
+            k['isolated_allreduce_g'] = {'buckets': len(iso), 'bytes': sum(b['bytes'] for b in iso), 'ms': _num(sum(b['ms'] for b in iso)),
+                                         'bus_GBps_largest': _num(max(iso, key=lambda b: b['bytes'])['bus_GBps'])}
+        if cm.get('grad_bit_identity'):
+            k['grads_identical_across_ranks'] = bool(cm['grad_bit_identity'].get('identical_across_ranks'))
+        if cm.get('error'):
+            k['error'] = str(cm['error'])[:300]
+        line['comm'] = k
+    if out.get('detail'):
+        line['detail'] = out['detail']
+    for drop in (None, ('sub_benchmarks',), ('substeps',), ('comm',), ('cpu_baseline', 'seconds'), ('config', 'lazy_steps_in_window')):
+        if drop is not None:
+            tgt = line
+            for k in drop[:-1]:
+                tgt = tgt.get(k, {})
+            tgt.pop(drop[-1], None)
+        text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+        if len(text) <= LINE_LIMIT:
+            break
+    assert len(text) <= LINE_LIMIT and '\n' not in text, len(text)
+    return text
+
+
+def write_detail(out):
+    """the full record (per-kernel tables, counters, notes) beside the line: gpurun_out/bench_detail.json (merged back from the GPU
+    box) or $TE_BENCH_DETAIL; returns the path written (relative to the repo root) or None.  Never raises."""
+    path = os.environ.get('TE_BENCH_DETAIL') or os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1, default=str)
+        return os.path.relpath(path, ROOT)
+    except Exception:
+        try:
+            path = f'/tmp/te_bench_detail.{os.getpid()}.json'
+            with open(path, 'w') as f:
+                json.dump(out, f, indent=1, default=str)
+            return path
+        except Exception:
+            return None
+
+
 def final_line(out, rank, world, dist_on):
     """rank 0's ONE JSON line, as the LAST thing any rank writes to stdout: whatever native libraries left in the C stdio
-    buffers of the ranks is flushed first, then a barrier, then the line"""
+    buffers of the ranks is flushed first, then a barrier, then the line (compact_line; the full record goes to write_detail)"""
     import ctypes
     sys.stdout.flush()
     try:
@@ -970,7 +1116,8 @@ def final_line(out, rank, world, dist_on):
     if dist_on and world > 1:
         torch.distributed.barrier()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out['detail'] = write_detail(out)
+        print(compact_line(out), flush=True)
 
 
 def _slim(roof):
