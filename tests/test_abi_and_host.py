@@ -417,7 +417,10 @@ def test_load_checkpoint_into_is_all_or_nothing():
         load_checkpoint_into({k: full[k] for k in ('g_ema', 'g', 'd')}, ema, g, d, go, do)   # neither a training nor a g_ema-only file
     assert torch.equal(ema.weight, before)                                  # nothing was loaded on the failed attempts
     gw = g.weight.clone()
-    load_checkpoint_into({'g_ema': src['d'].state_dict()}, ema, g, d, go, do)   # a g_ema-only file: the EMA generator alone
+    with pytest.raises(KeyError):                    # a g_ema-only file into a TRAINING restore: the reference's ckpt['g'] raises too (:487)
+        load_checkpoint_into({'g_ema': src['d'].state_dict()}, ema, g, d, go, do)
+    assert torch.equal(ema.weight, before)
+    assert load_checkpoint_into({'g_ema': src['d'].state_dict()}, ema, g, d, go, do, g_ema_only_ok=True) is None   # knowingly: EMA alone
     assert torch.equal(ema.weight, src['d'].weight) and torch.equal(g.weight, gw)
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter('always')

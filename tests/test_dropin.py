@@ -169,6 +169,36 @@ def test_legacy_ddp_outputs_restores_differentiation_between_wrapper_outputs():
             if a is not None:
                 assert torch.allclose(a, p.grad, rtol=0, atol=1e-6)
         assert got[-1] is None and got[-2] is None       # `unused`
+
+        # the switch is SCOPED: a static-graph wrapper, or one without find_unused_parameters, in the same process keeps
+        # torch's own sink - its first backward enqueues the delayed all-reduce from _DDPSink.backward
+        import torch.nn.parallel.distributed as ddp_mod
+        from transeditor_amd.utils.distributed import legacy_ddp_outputs_scope
+        seen = []
+        orig_apply = ddp_mod._te_original_sink.apply
+
+        net2 = torch.nn.Linear(4, 2)
+        static = DistributedDataParallel(net2, static_graph=True, broadcast_buffers=False)
+        ddp_mod._te_original_sink.apply = staticmethod(lambda *a: (seen.append(1), orig_apply(*a))[1])
+        try:
+            static(x).sum().backward()                    # first iteration of a static graph goes through the sink
+            assert seen, 'static-graph wrapper bypassed the original _DDPSink'
+            assert static._static_graph_delay_allreduce_enqueued
+            n = len(seen)
+            path_step()                                   # the reference-style wrapper: pass-through, original not called
+            assert len(seen) == n
+            wrapped._te_keep_ddp_sink = True              # per-instance opt-out
+            with pytest.raises(RuntimeError, match='not have been used in the graph'):
+                path_step()
+            wrapped._te_keep_ddp_sink = False
+        finally:
+            ddp_mod._te_original_sink.apply = orig_apply
+        legacy_ddp_outputs(False)
+        with legacy_ddp_outputs_scope() as scope:         # context-manager form: on inside, torch's behaviour back outside
+            assert scope.active
+            path_step()
+        with pytest.raises(RuntimeError, match='not have been used in the graph'):
+            path_step()
     finally:
         legacy_ddp_outputs(False)
         dist.destroy_process_group()

@@ -25,7 +25,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 ev = prof.key_averages(group_by_input_shape=True, group_by_stack_n=6)
 KERNEL = ('void ', '(anonymous', 'Cijk', 'Memcpy', 'Memset', '__amd')
 rows = [e for e in ev if e.self_device_time_total > 0 and not e.key.startswith(KERNEL) and 'evaluate_function' not in e.key]
-rows.sort(key=lambda e: -e.count)
+rows.sort(key=lambda e: -e.self_device_time_total if len(sys.argv) > 2 and sys.argv[2] == "time" else -e.count)
 print(f'---- framework ops that launch work, {N} iterations (count per iteration, self device us per iteration, op, shapes, frames)')
 tot_n = tot_t = 0
 for e in rows:

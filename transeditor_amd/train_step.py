@@ -73,10 +73,13 @@ def accumulate(model1, model2, decay=0.999):                                 # :
     MultiTensorEMA(model1, model2).update(decay)
 
 
-def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_optim=None, d_optim=None, device=None):
+def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_optim=None, d_optim=None, device=None, g_ema_only_ok=False):
     """The reference's restore (train_spatial_query.py:475-492; test_spatial_query.py:285 for a 'g_ema'-only file) on any set of
     modules / optimisers: `ckpt` is a path or a loaded dictionary in the layout :361-371 writes.  -> the start iteration parsed
-    from the file name ('790000.pt' -> 790000), or None."""
+    from the file name ('790000.pt' -> 790000), or None.
+    A TRAINING restore (all four training objects given) from a file that holds only 'g_ema' raises KeyError, as the reference's
+    `ckpt['g']` does (:487): resuming at iteration N with freshly initialised G, D and optimisers is never what was meant.
+    `g_ema_only_ok=True` accepts such a file knowingly: the EMA generator alone is loaded and the start iteration returned is None."""
     import os
     start = None
     if isinstance(ckpt, (str, bytes, os.PathLike)):
@@ -95,7 +98,11 @@ def load_checkpoint_into(ckpt, g_ema, generator=None, discriminator=None, g_opti
                              f'(got {given}, missing {missing_obj}); pass none of them to load g_ema only')
         missing_key = [k for k in training if k not in ckpt]
         if len(missing_key) == len(training):
-            given = []               # a 'g_ema'-only file (the published inference checkpoints, test_spatial_query.py:285): EMA generator alone
+            # a 'g_ema'-only file (the published inference checkpoints, test_spatial_query.py:285) handed to a training restore
+            if not g_ema_only_ok:
+                raise KeyError("load_checkpoint_into: training objects were passed but the checkpoint holds only 'g_ema' (no 'g', 'd', "
+                               "'g_optim', 'd_optim'): pass g_ema alone, or g_ema_only_ok=True to load the EMA generator and start from 0")
+            given, start = [], None
         elif missing_key:
             raise KeyError(f'load_checkpoint_into: the checkpoint holds {sorted(k for k in training if k in ckpt)} but not '
                            f'{missing_key}: neither a training checkpoint (train_spatial_query.py:361-371) nor a g_ema-only file')

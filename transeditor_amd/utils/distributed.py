@@ -311,17 +311,57 @@ def legacy_ddp_outputs(enable=True):
     replacing that node with a pass-through; `dropin/utils/distributed.py` calls it on import (TE_DROPIN_KEEP_DDP_SINK=1 keeps
     torch's behaviour).  The product's own loop (TrainStep + GradSync) does not use DistributedDataParallel and is unaffected.
     Returns True when the switch took effect."""
+    import inspect
     import torch.nn.parallel.distributed as ddp
     if not hasattr(ddp, '_DDPSink'):
         return False
     if not hasattr(ddp, '_te_original_sink'):
         ddp._te_original_sink = ddp._DDPSink
+    orig = ddp._te_original_sink
+    if not enable:
+        ddp._DDPSink = orig
+        return True
+    # Only the call convention this was written against: `_DDPSink.apply(weakref.ref(ddp_module), *outputs)` (torch >= 2.0).
+    # torch 1.9 - 1.13 call `apply(reducer, state_dict, *outputs)`: a pass-through would hand `state_dict` back as the first
+    # output, so refuse there and leave torch's behaviour in place.
+    try:
+        names = list(inspect.signature(orig.forward).parameters)
+    except (TypeError, ValueError):
+        names = []
+    if names != ['ctx', 'ddp_weakref', 'inputs']:
+        return False
 
-    class _PassThrough:
+    class _ScopedPassThrough:
+        """pass-through ONLY for the wrappers the reference builds - `find_unused_parameters=True`, no static graph (train_spatial_query.py:
+        494-509).  Every other wrapper in the process keeps torch's sink: a `static_graph=True` wrapper enqueues its delayed all-reduce
+        from `_DDPSink.backward` on the first iteration and would silently skip the gradient exchange without it.
+        What the pass-through gives up for the wrappers it does apply to: an output that does not reach the loss no longer sends an
+        undefined gradient to the reducer, so parameters reachable ONLY from such an output are not marked ready (torch 1.7 behaved
+        the same).  In the reference loop every output of G / D descends from the one graph that produces the image / the logit."""
         @staticmethod
         def apply(ddp_weakref, *inputs):
+            module = ddp_weakref() if callable(ddp_weakref) else None
+            if (module is None or getattr(module, 'static_graph', False) or not getattr(module, 'find_unused_parameters', False)
+                    or getattr(module, '_te_keep_ddp_sink', False)):
+                return orig.apply(ddp_weakref, *inputs)
             return inputs
 
-    ddp._DDPSink = _PassThrough if enable else ddp._te_original_sink
+    ddp._DDPSink = _ScopedPassThrough
     return True
 
+
+class legacy_ddp_outputs_scope:
+    """`with legacy_ddp_outputs_scope(): ...` - the same switch around a block (the reference loop), torch's behaviour restored on
+    exit; `.active` says whether it took effect."""
+
+    def __enter__(self):
+        import torch.nn.parallel.distributed as ddp
+        self._before = getattr(ddp, '_DDPSink', None)
+        self.active = legacy_ddp_outputs(True)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.parallel.distributed as ddp
+        if self._before is not None:
+            ddp._DDPSink = self._before
+        return False
