@@ -80,7 +80,7 @@ def _arithmetic_switches():
             'split_bf16_strided': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_S2), 'split_bf16_transposed': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_T2),
             'split_bf16_weight_gradient_3x3': bool(_lib.wgrad_split()),
             'arithmetic_short': ARITHMETIC_SHORT if modconv.USE_SPLIT_BF16 else 'fp32 MFMA / vector instructions everywhere',
-            'split_bf16_kernel_form': {1: 'ping-pong (wino6p_kernel)', 0: 'block-phase (wino6_kernel)'}.get(_w6_form(), None)}
+            'split_bf16_kernel_form': W6_KERNEL.get(_w6_form(), None)}
 
 
 def parse():
@@ -205,7 +205,7 @@ class KernelTimer:
         dom = ks.get('conv3x3_split_bf16')
         dominant = None
         if dom:
-            dominant = {'kernel': 'wino6p_kernel' if _w6_form() == 1 else 'wino6_kernel', 'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16)',
+            dominant = {'kernel': W6_KERNEL.get(_w6_form(), 'wino6_kernel'), 'pipe': 'bf16 MFMA (v_mfma_f32_32x32x16_bf16)',
                         'launches': dom['launches'], 'ms_per_step': dom['total_ms'] / steps,
                         'share_of_step': dom['total_ms'] * 1e-3 / wall_s if wall_s else None,
                         'achieved_algorithmic': dom['tflops'], 'achieved': dom['executed_bf16_tflops'], 'peak': PEAK_BF16_TFLOPS,
@@ -215,7 +215,7 @@ class KernelTimer:
                 'achieved_unit_note': 'bf16-pipe-equivalent executed TFLOP/s = executed_bf16_tflops + executed_tflops x (2516 / 157.3)',
                 'peaks': {'bf16_mfma_dense': PEAK_BF16_TFLOPS, 'fp32_mfma': PEAK_FP32_TFLOPS},
                 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
-                'kernel': ('wino6p_kernel' if _w6_form() == 1 else 'wino6_kernel') +
+                'kernel': W6_KERNEL.get(_w6_form(), 'wino6_kernel') +
                           ' / s2s6_kernel / t2s6_kernel / wgrad6_kernel / wgrad6t_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / '
                           'wino3x3_kernel / conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2) where the split kernels do '
                           'not apply; all 3x3 kinds',
@@ -242,6 +242,9 @@ class KernelTimer:
                 'whole_step_frac': ex_frac * share if share else None,
                 'whole_step_algorithmic_vs_fp32_peak': gflop / 1e3 / wall_s / PEAK_FP32_TFLOPS if wall_s else None,
                 'per_kernel': ks}
+
+
+W6_KERNEL = {2: 'wino6q_kernel (wino6p_kernel where M % 128 != 0)', 1: 'wino6p_kernel', 0: 'wino6_kernel'}
 
 
 def _w6_form():

@@ -6,7 +6,10 @@
  *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; the CALLER owns every
  *     buffer (the Python host allocates through the torch caching allocator);
  *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
- *     no synchronisation, no global mutable state; safe to call from several host threads;
+ *     no synchronisation; safe to call from several host threads.  No global mutable state takes part in any RESULT; the only
+ *     process-wide state are two debug / A-B switches that select between kernels with the same results (bit-identical for
+ *     te_conv_wino6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
+ *     written by the product's own code paths) and the per-thread last-error string;
  *   - return 0 on success, a negative TE_ERR_* for argument validation failures, or a positive
  *     hipError_t if the launch failed; nothing throws across the ABI.  te_last_error_string()
  *     describes the calling thread's most recent failure.
@@ -211,11 +214,16 @@ int te_conv_wino6_supported(int B, int K, int M, int H, int W);
 int te_conv_s2s6_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_T2S6 covers the problem (H, W = INPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
 int te_conv_t2s6_supported(int B, int K, int M, int H, int W);
-/* Kernel form of TE_CONV_3X3W6 (process-wide; returns the previous value; anything but 0 / 1 only queries):
- *   1 = ping-pong (round 5, default): the two waves of every SIMD work half a stage apart - one feeds the matrix pipe from its
+/* Kernel form of TE_CONV_3X3W6 (a DEBUG / A-B switch, process-wide - the one piece of mutable state behind this ABI besides
+ * te_wgrad_split_bf16; the results do not depend on it; returns the previous value; anything but 0 .. 3 only queries):
+ *   2 = two-image (round 6, default): as 1, but a block owns 128 output channels - every staged half tile is multiplied by two
+ *       64-channel weight images, so the style scale / B^T d / three-piece split of an input element is done once per 128 output
+ *       channels instead of once per 64; launches with M % 128 != 0, or whose grid would leave CUs without a block, run form 1
+ *       (3 = the two-image form wherever M % 128 == 0, whatever the grid: tests);
+ *   1 = ping-pong (round 5): the two waves of every SIMD work half a stage apart - one feeds the matrix pipe from its
  *       half tile while the other transforms / splits / writes the next half tile and renews half of the weight image;
  *   0 = block-phase (round 4): all eight waves multiply, barrier, all eight waves stage, barrier.
- * Both forms issue the same products in the same order per output element: results are bit-identical.  TE_W6_FORM in the
+ * All forms issue the same products in the same order per output element: results are bit-identical.  TE_W6_FORM in the
  * environment sets the initial value (A/B measurements). */
 int te_conv_wino6_form(int form);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,

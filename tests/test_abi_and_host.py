@@ -389,10 +389,12 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
     try:
         modconv.USE_SPLIT_BF16 = False
         assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_WFWD, _lib.CONV_3X3W)
+        assert _lib.wgrad_split() == 0               # ONE switch: the weight-gradient kernels follow the Python flag
         modconv.USE_WINOGRAD = False
         assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_FWD, _lib.CONV_3X3)
     finally:
         modconv.USE_SPLIT_BF16, modconv.USE_WINOGRAD = old
+    assert _lib.wgrad_split() == (1 if old[0] else 0)
 
 
 def test_load_checkpoint_into_is_all_or_nothing():

@@ -18,6 +18,9 @@ DEV = 'cuda'
 
 SHAPES = [(2, 64, 64, 8, 32), (3, 128, 64, 13, 64), (1, 64, 192, 40, 96), (4, 64, 64, 5, 32), (2, 128, 128, 32, 32), (1, 64, 64, 1, 32),
           (2, 64, 128, 2, 64), (1, 192, 64, 3, 32)]
+# round 6, the sample-pair form (Co == Ci == 32, even batch: two samples on the diagonal of one 64 x 64 block tile) - the 32-channel
+# layer of the FFHQ-1024 generator (reference channel table model_spatial_query.py:473-483)
+PAIR_SHAPES = [(2, 32, 32, 8, 32), (4, 32, 32, 13, 64), (6, 32, 32, 40, 96), (2, 32, 32, 1, 32), (8, 32, 32, 3, 32)]
 
 
 @pytest.fixture(autouse=True)
@@ -33,7 +36,7 @@ def _fp64_corr(g, x):
                         for b in range(B)]).reshape(B, Co, Ci, 9)
 
 
-@pytest.mark.parametrize('B,Co,Ci,H,W', SHAPES)
+@pytest.mark.parametrize('B,Co,Ci,H,W', SHAPES + PAIR_SHAPES)
 def test_split_bf16_weight_gradient_slabs_vs_fp64(B, Co, Ci, H, W):
     assert _lib.wgrad_split_ok(_lib.CONV_3X3, Co, Ci, H, W)
     g = synth.normal((B, Co, H, W), f'wg6.g.{Co}.{H}').to(DEV)
@@ -43,7 +46,10 @@ def test_split_bf16_weight_gradient_slabs_vs_fp64(B, Co, Ci, H, W):
     got = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
     _lib.wgrad_split(0)
     ref = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W)
-    assert got.shape == ref.shape                       # same slab count, same layout: the reducers do not know which kernel ran
+    if Co != 32:
+        assert got.shape == ref.shape                   # same slab count, same layout: the reducers do not know which kernel ran
+    else:                                               # (the pair form runs one block per sample PAIR: its plan may take more chunks)
+        assert got.shape[0] == ref.shape[0] and got.shape[2:] == ref.shape[2:]
     got, ref = got.sum(1), ref.sum(1)
     l2 = lambda a: float((a.double() - want).norm() / want.norm())
     print(f'split-bf16 weight gradient {Ci}->{Co} @{H}x{W} B{B}: max {rel_err(got, want):.2e} (fp32 kernel {rel_err(ref, want):.2e}), '
@@ -68,6 +74,47 @@ def test_split_bf16_weight_gradient_long_reduction_vs_fp32_kernel():
     assert e_split < 5e-6 and e_split < 2.5 * e_ref + 1e-7
 
 
+def test_split_bf16_weight_gradient_pair_form_long_reduction_and_odd_batch():
+    """the sample-pair form at the FFHQ-1024 layer's own size class (32 channels, 256 x 256 here, batch 4: thousands of steps per
+    accumulator, S > 1 chunks that end inside a column) against the fp32 kernel and fp64; an ODD batch cannot be paired and runs the
+    fp32 kernel: identical slabs whatever the switch says"""
+    B, C, H, W = 4, 32, 256, 256
+    g = synth.normal((B, C, H, W), 'wg6.pg').to(DEV)
+    x = synth.normal((B, C, H, W), 'wg6.px').to(DEV)
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W).sum(1)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W).sum(1)
+    want = _fp64_corr(g, x)
+    e_split, e_ref = rel_err(got, want), rel_err(ref, want)
+    print(f'pair form, long reduction: vs fp64 split {e_split:.2e}, fp32 kernel {e_ref:.2e}; split vs fp32 kernel {rel_err(got, ref):.2e}')
+    assert e_split < 5e-6 and e_split < 2.5 * e_ref + 1e-7
+    for b in range(B):                                   # every sample's slab is ITS correlation (no mix-up inside a pair)
+        assert rel_err(got[b], want[b]) < 5e-6
+    g3, x3 = g[:3, :, :16, :32].contiguous(), x[:3, :, :16, :32].contiguous()
+    _lib.wgrad_split(1)
+    a = _lib.wgrad_slabs(g3, x3, _lib.CONV_3X3, 16, 32)
+    _lib.wgrad_split(0)
+    b3 = _lib.wgrad_slabs(g3, x3, _lib.CONV_3X3, 16, 32)
+    assert torch.equal(a, b3)
+
+
+def test_split_bf16_weight_gradient_pair_form_reduced():
+    """the reducer's three gradients (dW, d style scale, d demodulation) on the pair form's slabs against the fp32 kernel's"""
+    B, C, H, W = 4, 32, 64, 64
+    g = synth.normal((B, C, H, W), 'wg6.qg').to(DEV)
+    x = synth.normal((B, C, H, W), 'wg6.qx').to(DEV)
+    w = (synth.normal((C, C, 3, 3), 'wg6.qw') / (3 * math.sqrt(C))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, C), 'wg6.qi')).to(DEV), (1 + 0.3 * synth.normal((B, C), 'wg6.qo')).to(DEV)
+    out = {}
+    for on in (0, 1):
+        _lib.wgrad_split(on)
+        out[on] = _lib.wgrad_reduce(_lib.wgrad_slabs(g, x, _lib.CONV_3X3, H, W), w, 0.7, isc, osc, True, True, True)
+    for a, b, name in zip(out[1], out[0], ('dW', 'd isc', 'd osc')):
+        print(f'reducer on pair-form slabs, {name}: vs fp32 slabs {rel_err(a, b):.2e}')
+        assert rel_err(a, b) < 5e-6
+
+
 def test_split_bf16_weight_gradient_grouped_and_reduced():
     """the grouped form (NB samples per slab, the discriminator's plain gradient) and the reducer's three gradients on the split slabs"""
     B, Co, Ci, H, W = 8, 128, 128, 32, 32
@@ -88,7 +135,9 @@ def test_split_bf16_weight_gradient_grouped_and_reduced():
         assert rel_err(a, b) < 5e-6
 
 
-T_SHAPES = [(2, 64, 64, 8, 16), (3, 128, 64, 13, 32), (1, 64, 192, 20, 48), (4, 64, 64, 5, 16), (1, 64, 64, 1, 16), (2, 128, 128, 32, 32)]
+T_SHAPES = [(2, 64, 64, 8, 16), (3, 128, 64, 13, 32), (1, 64, 192, 20, 48), (4, 64, 64, 5, 16), (1, 64, 64, 1, 16), (2, 128, 128, 32, 32),
+            # round 6, narrow sides: 32 valid channels in the last 64-channel block of a side (the 64 -> 32 up-sampling layer of FFHQ-1024)
+            (2, 32, 64, 8, 16), (3, 64, 32, 13, 32), (1, 96, 64, 20, 48), (2, 32, 96, 5, 16), (1, 96, 160, 6, 16)]
 
 
 @pytest.mark.parametrize('B,Co,Ci,H,W', T_SHAPES)
@@ -113,8 +162,8 @@ def test_split_bf16_weight_gradient_transposed_kind_vs_fp64(B, Co, Ci, H, W):
     assert l2(got) < 2.5 * l2(ref) + 1e-7
 
 
-def test_split_bf16_weight_gradient_transposed_kind_long_reduction():
-    B, Co, Ci, H, W = 2, 128, 128, 128, 128
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 128, 128, 128, 128), (2, 32, 64, 128, 128)])
+def test_split_bf16_weight_gradient_transposed_kind_long_reduction(B, Co, Ci, H, W):
     g = synth.normal((B, Co, 2 * H + 1, 2 * W + 1), 'wg6t.lg').to(DEV)
     x = synth.normal((B, Ci, H, W), 'wg6t.lx').to(DEV)
     _lib.wgrad_split(1)
@@ -142,10 +191,12 @@ def test_split_bf16_weight_gradient_range(scale):
 def test_split_bf16_weight_gradient_selection_and_switch():
     ok = _lib.wgrad_split_ok
     assert ok(_lib.CONV_3X3, 128, 128, 256, 256) and ok(_lib.CONV_3X3, 512, 64, 4, 32)
-    assert not ok(_lib.CONV_3X3, 96, 128, 32, 32) and not ok(_lib.CONV_3X3, 128, 32, 32, 32)      # whole 64-channel blocks only
+    assert not ok(_lib.CONV_3X3, 96, 128, 32, 32) and not ok(_lib.CONV_3X3, 128, 32, 32, 32)      # whole 64-channel blocks only ...
+    assert ok(_lib.CONV_3X3, 32, 32, 1024, 1024) and not ok(_lib.CONV_3X3, 32, 64, 32, 32)        # ... or the 32 x 32 sample-pair form
     assert not ok(_lib.CONV_3X3, 128, 128, 16, 16) and not ok(_lib.CONV_3X3, 128, 128, 32, 48)    # whole 32-column tiles only
     assert ok(_lib.CONV_T2, 128, 128, 32, 32) and ok(_lib.CONV_T2, 512, 512, 16, 16)
-    assert not ok(_lib.CONV_T2, 128, 128, 8, 8) and not ok(_lib.CONV_T2, 96, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
+    assert not ok(_lib.CONV_T2, 128, 128, 8, 8) and not ok(_lib.CONV_T2, 80, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
+    assert ok(_lib.CONV_T2, 32, 64, 512, 512) and ok(_lib.CONV_T2, 96, 128, 32, 32) and not ok(_lib.CONV_T2, 32, 32, 32, 32)   # narrow sides
     old = _lib.wgrad_split(0)
     assert _lib.wgrad_split() == 0 and _lib.wgrad_split(1) == 0 and _lib.wgrad_split() == 1
     _lib.wgrad_split(old)

@@ -255,13 +255,13 @@ def test_split_bf16_winograd_tiny_magnitudes_degrade_gracefully():
         assert e < bar
 
 
-@pytest.mark.parametrize('form', [0, 1])
-def test_split_bf16_winograd_non_finite_inputs_propagate_like_the_direct_kernel(form):
+@pytest.mark.parametrize('form,M', [(0, 64), (1, 64), (3, 128)])
+def test_split_bf16_winograd_non_finite_inputs_propagate_like_the_direct_kernel(form, M):
     """Inf / NaN in the input reach exactly the outputs whose 3x3 windows contain them - the set the direct fp32 kernel marks - and
     nothing else; every other output is unaffected (same value as without the planted element, 5e-6).  WHAT the marked outputs hold
     differs by design: the direct kernel gives w * inf = +-inf where the split kernel gives NaN (inf = h, inf - h = NaN is the
     second piece; and Winograd's t = d0 - d2 may cancel infinities) - a non-finite value either way, documented in te_hip.h."""
-    B, K, M, H, W = 2, 32, 64, 16, 64
+    B, K, H, W = 2, 32, 16, 64
     x = synth.normal((B, K, H, W), 'w6.nx').to(DEV)
     w = (synth.normal((M, K, 3, 3), 'w6.nw') / (3 * math.sqrt(K))).to(DEV)
     w = torch.where(w.abs() < 1e-3, torch.full_like(w, 1e-3), w)        # no exact zeros / tiny taps: w * inf is +-inf in the direct kernel
@@ -288,10 +288,13 @@ def test_split_bf16_winograd_non_finite_inputs_propagate_like_the_direct_kernel(
     assert rel_err(got[fin], clean[fin]) < 5e-6
 
 
-@pytest.mark.parametrize('B,K,M,H,W', W6_SHAPES + [(2, 160, 64, 8, 64), (1, 96, 64, 32, 32)])
+@pytest.mark.parametrize('B,K,M,H,W', W6_SHAPES + [(2, 160, 64, 8, 64), (1, 96, 64, 32, 32), (2, 32, 128, 8, 32), (3, 64, 256, 16, 64),
+                                             (1, 96, 128, 24, 32), (5, 32, 384, 8, 32), (2, 160, 128, 40, 96)])
 def test_split_bf16_kernel_forms_are_bit_identical(B, K, M, H, W):
-    """ping-pong (round 5, default) and block-phase (round 4) forms of TE_CONV_3X3W6 issue the same products in the same order per
-    output element: identical bits, with every epilogue stage, on single- and multi-tile images and 2 - 32 channel stages"""
+    """two-image (round 6, default where M % 128 == 0), ping-pong (round 5) and block-phase (round 4) forms of TE_CONV_3X3W6 issue the
+    same products in the same order per output element: identical bits, with every epilogue stage, on single- and multi-tile images,
+    2 - 32 channel stages, 1 - 3 blocks of 128 output channels (form 3 = the two-image kernel whatever the grid size; it runs
+    the ping-pong kernel where M % 128 != 0)"""
     x = synth.normal((B, K, H, W), f'w6.fx.{K}.{H}').to(DEV)
     w = (synth.normal((M, K, 3, 3), f'w6.fw.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
     isc, osc = (1 + 0.3 * synth.normal((B, K), 'w6.fi')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'w6.fo')).to(DEV)
@@ -301,7 +304,7 @@ def test_split_bf16_kernel_forms_are_bit_identical(B, K, M, H, W):
     out = {}
     old = _lib.wino6_form(-1)
     try:
-        for form in (0, 1):
+        for form in (0, 1, 3):
             _lib.wino6_form(form)
             out[form] = (_lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, isc, osc, bias, 3),
                          _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, None, None, bias, 4, res=res, mask_ref=mref, mask_gain=1.3),
@@ -309,5 +312,5 @@ def test_split_bf16_kernel_forms_are_bit_identical(B, K, M, H, W):
     finally:
         _lib.wino6_form(old)
     assert _lib.wino6_form(-1) == old
-    for a, b in zip(out[0], out[1]):
-        assert torch.equal(a, b)
+    for a, b, c in zip(out[0], out[1], out[3]):
+        assert torch.equal(a, b) and torch.equal(a, c)

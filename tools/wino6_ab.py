@@ -28,7 +28,7 @@ def rel2(a, b):
 
 def main():
     print('variant', os.environ.get('VARIANT', 'product'), flush=True)
-    small = [(40, 32, 64, 8, 32), (2, 32, 64, 8, 32), (3, 96, 192, 24, 32), (2, 64, 64, 16, 64), (1, 32, 128, 40, 96), (2, 160, 64, 8, 64), (1, 48 * 2, 64, 32, 32)]
+    small = [(2, 32, 128, 8, 32), (3, 64, 256, 16, 64), (1, 48 * 2, 128, 24, 32), (5, 32, 384, 8, 32), (40, 32, 64, 8, 32), (2, 32, 64, 8, 32), (3, 96, 192, 24, 32), (2, 64, 64, 16, 64), (1, 32, 128, 40, 96), (2, 160, 64, 8, 64), (1, 48 * 2, 64, 32, 32)]
     big = [(16, 128, 128, 256, 256), (16, 256, 256, 128, 128), (16, 512, 512, 64, 64), (16, 512, 512, 32, 32)]
     bad = 0
     only_big = bool(os.environ.get('ONLY_BIG'))      # tuning variants: timing at the four large shapes only
@@ -43,7 +43,7 @@ def main():
         u6 = _lib.conv_pack(w, _lib.PACK_W6FWD, 0.83)
         f6 = lambda: _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, isc, osc, bias, 3)
         out = {}
-        forms = (0, 1, 2) if os.environ.get('FORM2') else (0, 1)
+        forms = (0, 1, 3) if os.environ.get('FORM2') else (0, 1)
         for form in forms:
             _lib.wino6_form(form)
             out[form] = f6()
@@ -63,8 +63,8 @@ def main():
             _lib.wino6_form(form)
             t[form] = min(t.get(form, 1e9), timeit(f6, n=20))
         msg += f' | block-phase {t[0] * 1e3:8.1f} us {flops / t[0] / 1e9:6.1f} TF/s, ping-pong {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s'
-        if 2 in t:
-            msg += f', persistent {t[2] * 1e3:8.1f} us {flops / t[2] / 1e9:6.1f} TF/s'
+        if 3 in t:
+            msg += f', two-image {t[3] * 1e3:8.1f} us {flops / t[3] / 1e9:6.1f} TF/s'
         print(msg, flush=True)
     # epilogue stages (residual + mask, no activation / activation) and the data-gradient packing, small shapes, both forms
     for B, K, M, H, W in ([] if only_big else [(2, 64, 128, 16, 32), (1, 32, 64, 8, 96)]):
@@ -77,11 +77,11 @@ def main():
         for act in (0, 3):
             for r, m in ((res, None), (None, mref), (res, mref)):
                 o = {}
-                for form in (0, 1):
+                for form in ((0, 1, 3) if os.environ.get('FORM2') else (0, 1)):
                     _lib.wino6_form(form)
                     o[form] = _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, W, None, None, None, act, res=r, mask_ref=m, mask_gain=2 ** 0.5)
                 od = _lib.conv(x, ud, _lib.CONV_3X3, M, H, W, None, None, None, act, res=r, mask_ref=m, mask_gain=2 ** 0.5)
-                same = torch.equal(o[0], o[1])
+                same = all(torch.equal(o[0], v) for v in o.values())
                 bad += 0 if same else 1
                 print(f'epilogue B{B} {K}->{M} @{H}x{W} act {act} res {r is not None} mask {m is not None}: bit-identical {same}, '
                       f'vs direct kernel {rel2(o[1], od):.2e}', flush=True)
@@ -92,7 +92,7 @@ def main():
             _lib.wino6_form(form)
             got = _lib.conv(g, ug, _lib.CONV_3X3W6, K, H, W)
             print(f'dgrad form {form} B{B} {M}->{K} @{H}x{W}: {rel2(got, want):.2e}', flush=True)
-    _lib.wino6_form(1)
+    _lib.wino6_form(2)
     print('MISMATCHES', bad, flush=True)
 
 

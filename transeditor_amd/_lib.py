@@ -351,7 +351,8 @@ def t2s6_ok(B, K, M, H, W):
 
 
 def wino6_form(form=-1):
-    """kernel form of TE_CONV_3X3W6: 1 = ping-pong (default), 0 = block-phase; returns the previous value (-1: query only)"""
+    """kernel form of TE_CONV_3X3W6: 2 = two-image (default; M % 128 == 0, else ping-pong), 1 = ping-pong, 0 = block-phase (bit-identical
+    results); returns the previous value (-1: query only)"""
     return int(lib().te_conv_wino6_form(form))
 
 

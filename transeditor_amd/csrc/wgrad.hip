@@ -884,6 +884,9 @@ extern "C" int te_debug_wgrad_prof(void* host_dst, int64_t bytes) {
 }
 #endif
 
+extern "C" int te_wgrad_split_bf16(int on);
+extern "C" int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W);
+
 extern "C" int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W) {
     if (kind != TE_CONV_3X3 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return 0;
     const int TW = std::max(2, std::min(32, pow2ceil(W))), TH = std::max(1, std::min(pow2ceil(H), 64 / TW));
@@ -893,7 +896,9 @@ extern "C" int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W) {
 extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
-    const int64_t mn = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH) * (int64_t)B;
+    int64_t mn = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH) * (int64_t)B;
+    // the sample-pair form of csrc/wgrad6.hip (Co == Ci == 32) runs one block per PAIR of samples and chunk
+    if (te_wgrad_split_bf16(-1) == 1 && te_wgrad_split_supported(kind, Co, Ci, H, W) == 2 && B % 2 == 0) mn = B / 2;
     // blocks per CU the split aims at: the 8-wave 3x3 / T2 blocks own a CU (two 68 KB operand images), so ONE round of them
     // does the same work as two with half the slab bytes for the reducer (same-box A/B, round 3: +0.8 % / +1.2 % on the
     // kernels, half the te_wgrad_reduce traffic of the narrow layers); the light 1x1 blocks share a CU and want two

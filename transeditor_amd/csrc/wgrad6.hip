@@ -62,6 +62,12 @@ __device__ __forceinline__ void w6g_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ unsigned long long te_wgrad6_prof_buf[2048 * 4 * 4];
 #endif
 
+// PAIR (round 6; Co == Ci == 32, NB == 1, B even - the 32-channel 3x3 layer at 1024^2 of the FFHQ-1024 generator, reference channel table
+// model_spatial_query.py:473-483): the 64 lanes of a staging wave are the 32 channels of sample 2 k (lanes 0-31) and the 32 channels of
+// sample 2 k + 1 (lanes 32-63), so the block tile holds TWO 32 x 32 problems on its diagonal: wave (0, 0) accumulates sample 2 k, wave
+// (1, 1) sample 2 k + 1, the two off-diagonal waves (products across the two samples) only stage.  Half of the block's matrix pipes
+// idle, but every staged element is used and the launch leaves the fp32 pipe: 1 255 us -> see profiles/r06_*.
+template <bool PAIR>
 __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);
@@ -70,15 +76,18 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 32 x 32 tile
     const bool role = (wid >> 1) != 0;                        // staging: false = gradient rows (waves 0, 1), true = input rows (2, 3)
     const int kh = wid & 1;                                   //          k half = cells 16 kh .. 16 kh + 15 of the row segment; lane = channel
+    const bool active = !PAIR || wco == wci;                  // (wave-uniform) does this wave's tile belong to a problem?
 
-    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;
-    const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
+    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = PAIR ? 2 * bgrp : bgrp * p.NB;
+    const int co0 = PAIR ? 0 : blockIdx.y * TC, ci0 = PAIR ? 0 : blockIdx.z * TC;
     const size_t plane = (size_t)p.H * p.W;
     const unsigned g_sample = (unsigned)(p.Co * plane * 4), x_sample = (unsigned)(p.Ci * plane * 4);      // bytes (host-checked < 2 GiB per group)
-    const __amdgpu_buffer_rsrc_t rs = role ? make_rsrc(p.x + (size_t)b * p.Ci * plane, x_sample * (unsigned)p.NB)
-                                           : make_rsrc(p.g + (size_t)b * p.Co * plane, g_sample * (unsigned)p.NB);
+    const unsigned nb_span = PAIR ? 2u : (unsigned)p.NB;
+    const __amdgpu_buffer_rsrc_t rs = role ? make_rsrc(p.x + (size_t)b * p.Ci * plane, x_sample * nb_span)
+                                           : make_rsrc(p.g + (size_t)b * p.Co * plane, g_sample * nb_span);
     const unsigned my_sample = role ? x_sample : g_sample;
-    const unsigned chan_off = (unsigned)(((role ? ci0 : co0) + lane) * plane * 4);                         // bytes
+    const unsigned chan_off = PAIR ? (unsigned)(l31 * plane * 4) + (lane >> 5) * my_sample                 // channel l31 of sample b + (lane >> 5)
+                                   : (unsigned)(((role ? ci0 : co0) + lane) * plane * 4);                  // bytes
 
     f32x16 acc[12];                                           // [ky * 4 + component]
 #pragma unroll
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
                 for (int m = 0; m < 18; ++m) {
                     const int q = m / 3, ky = m % 3;
 #ifndef WG6_SKIP_MFMA
-                    acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[j & 1][ky][PB[q]], acc[ky * 4 + j], 0, 0, 0);
+                    if (active) acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[j & 1][ky][PB[q]], acc[ky * 4 + j], 0, 0, 0);
 #endif
                     if (j + 1 < 4 && m < 12) {                                            // operands of the next component: 12 reads
                         if (m < 3) rd_a(j + 1, m);
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
 #ifndef WG6_SKIP_MFMA
-                    acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[gi & 1][PB[q]], acc[ky * 4 + j], 0, 0, 0);
+                    if (active) acc[ky * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j & 1][PA[q]], bv[gi & 1][PB[q]], acc[ky * 4 + j], 0, 0, 0);
 #endif
                     if (gi + 1 < 12 && q < 3) {                                           // operands of the next group
                         rd_b(gi + 1, q);
@@ -307,11 +316,12 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
 #endif
 
     // ---- fold the twelve accumulators to the nine taps and write the slab tile: slab[b][s][co][ci][tap]
-    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
-    const int ci = ci0 + wci * 32 + l31;
+    if (!active) return;
+    float* sl = p.slabs + ((size_t)(PAIR ? 2 * bgrp + wco : bgrp) * p.S + s_chunk) * p.Co * p.Ci * 9;
+    const int ci = PAIR ? l31 : ci0 + wci * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = (PAIR ? 0 : co0 + wco * 32) + (r & 3) + 8 * (r >> 2) + 4 * half;
         float* dst = sl + ((size_t)co * p.Ci + ci) * 9;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -340,6 +350,10 @@ constexpr int GI = 3 * 3 * 2 * TC;            // elements of one g-row image: 1 
 constexpr int XI = 3 * 2 * TC;                // elements of one x-row image: 384 (6 KB)
 constexpr int NGR = 5;
 
+// NARROW (round 6): Co or Ci is an odd multiple of 32 (the 64 -> 32 up-sampling layer of the FFHQ-1024 generator): the last channel block
+// of that side has 32 valid channels.  Lanes past them read the last valid channel again (no access outside the tensor; their LDS
+// elements only feed wave tiles that are not computed), and the waves whose 32 x 32 tile lies in the padding skip MFMAs and stores.
+template <bool NARROW>
 __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);
@@ -356,7 +370,9 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     // global loads, no 64-bit vector arithmetic in the step
     const float* gblk = p.g + ((size_t)b * p.Co + co0) * gplane;             // channel block of the group's first sample
     const float* xblk = p.x + ((size_t)b * p.Ci + ci0) * xplane;
-    const unsigned g_lane = (unsigned)(lane * gplane * 4), x_lane = (unsigned)(lane * xplane * 4);       // bytes (host-checked < 2 GiB)
+    const int g_ch = NARROW ? min(lane, p.Co - co0 - 1) : lane, x_ch = NARROW ? min(lane, p.Ci - ci0 - 1) : lane;
+    const unsigned g_lane = (unsigned)(g_ch * gplane * 4), x_lane = (unsigned)(x_ch * xplane * 4);       // bytes (host-checked < 2 GiB)
+    const bool active = !NARROW || (co0 + wco * 32 < p.Co && ci0 + wci * 32 < p.Ci);                     // wave-uniform
 
     f32x16 acc[9];                                            // [ky * 3 + kx]
 #pragma unroll
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
 #pragma unroll
                 for (int qq = 0; qq < 6; ++qq) {
 #ifndef WG6_SKIP_MFMA
-                    acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tp & 1][PA[qq]], bx[PB[qq]], acc[tp], 0, 0, 0);
+                    if (active) acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tp & 1][PA[qq]], bx[PB[qq]], acc[tp], 0, 0, 0);
 #endif
                     if (tp + 1 < 9 && qq < 3) rd_a(tp + 1, qq);
 #ifndef WG6_SKIP_ARITH
@@ -540,6 +556,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     }
 #endif
 
+    if (!active) return;
     float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
     const int ci = ci0 + wci * 32 + l31;
 #pragma unroll
@@ -578,29 +595,55 @@ extern "C" int te_wgrad_split_bf16(int on) {
 }
 
 extern "C" int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W) {
-    if (!(Co > 0 && Ci > 0 && Co % TC == 0 && Ci % TC == 0 && H > 0)) return 0;
-    if (kind == TE_CONV_3X3) return (W >= 32 && W % 32 == 0) ? 1 : 0;
-    if (kind == TE_CONV_T2) return (W >= 16 && W % 16 == 0) ? 1 : 0;
+    if (!(Co > 0 && Ci > 0 && H > 0)) return 0;
+    if (kind == TE_CONV_3X3) {
+        if (!(W >= 32 && W % 32 == 0)) return 0;
+        if (Co % TC == 0 && Ci % TC == 0) return 1;
+        return (Co == 32 && Ci == 32) ? 2 : 0;              // 2: the sample-pair form (needs an even batch and per-sample slabs)
+    }
+    if (kind == TE_CONV_T2) {
+        if (!(W >= 16 && W % 16 == 0)) return 0;
+        return (Co % 32 == 0 && Ci % 32 == 0 && Co + Ci >= 96) ? 1 : 0;      // (32 x 32: a quarter of the tile - stays on the fp32 kernel)
+    }
     return 0;
 }
 
 // returns 1 when the launch was taken, 0 when the caller has to use the fp32 kernel, < 0 on error
 int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H, int W, int S, int NB, hipStream_t s) {
-    if (!g_wg6_on.load(std::memory_order_relaxed) || !te_wgrad_split_supported(kind, Co, Ci, H, W)) return 0;
+    const int sup = te_wgrad_split_supported(kind, Co, Ci, H, W);
+    if (!g_wg6_on.load(std::memory_order_relaxed) || !sup) return 0;
     if (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x)) & 15) != 0) return 0;
     Wg6Args a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB; a.tiles_x = W / 32;
-    dim3 grid((unsigned)(B / NB * S), (unsigned)(Co / TC), (unsigned)(Ci / TC));
+    dim3 grid((unsigned)(B / NB * S), (unsigned)te::cdiv(Co, TC), (unsigned)te::cdiv(Ci, TC));
     if (kind == TE_CONV_T2) {
         if (!g_wg6t_on.load(std::memory_order_relaxed)) return 0;
-        static std::atomic<uint64_t> attr_done_t{0};
-        te::allow_big_lds(attr_done_t, (const void*)wgrad6t_kernel, 160 * 1024);
-        wgrad6t_kernel<<<grid, WT, (size_t)(NGR * GI + 2 * XI) * 16, s>>>(a);
+        // 32-bit byte offsets inside a sample group: lane * plane * 4 over the 64 channels of a tile, for the (2H+1) x (2W+1) tensor and
+        // for the H x W one (the fp32 kernel takes the launch otherwise, as for the 3x3 kind below)
+        if ((int64_t)NB * std::max(Co, Ci) * (2 * (int64_t)H + 1) * (2 * (int64_t)W + 1) * 4 >= (int64_t)OOBW) return 0;
+        const size_t lds = (size_t)(NGR * GI + 2 * XI) * 16;
+        if (Co % TC == 0 && Ci % TC == 0) {
+            static std::atomic<uint64_t> attr_done_t{0};
+            te::allow_big_lds(attr_done_t, (const void*)wgrad6t_kernel<false>, 160 * 1024);
+            wgrad6t_kernel<false><<<grid, WT, lds, s>>>(a);
+        } else {
+            static std::atomic<uint64_t> attr_done_tn{0};
+            te::allow_big_lds(attr_done_tn, (const void*)wgrad6t_kernel<true>, 160 * 1024);
+            wgrad6t_kernel<true><<<grid, WT, lds, s>>>(a);
+        }
+        return 1;
+    }
+    if (sup == 2) {                                       // sample-pair form
+        if (NB != 1 || B % 2 != 0) return 0;
+        if ((int64_t)2 * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;
+        static std::atomic<uint64_t> attr_done_p{0};
+        te::allow_big_lds(attr_done_p, (const void*)wgrad6_kernel<true>, 160 * 1024);
+        wgrad6_kernel<true><<<dim3((unsigned)(B / 2 * S), 1, 1), WT, (size_t)N_IMG * IMG * 16, s>>>(a);
         return 1;
     }
     if ((int64_t)NB * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;
     static std::atomic<uint64_t> attr_done{0};
-    te::allow_big_lds(attr_done, (const void*)wgrad6_kernel, 160 * 1024);
-    wgrad6_kernel<<<grid, WT, (size_t)N_IMG * IMG * 16, s>>>(a);
+    te::allow_big_lds(attr_done, (const void*)wgrad6_kernel<false>, 160 * 1024);
+    wgrad6_kernel<false><<<grid, WT, (size_t)N_IMG * IMG * 16, s>>>(a);
     return 1;
 }

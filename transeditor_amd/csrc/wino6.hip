@@ -341,7 +341,10 @@ __device__ __forceinline__ void w6p_wait_vm() { asm volatile("s_waitcnt vmcnt(0)
 // stage): with `if (iscb)` / `if (fetch)` around the loads the compiler kept two copies of the 26 fetch registers and moved them twice per
 // staging phase - ~40 vector-ALU instructions in the wave whose instructions cost 10 - 27 cycles each (found in s2s6.hip's phase
 // profile, profiles/experiments/r05_s2s6_phase_profile.log; the ISA of the staging role now has no register move at all).
-template <bool ISC>
+// NARROW (round 6): M is an odd multiple of 32 (the 32 -> 32 layer at 1024^2 of the FFHQ-1024 generator, reference channel table
+// model_spatial_query.py:473-483): the last block of 64 output channels has ONE valid 32-channel tile.  Its weight slots are not
+// fetched and the waves that own it (wm == 1) skip MFMAs and stores; they keep their share of the staging.
+template <bool ISC, bool NARROW>
 __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const unsigned q2 = 2u * ((gt >> 4) & 7);
     const size_t plane = (size_t)p.H * p.W;
     const int MT = p.M >> 5;
+    const bool active = !NARROW || 2 * mb + wm < MT;              // (wave-uniform) is this wave's 32-channel tile inside M?
     f32x4 rin[P_IN][2];
     f32x2 rsc = {1.f, 1.f};        // style scales of this thread's channel pair (the same pair for its three items: 256 % 128 == 0)
     const int nstage = p.K / KC;
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         for (int r = 0; r < 9; ++r) {
             const int j = wq * 9 + r, piece = j / 12, rem = j % 12, kc = (rem >> 1) + 6 * uh, mt = rem & 1;
             const int pk = piece * 12 + kc;                                   // == (piece * 3 + ky) * 4 + c
+            if (NARROW && 2 * mb + mt >= MT) continue;                        // (a tile past M: nobody reads its slots)
             const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + (unsigned)lane;      // uniform base + 32-bit lane offset
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(ul + (pk * 2 + mt) * 64), 16, 0, 0);
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     if (grp == 0) {
         if (ISC) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
+    }   // (counts the 7 / 6 loads of issue(1) issued LAST: right for NARROW blocks too, which only issue fewer DMAs before them)
     w6p_barrier();
     const int nphase = 2 * nstage;
     if (W6P_PRIO == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
 #ifndef W6_SKIP_MFMA
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
+                    if (active) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
 #endif
                     if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
 #ifndef W6_SKIP_COMMIT
@@ -611,6 +616,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     }
 #endif
     // epilogue: as wino6_kernel (output transform, demodulation scale, bias, leaky ReLU, residual, mask); group 0 is here one phase early
+    if (!active) return;
     const int wr = grp * 2 + wrl;
     const int mbase = mb * BM + wm * 32;
     const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
@@ -656,14 +662,307 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: TWO 64-channel weight images per staged half tile (wino6q_kernel, form 2, taken when M % 128 == 0).
+//
+// What the round-6 power / clock telemetry says about wino6p_kernel (profiles/r06_power_clock_*.txt, 3-second loops, 1 400 W cap): the
+// product kernel sits AT the cap (1 364 - 1 389 W, PPT residency 60 - 75 % of the samples) at 1.99 - 2.04 GHz; with the staging arithmetic
+// and its LDS writes compiled out the same MFMA stream runs 21 - 26 % faster at the same power (0.96 - 1.10 pJ per executed FLOP against
+// 1.23 - 1.40), and the staging alone (MFMAs compiled out) needs MORE shader cycles than the MFMAs alone (2.16 M against 1.92 M kilocycles
+// at 128 -> 128 @256^2).  The block tile of wino6p is 64 output channels, so the style scale, B^T d and the three-piece split of every
+// input element are re-done by every M block: twice at 128 channels, four times at 256, eight times at 512.  Here a block owns 128
+// output channels: each half tile T_g(s) is staged ONCE and multiplied by the two weight images (s, m = 0) and (s, m = 1) in two
+// multiplying phases with their own accumulators (2 x 64 registers) - half the staging instructions, LDS writes and fetches per MFMA, same LDS
+// budget (one 72 KB weight image, two 36 KB half tiles), same weight-image hand-over protocol with the "stage" index replaced by the
+// image index j = 2 s + m:
+//     phase p (0 .. 4 nstage - 1): group p & 1 multiplies with image j = p >> 1; the other group is in its staging role
+//     group 0:            M0(s)  SA  M1(s)  SB          group 1:   S  M0(s)  SA  M1(s)  SB   (one phase behind)
+//     M0: 72 MFMAs + the fetch of stage s + 1 (consumed one multiplying phase later)    SA: weight DMA only
+//     M1: 72 MFMAs + the staging arithmetic (rin -> res) behind them                       SB: weight DMA + res -> T_g(s + 1)
+// Both groups run the SAME straight-line loop body (M0 SA M1 SB), group 1 one staging phase late: no role branch around the MFMA streams, two
+// copies of the stream (one per accumulator set).  Same products in the same order per output element as wino6p / wino6: bit-identical.
+template <bool ISC>
+__global__ __launch_bounds__(WT, 2) void wino6q_kernel(const Wino6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wrl = wq & 1, gt = tid & (GT - 1);
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + U_CHUNKS * 16) + grp * TP_DWORDS;      // this group's half tile
+    const u32x4* tl4 = reinterpret_cast<const u32x4*>(tl);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tq = jx / p.mblocks, mbq = jx % p.mblocks;               // (mblocks = M / 128 for this form)
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH, yh = y0 + PH * grp;
+    const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
+    const bool has_left = x0 == 0, has_right = x0 + TW == p.W, has_rowout = (yh == 0) || (yh + PH == p.H);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+
+    unsigned g_off[P_IN];
+    int l_off[P_IN], e_flag[P_IN];
+#pragma unroll
+    for (int i = 0; i < P_IN; ++i) {
+        const int e = gt + GT * i;
+        const int jj = e & 15, q = (e >> 4) & 7, row = e >> 7;
+        const int gy = yh - 1 + row;
+        const bool left = x0 == 0 && jj == 0, right = x0 + TW == p.W && jj == NP - 1, rowout = gy < 0 || gy >= p.H;
+        e_flag[i] = (left ? 1 : 0) | (right ? 2 : 0) | (rowout ? 4 : 0);
+        const int gyc = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
+        g_off[i] = (unsigned)((2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0));
+        l_off[i] = ((row * 2 + (q >> 2)) * NP + jj) * 4 + (q & 3);                        // + (piece * 4 + c) * TP_PLANE
+    }
+    const unsigned q2 = 2u * ((gt >> 4) & 7);
+    const size_t plane = (size_t)p.H * p.W;
+    const int MT = p.M >> 5;
+    f32x4 rin[P_IN][2];
+    f32x2 rsc = {1.f, 1.f};
+    const int nstage = p.K / KC, nimg = 2 * nstage;
+    auto fetch_scales = [&](int s) {
+        if (ISC) rsc = *reinterpret_cast<const f32x2u*>(iscb + s * KC + q2);
+    };
+    auto fetch_item = [&](int i, int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+            rin[i][h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * plane + g_off[i]);
+    };
+    // weight half `uh` of image j = 2 s + m: 36 fragment slots (3 pieces x 6 (tap row, component) groups x 2 M tiles), 9 per wave
+    auto issue_u = [&](int uh, int j) {
+        const u32x4* us = p.U + (size_t)(j >> 1) * 36 * MT * 64;
+        const int mb = 2 * mbq + (j & 1);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int jw = wq * 9 + r, piece = jw / 12, rem = jw % 12, kc = (rem >> 1) + 6 * uh, mt = rem & 1;
+            const int pk = piece * 12 + kc;                                   // == (piece * 3 + ky) * 4 + c
+            const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + (unsigned)lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ul + (pk * 2 + mt) * 64), 16, 0, 0);
+        }
+    };
+    // the staging arithmetic as a program of 51 slots (wino6p_kernel: arith), run behind the MFMAs of the m = 1 phase
+    unsigned res[P_IN][4][3];
+    float te = 0.f, to = 0.f, fe = 0.f, fo = 0.f;
+    constexpr int N_SLOT = 3 + 4 * 4 * P_IN;
+    auto arith = [&](int k) {
+        if (k < 0) {
+        } else if (k < P_IN) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[k][h2];
+                // (the flag is made opaque INSIDE each branch: otherwise the nine lane masks (f & bit) != 0 are hoisted out of the loop
+                //  as 18 scalar registers, which - with two accumulator sets - spill to v_writelane / v_readlane pairs in the MFMA stream)
+                if (has_left) {
+                    int f = e_flag[k];
+                    asm volatile("" : "+v"(f) :: "memory");
+                    if (f & 1) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+                }
+                if (has_right) {
+                    int f = e_flag[k];
+                    asm volatile("" : "+v"(f) :: "memory");
+                    if (f & 2) { v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = 0.f; }
+                }
+                if (has_rowout) {
+                    int f = e_flag[k];
+                    asm volatile("" : "+v"(f) :: "memory");
+                    if (f & 4) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                }
+                rin[k][h2] = ISC ? v * rsc[h2] : v;
+                asm volatile("" : "+v"(rin[k][h2]));
+            }
+        } else if (k < N_SLOT) {
+            const int u = (k - P_IN) >> 2, j = (k - P_IN) & 3, i = u >> 2, c = u & 3;
+            if (j == 0) {
+                const f32x4 e = rin[i][0], o = rin[i][1];
+                te = c == 0 ? e[0] - e[2] : (c == 1 ? e[1] + e[2] : (c == 2 ? e[2] - e[1] : e[1] - e[3]));
+                to = c == 0 ? o[0] - o[2] : (c == 1 ? o[1] + o[2] : (c == 2 ? o[2] - o[1] : o[1] - o[3]));
+                const f32x2 t = {te, to};
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[i][c][0] = h;
+                fe = __builtin_bit_cast(float, h << 16);
+                fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
+            } else if (j == 1) {
+                te -= fe; to -= fo;
+            } else if (j == 2) {
+                const f32x2 t = {te, to};
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[i][c][1] = m;
+                fe = __builtin_bit_cast(float, m << 16);
+                fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
+            } else {
+                te -= fe; to -= fo;
+                const f32x2 t = {te, to};
+                res[i][c][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                asm volatile("" : "+v"(res[i][c][2]));
+            }
+            asm volatile("" : "+v"(te), "+v"(to), "+v"(fe), "+v"(fo));
+        }
+    };
+    auto write_res = [&]() {
+#pragma unroll
+        for (int i = 0; i < P_IN; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) tl[l_off[i] + (pc * 4 + c) * TP_PLANE] = res[i][c][pc];
+    };
+    const int rr = l31 >> 4, jj = l31 & 15;
+    const int b_chunk = ((2 * wrl + rr) * 2 + half) * NP + jj;
+    const int a_chunk = wm * 64 + lane;
+
+    // one multiplying phase with accumulator set MSET; behind the MFMAs: MSET 0 the fetch of stage `fs`, MSET 1 the staging arithmetic
+    auto multiply = [&](auto mset_tag, int fs) {
+        constexpr int MSET = decltype(mset_tag)::value;
+        bf16x8 av[2][3], bv[2][3];
+        auto rd1 = [&](int g, int slot, int q) {
+            const int ky = g >> 2, c = g & 3;
+            if (q < 3) av[slot][q] = __builtin_bit_cast(bf16x8, ul[a_chunk + ((q * 3 + ky) * 4 + c) * 128]);
+            else bv[slot][q - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk + (((q - 3) * 4 + c) * PR + ky) * 2 * NP]);
+        };
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rd1(0, 0, q);
+        if (W6P_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int slot = g & 1, c = g & 3;
+            if (g == 5) w6p_barrier();             // mid-phase barrier
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+#ifndef W6_SKIP_MFMA
+                acc[MSET][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[MSET][c], 0, 0, 0);
+#endif
+                if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
+                const int k = g * 6 + q;
+                if (MSET == 0) {
+                    // the fetch of the next stage, an item every twelve slots from the sixth on (rin is free: the m = 1 phase consumed it)
+                    if (k == 5) fetch_scales(fs);
+#pragma unroll
+                    for (int i = 0; i < P_IN; ++i)
+                        if (k == 6 + 12 * i) fetch_item(i, fs);
+                } else {
+#ifndef W6_SKIP_COMMIT
+                    arith(k - W6P_SLOT0);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (W6P_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        w6p_barrier();                             // end of phase
+    };
+    // one phase in the staging role.  p = global phase index; image cs = (p + 1) >> 1 is the one whose half this phase renews:
+    // group 1 (even p) renews Ub(cs) in FRONT of the mid-phase barrier (its partner reads it right behind), group 0 (odd p) renews
+    // Ua(cs) BEHIND it (the partner is past the last read of Ua(cs - 1) there).  WRITE: this is the phase behind the group's m = 1
+    // multiply: the parked results go to the half tile (nobody reads it until the group's next m = 0 phase).
+    auto stage = [&](int ph, bool write) {
+        const int cs = (ph + 1) >> 1;
+        const bool work = cs >= 1 && cs < nimg;
+        if (grp == 1 && work) issue_u(1, cs);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef W6_SKIP_COMMIT
+        if (write) write_res();
+#endif
+        if (grp == 1 && work) w6p_wait_vm();
+        w6p_barrier();                             // mid-phase
+        if (grp == 0 && work) {
+            issue_u(0, cs);
+            w6p_wait_vm();
+        }
+        w6p_barrier();                             // end of phase
+    };
+
+    // prologue: every group transforms and writes its half of stage 0; group 0 brings in the whole weight image 0
+    fetch_scales(0);
+#pragma unroll
+    for (int i = 0; i < P_IN; ++i) fetch_item(i, 0);
+    if (grp == 0) { issue_u(0, 0); issue_u(1, 0); }
+#pragma unroll
+    for (int k = 0; k < N_SLOT; ++k) arith(k);
+    write_res();
+    w6p_wait_vm();
+    w6p_barrier();
+    int ph = 0;
+    if (grp == 1) { stage(0, false); ph = 1; }
+    for (int s = 0; s < nstage; ++s) {
+        const int fs = min(s + 1, nstage - 1);
+        multiply(std::integral_constant<int, 0>{}, fs);
+        stage(ph + 1, false);
+        multiply(std::integral_constant<int, 1>{}, fs);
+        if (!(grp == 1 && s == nstage - 1)) stage(ph + 3, true);
+        ph += 4;
+    }
+
+    // epilogue: as wino6_kernel, once per accumulator set
+    const int wr = grp * 2 + wrl;
+    const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mbase = (2 * mbq + m) * BM + wm * 32;
+        const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
+        float scv[16], biv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = mbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+            scv[r] = p.osc ? p.osc[(size_t)b * p.M + mm] : 1.f;
+            biv[r] = p.bias ? p.bias[mm] : 0.f;
+        }
+        f32x2 resv[16], mrefv[16];
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                resv[r] = *reinterpret_cast<const f32x2*>(p.res + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+        }
+        if (p.mref) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mrefv[r] = *reinterpret_cast<const f32x2*>(p.mref + off0 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * plane);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v0 = acc[m][0][r] + acc[m][1][r] + acc[m][2][r];
+            float v1 = acc[m][1][r] - acc[m][2][r] - acc[m][3][r];
+            const float sc = scv[r], bi = biv[r];
+            v0 = v0 * sc + bi;
+            v1 = v1 * sc + bi;
+            if (p.act >= 3) {
+                v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+                v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
+            }
+            const size_t o = off0 + (size_t)dm * plane;
+            if (p.res) { v0 += resv[r][0]; v1 += resv[r][1]; }
+            if (p.mref) {
+                v0 *= mrefv[r][0] > 0.f ? p.mgain : 0.2f * p.mgain;
+                v1 *= mrefv[r][1] > 0.f ? p.mgain : 0.2f * p.mgain;
+            }
+            f32x2 v; v[0] = v0; v[1] = v1;
+            *reinterpret_cast<f32x2*>(p.out + o) = v;
+        }
+    }
+}
+
 }  // namespace
 
 // kernel form of TE_CONV_3X3W6: 1 = ping-pong (wino6p_kernel, round 5, default), 0 = block-phase (wino6_kernel, round 4); same results
 // bit for bit (same products, same accumulation order per output element).  TE_W6_FORM in the environment sets the initial value.
-static std::atomic<int> g_w6_form{[] { const char* e = getenv("TE_W6_FORM"); return e ? atoi(e) : 1; }()};
+// 2 (round 6, default) = the two-image form wino6q_kernel where M % 128 == 0 and the grid still gives every CU a block (it has half
+// as many blocks as the ping-pong form: measured slower on small grids, e.g. 39 against 22 us at 3 x 64 -> 256 @16x64), the ping-pong
+// form elsewhere; 3 = the two-image form wherever M % 128 == 0 (tests).
+static std::atomic<int> g_w6_form{[] { const char* e = getenv("TE_W6_FORM"); return e ? atoi(e) : 2; }()};
 extern "C" int te_conv_wino6_form(int form) {
     const int old = g_w6_form.load(std::memory_order_relaxed);
-    if (form == 0 || form == 1) g_w6_form.store(form, std::memory_order_relaxed);
+    if (form >= 0 && form <= 3) g_w6_form.store(form, std::memory_order_relaxed);
     return old;
 }
 
@@ -674,14 +973,16 @@ extern "C" int te_debug_w6p_prof(void* host_dst, int64_t bytes) {
 #endif
 
 extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
-    if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
-    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
+    // M % 64 == 0, or (round 6) exactly 32 channels - one valid tile in the block of 64, half of its matrix pipes idle: taken for the
+    // 32-channel layer of the FFHQ-1024 generator, not for 96 / 160 ... (those keep the fp32 Winograd kernel)
+    if (!(B > 0 && K >= 32 && K % 32 == 0 && (M == 32 || (M >= BM && M % BM == 0)) && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
+    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * te::cdiv(M, BM) < 0x7FFFFFF0) ? 1 : 0;
 }
 
 int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                     const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s) {
     TE_REQUIRE(te_conv_wino6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
-               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
+               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0 or M == 32, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
     TE_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(res) |
                  reinterpret_cast<uintptr_t>(mask_ref)) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_3X3W6): 16-byte aligned tensors required");
@@ -689,19 +990,41 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
     a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.res = res;
     a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
-    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
+    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = (int)te::cdiv(M, BM);
     a.ntiles = B * a.tiles_x * a.tiles_y;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    if (g_w6_form.load(std::memory_order_relaxed) == 1) {
+    const int form = g_w6_form.load(std::memory_order_relaxed);
+    const int64_t blocks_q = te::cdiv(a.ntiles, 8) * 8 * (M / (2 * BM));
+    if (form >= 2 && M % (2 * BM) == 0 && (form == 3 || blocks_q >= te::kNumCU)) {
+        a.mblocks = M / (2 * BM);
+        const int64_t blocks2 = blocks_q;
         const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
-        static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0};
+        static std::atomic<uint64_t> attr_done_q{0}, attr_done_qs{0};
         if (isc) {
-            te::allow_big_lds(attr_done_ps, (const void*)wino6p_kernel<true>, 160 * 1024);
-            wino6p_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+            te::allow_big_lds(attr_done_qs, (const void*)wino6q_kernel<true>, 160 * 1024);
+            wino6q_kernel<true><<<dim3((unsigned)blocks2), WT, lds, s>>>(a);
         } else {
-            te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel<false>, 160 * 1024);
-            wino6p_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+            te::allow_big_lds(attr_done_q, (const void*)wino6q_kernel<false>, 160 * 1024);
+            wino6q_kernel<false><<<dim3((unsigned)blocks2), WT, lds, s>>>(a);
+        }
+    } else if (form >= 1 || M % BM != 0) {
+        const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
+        static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0}, attr_done_pn{0}, attr_done_psn{0};
+        if (M % BM != 0) {
+            if (isc) {
+                te::allow_big_lds(attr_done_psn, (const void*)wino6p_kernel<true, true>, 160 * 1024);
+                wino6p_kernel<true, true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+            } else {
+                te::allow_big_lds(attr_done_pn, (const void*)wino6p_kernel<false, true>, 160 * 1024);
+                wino6p_kernel<false, true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+            }
+        } else if (isc) {
+            te::allow_big_lds(attr_done_ps, (const void*)wino6p_kernel<true, false>, 160 * 1024);
+            wino6p_kernel<true, false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+        } else {
+            te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel<false, false>, 160 * 1024);
+            wino6p_kernel<false, false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
         }
     } else {
         const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;

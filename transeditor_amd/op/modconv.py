@@ -473,6 +473,17 @@ class _ConvWgrad(Function):
         return g_gy, g_x, None, None, None
 
 
+def set_split_bf16(on):
+    """ONE switch for every split-bf16 kernel: the convolution kinds (gated here, by USE_SPLIT_BF16) and the weight-gradient kernels
+    (gated in the library, te_wgrad_split_bf16).  Assigning `modconv.USE_SPLIT_BF16 = x` does the same (module property below), so an
+    A/B that flips the Python flag can no longer leave the weight gradient on the other arithmetic.  TE_SPLIT_WGRAD=0 in the
+    environment keeps the weight gradient alone on the fp32 kernels."""
+    on = bool(on)
+    globals()['USE_SPLIT_BF16'] = on
+    _lib.wgrad_split(1 if (on and os.environ.get('TE_SPLIT_WGRAD', '1') != '0') else 0)
+    return on
+
+
 def conv_core(x, w, kind='3x3', wscale=1.0):
     """Plain convolution y = conv(x, wscale * w) (w [Co,Ci,k,k]), differentiable to any order."""
     return _ConvFwd.apply(x, w, kind, float(wscale))
@@ -751,3 +762,21 @@ def modconv(x, w, isc=None, osc=None, bias=None, act=False, kind='3x3', wscale=1
     if _STATE.frozen_on and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, isc, osc, bias))):
         return _modconv_frozen(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
     return _ModConvFused.apply(x, w, isc, osc, bias, act, kind, float(wscale), demod_eps)
+
+
+# `modconv.USE_SPLIT_BF16 = flag` goes through set_split_bf16 (reads stay plain global lookups)
+import sys as _sys
+import types as _types
+
+
+class _ModconvModule(_types.ModuleType):
+    @property
+    def USE_SPLIT_BF16(self):
+        return self.__dict__['USE_SPLIT_BF16']
+
+    @USE_SPLIT_BF16.setter
+    def USE_SPLIT_BF16(self, on):
+        set_split_bf16(on)
+
+
+_sys.modules[__name__].__class__ = _ModconvModule
