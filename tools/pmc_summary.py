@@ -12,6 +12,7 @@ KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 'wgrad6', 'wgrad_mfma',
 ALG = {
     'wino6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),       # algorithmic (direct-form) FLOPs
     'wino6p_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the ping-pong form, round 5)
+    'wino6q_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the two-image form, round 6)
     's2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     't2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs

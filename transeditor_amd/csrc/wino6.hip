@@ -341,10 +341,12 @@ __device__ __forceinline__ void w6p_wait_vm() { asm volatile("s_waitcnt vmcnt(0)
 // stage): with `if (iscb)` / `if (fetch)` around the loads the compiler kept two copies of the 26 fetch registers and moved them twice per
 // staging phase - ~40 vector-ALU instructions in the wave whose instructions cost 10 - 27 cycles each (found in s2s6.hip's phase
 // profile, profiles/experiments/r05_s2s6_phase_profile.log; the ISA of the staging role now has no register move at all).
-// NARROW (round 6): M is an odd multiple of 32 (the 32 -> 32 layer at 1024^2 of the FFHQ-1024 generator, reference channel table
-// model_spatial_query.py:473-483): the last block of 64 output channels has ONE valid 32-channel tile.  Its weight slots are not
-// fetched and the waves that own it (wm == 1) skip MFMAs and stores; they keep their share of the staging.
-template <bool ISC, bool NARROW>
+// (Round 6, tried and NOT taken: a NARROW form for M == 32 - the 32 -> 32 layer at 1024^2 of the FFHQ-1024 generator - in which the block's
+//  second 32-channel tile is padding, its weight slots are not fetched and the waves that own it skip MFMAs and stores.  Correct at the
+//  5e-6 bar, but 1 121 us against the 769 us of the fp32 Winograd kernel wino3x3_kernel<32>: with K = 32 a block lives for two stages, one
+//  block per CU (144 KB of LDS), so the prologue's HBM latency and the epilogue are not overlapped by anything;
+//  profiles/experiments/r06_g1024_kernel_stats_with_wino6p_narrow.txt, r06_wino6p_narrow.patch.)
+template <bool ISC>
 __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
@@ -389,7 +391,6 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const unsigned q2 = 2u * ((gt >> 4) & 7);
     const size_t plane = (size_t)p.H * p.W;
     const int MT = p.M >> 5;
-    const bool active = !NARROW || 2 * mb + wm < MT;              // (wave-uniform) is this wave's 32-channel tile inside M?
     f32x4 rin[P_IN][2];
     f32x2 rsc = {1.f, 1.f};        // style scales of this thread's channel pair (the same pair for its three items: 256 % 128 == 0)
     const int nstage = p.K / KC;
@@ -419,7 +420,6 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         for (int r = 0; r < 9; ++r) {
             const int j = wq * 9 + r, piece = j / 12, rem = j % 12, kc = (rem >> 1) + 6 * uh, mt = rem & 1;
             const int pk = piece * 12 + kc;                                   // == (piece * 3 + ky) * 4 + c
-            if (NARROW && 2 * mb + mt >= MT) continue;                        // (a tile past M: nobody reads its slots)
             const u32x4* g = us + ((size_t)pk * MT + 2 * mb + mt) * 64 + (unsigned)lane;      // uniform base + 32-bit lane offset
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(ul + (pk * 2 + mt) * 64), 16, 0, 0);
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     if (grp == 0) {
         if (ISC) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }   // (counts the 7 / 6 loads of issue(1) issued LAST: right for NARROW blocks too, which only issue fewer DMAs before them)
+    }
     w6p_barrier();
     const int nphase = 2 * nstage;
     if (W6P_PRIO == 3 && grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
 #ifndef W6_SKIP_MFMA
-                    if (active) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[q]], bv[slot][PB[q]], acc[c], 0, 0, 0);
 #endif
                     if (g + 1 < 12 && q < 3) { rd1(g + 1, slot ^ 1, 2 * q); rd1(g + 1, slot ^ 1, 2 * q + 1); }
 #ifndef W6_SKIP_COMMIT
@@ -616,7 +616,6 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     }
 #endif
     // epilogue: as wino6_kernel (output transform, demodulation scale, bias, leaky ReLU, residual, mask); group 0 is here one phase early
-    if (!active) return;
     const int wr = grp * 2 + wrl;
     const int mbase = mb * BM + wm * 32;
     const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
@@ -973,16 +972,14 @@ extern "C" int te_debug_w6p_prof(void* host_dst, int64_t bytes) {
 #endif
 
 extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
-    // M % 64 == 0, or (round 6) exactly 32 channels - one valid tile in the block of 64, half of its matrix pipes idle: taken for the
-    // 32-channel layer of the FFHQ-1024 generator, not for 96 / 160 ... (those keep the fp32 Winograd kernel)
-    if (!(B > 0 && K >= 32 && K % 32 == 0 && (M == 32 || (M >= BM && M % BM == 0)) && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
-    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * te::cdiv(M, BM) < 0x7FFFFFF0) ? 1 : 0;
+    if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
+    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
 }
 
 int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                     const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s) {
     TE_REQUIRE(te_conv_wino6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
-               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0 or M == 32, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
+               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
     TE_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(res) |
                  reinterpret_cast<uintptr_t>(mask_ref)) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_3X3W6): 16-byte aligned tensors required");
@@ -990,7 +987,7 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
     a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.res = res;
     a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
-    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = (int)te::cdiv(M, BM);
+    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
     a.ntiles = B * a.tiles_x * a.tiles_y;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
@@ -1008,23 +1005,15 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
             te::allow_big_lds(attr_done_q, (const void*)wino6q_kernel<false>, 160 * 1024);
             wino6q_kernel<false><<<dim3((unsigned)blocks2), WT, lds, s>>>(a);
         }
-    } else if (form >= 1 || M % BM != 0) {
+    } else if (form >= 1) {
         const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
-        static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0}, attr_done_pn{0}, attr_done_psn{0};
-        if (M % BM != 0) {
-            if (isc) {
-                te::allow_big_lds(attr_done_psn, (const void*)wino6p_kernel<true, true>, 160 * 1024);
-                wino6p_kernel<true, true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
-            } else {
-                te::allow_big_lds(attr_done_pn, (const void*)wino6p_kernel<false, true>, 160 * 1024);
-                wino6p_kernel<false, true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
-            }
-        } else if (isc) {
-            te::allow_big_lds(attr_done_ps, (const void*)wino6p_kernel<true, false>, 160 * 1024);
-            wino6p_kernel<true, false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+        static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0};
+        if (isc) {
+            te::allow_big_lds(attr_done_ps, (const void*)wino6p_kernel<true>, 160 * 1024);
+            wino6p_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
         } else {
-            te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel<false, false>, 160 * 1024);
-            wino6p_kernel<false, false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
+            te::allow_big_lds(attr_done_p, (const void*)wino6p_kernel<false>, 160 * 1024);
+            wino6p_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
         }
     } else {
         const size_t lds = (size_t)U_CHUNKS * 16 + (size_t)T_DWORDS * 4;
