@@ -28,6 +28,10 @@ REDUCE_CASES = [   # B, S, Co, Ci, taps, (isc, osc)
     (4, 3, 64, 64, 9, (True, True)),        # fused single pass, one chunk group
     (16, 16, 32, 32, 9, (True, True)),      # fused, slab chunks split over blockIdx.z (narrow layer): dW through parts as well
     (3, 5, 128, 96, 9, (True, False)),      # fused, odd batch (tail sample), no demodulation
+    (16, 1, 256, 256, 9, (True, True)),     # fused, round 6: ONE chunk per sample, the BATCH split over blockIdx.z (4 ranges of 4 samples)
+    (16, 4, 128, 128, 9, (True, True)),     # fused, chunks AND batch split (4 x 4)
+    (9, 2, 256, 256, 9, (True, True)),      # fused, odd batch split in two ranges (4 + 5 samples: a tail sample in one of them), 2 chunk ranges
+    (5, 3, 128, 128, 9, (False, True)),     # fused, three chunk ranges of one chunk, no batch split
     (2, 2, 24, 20, 9, (True, True)),        # generic path (not multiples of 16 / 32)
     (5, 7, 40, 12, 1, (True, True)),        # generic, 1x1
     (8, 4, 512, 512, 1, (False, False)),    # plain 1x1 (discriminator skip): dW only, chunks over (b, s)

@@ -780,17 +780,21 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
                                                                       float* __restrict__ gosc, const float* __restrict__ slabs,
                                                                       const float* __restrict__ w, float wscale,
                                                                       const float* __restrict__ isc, const float* __restrict__ osc,
-                                                                      int B, int S, int Co, int Ci) {
-    // blockIdx.z splits the slab chunks of every sample (narrow layers: a 32 x 32 weight has 2 tiles but hundreds of
-    // chunks); all three outputs are linear in the slab sums.  NO atomics: d osc of a (sample, channel) gets a share from
-    // every ci block and chunk, d isc from every co block and chunk, dW (when chunked) from every chunk - each block writes
-    // its share to its own row of the workspace (gosc: [gridDim.z * gridDim.x][B][Co], gisc: [gridDim.z * gridDim.y][B][Ci],
-    // gw: [gridDim.z][E]) and sum_parts_kernel adds the rows in a fixed order: bit-reproducible gradients.
-    const int s0 = (int)((int64_t)S * blockIdx.z / gridDim.z), s1 = (int)((int64_t)S * (blockIdx.z + 1) / gridDim.z);
+                                                                      int B, int S, int Co, int Ci, int nzs) {
+    // blockIdx.z = zb * nzs + zs splits the slab chunks of every sample (zs: narrow layers - a 32 x 32 weight has 2 tiles but
+    // hundreds of chunks) and, round 6, the BATCH (zb: the 128- / 256-channel layers have 32 / 128 tiles of two waves and one or
+    // two chunks per sample - a quarter of the CUs got a block and the pass ran at 0.31 of the HBM peak); all three outputs are
+    // linear in the slab sums.  NO atomics: d osc of a (sample, channel) gets a share from every ci block and chunk range, d isc
+    // from every co block and chunk range, dW (when split) from every z - each block writes its share to its own row of the
+    // workspace (gosc: [nzs * gridDim.x][B][Co], gisc: [nzs * gridDim.y][B][Ci] - a sample belongs to ONE zb -, gw: [gridDim.z][E])
+    // and sum_parts_kernel adds the rows in a fixed order: bit-reproducible gradients.
+    const int zs = blockIdx.z % nzs, zb = blockIdx.z / nzs, nzb = gridDim.z / nzs;
+    const int s0 = (int)((int64_t)S * zs / nzs), s1 = (int)((int64_t)S * (zs + 1) / nzs);
+    const int b0 = (int)((int64_t)B * zb / nzb), b1 = (int)((int64_t)B * (zb + 1) / nzb);
     __shared__ float red[2 * 64];
     FusedCtx c;
-    c.gisc = gisc ? gisc + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * B * Ci : nullptr;
-    c.gosc = gosc ? gosc + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * B * Co : nullptr;
+    c.gisc = gisc ? gisc + ((size_t)zs * gridDim.y + blockIdx.y) * B * Ci : nullptr;
+    c.gosc = gosc ? gosc + ((size_t)zs * gridDim.x + blockIdx.x) * B * Co : nullptr;
     c.isc = isc; c.osc = osc; c.Co = Co; c.Ci = Ci;
     c.tid = threadIdx.x; c.l8 = c.tid & 7; c.lane = c.tid & 63; c.wid = c.tid >> 6;
     c.co = blockIdx.y * FROWS + (c.tid >> 3); c.cib = blockIdx.x * 32; c.ci0 = c.cib + c.l8 * 4;
@@ -802,8 +806,8 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
         wv[i] = *reinterpret_cast<const f32x4*>(w + off + 4 * i) * wscale;
         acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    int b = 0;
-    for (; b + 1 < B; b += 2) {
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
         f32x4 u0[9], u1[9];
         const float* p0 = slabs + ((size_t)b * S + s0) * E + off;
         const float* p1 = p0 + (size_t)S * E;
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(FTHREADS) void wgrad_reduce_fused_kernel(float* __r
         fused_consume(c, b, u0, wv, acc, red);
         fused_consume(c, b + 1, u1, wv, acc, red);
     }
-    if (b < B) {
+    if (b < b1) {
         f32x4 u0[9];
         const float* p0 = slabs + ((size_t)b * S + s0) * E + off;
 #pragma unroll
@@ -864,9 +868,13 @@ inline void launch_sum_parts(const SumJob* jobs, int n, hipStream_t s) {
 
 // chunk counts of the reducer paths (shared by te_wgrad_reduce_ws_floats and the launch)
 inline bool reduce_fused_ok(int Co, int Ci, int taps) { return taps == 9 && Co % FROWS == 0 && Ci % 32 == 0 && Co / FROWS <= 65535; }
-inline int reduce_fused_nz(int S, int Co, int Ci) {
-    const int tiles = (Ci / 32) * (Co / FROWS);
-    return (tiles < te::kNumCU / 4 && S >= 8) ? (int)std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, tiles)) : 1;
+// (chunk splits nzs, batch splits nzb) of the fused reducer: two blocks of two waves per CU where the problem allows, every block
+// still sums >= 4 (sample, chunk) slabs so that the dW parts stay <= a quarter of the slab bytes
+inline void reduce_fused_split(int B, int S, int Co, int Ci, int& nzs, int& nzb) {
+    const int64_t tiles = (int64_t)(Ci / 32) * (Co / FROWS);
+    int64_t nz = std::max<int64_t>(1, std::min<int64_t>(te::cdiv(2 * te::kNumCU, tiles), (int64_t)B * S / 4));
+    nzs = (int)std::max<int64_t>(1, std::min<int64_t>(S, nz));
+    nzb = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, B / 2), nz / nzs));
 }
 inline int reduce_few_nz(int B, int S, int Ci) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(S / 4, te::cdiv(te::kNumCU, (int64_t)te::cdiv(Ci, RTHREADS) * B)));
@@ -979,10 +987,11 @@ extern "C" int64_t te_wgrad_reduce_ws_floats(int B, int S, int Co, int Ci, int t
     const int64_t E = (int64_t)Co * Ci * taps;
     int64_t n = 0;
     if (reduce_fused_ok(Co, Ci, taps)) {
-        const int nz = reduce_fused_nz(S, Co, Ci);
-        if (want_osc) n += (int64_t)nz * (Ci / 32) * B * Co;
-        if (want_isc) n += (int64_t)nz * (Co / FROWS) * B * Ci;
-        if (want_w && nz > 1) n += (int64_t)nz * E;
+        int nzs, nzb;
+        reduce_fused_split(B, S, Co, Ci, nzs, nzb);
+        if (want_osc) n += (int64_t)nzs * (Ci / 32) * B * Co;
+        if (want_isc) n += (int64_t)nzs * (Co / FROWS) * B * Ci;
+        if (want_w && nzs * nzb > 1) n += (int64_t)nzs * nzb * E;
     }
     int64_t m = 0;                                         // the generic path (also the fall-back of a misaligned fused problem)
     if (want_w) m += (int64_t)std::max(reduce_w_nchunk(B, S, E, false), reduce_w_nchunk(B, S, E, E % 4 == 0)) * E;
@@ -1010,14 +1019,16 @@ extern "C" int te_wgrad_reduce_f32(float* gw, float* gisc, float* gosc, float* w
     const uintptr_t al = reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gw) |
                          reinterpret_cast<uintptr_t>(ws);
     if (reduce_fused_ok(Co, Ci, taps) && (al & 15) == 0) {                                          // single-pass path
-        const int nz = reduce_fused_nz(S, Co, Ci), nX = Ci / 32, nY = Co / FROWS;
+        int nzs, nzb;
+        reduce_fused_split(B, S, Co, Ci, nzs, nzb);
+        const int nz = nzs * nzb, nX = Ci / 32, nY = Co / FROWS;
         float* p = ws;
         float* po = nullptr; float* pi = nullptr; float* pw = gw;
-        if (gosc) { po = p; p += (size_t)nz * nX * B * Co; jobs[nj++] = SumJob{gosc, po, nz * nX, (int64_t)B * Co}; }
-        if (gisc) { pi = p; p += (size_t)nz * nY * B * Ci; jobs[nj++] = SumJob{gisc, pi, nz * nY, (int64_t)B * Ci}; }
+        if (gosc) { po = p; p += (size_t)nzs * nX * B * Co; jobs[nj++] = SumJob{gosc, po, nzs * nX, (int64_t)B * Co}; }
+        if (gisc) { pi = p; p += (size_t)nzs * nY * B * Ci; jobs[nj++] = SumJob{gisc, pi, nzs * nY, (int64_t)B * Ci}; }
         if (gw && nz > 1) { pw = p; p += (size_t)nz * E; jobs[nj++] = SumJob{gw, pw, nz, E}; }
         dim3 grid((unsigned)nX, (unsigned)nY, (unsigned)nz);
-        wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(pw, pi, po, slabs, w, wscale, isc, osc, B, S, Co, Ci);
+        wgrad_reduce_fused_kernel<<<grid, FTHREADS, 0, s>>>(pw, pi, po, slabs, w, wscale, isc, osc, B, S, Co, Ci, nzs);
         launch_sum_parts(jobs, nj, s);
         return te::launch_status("te_wgrad_reduce_f32");
     }

@@ -52,6 +52,35 @@ __device__ __forceinline__ f32x4 buf_load4w(__amdgpu_buffer_rsrc_t r, unsigned o
 }
 __device__ __forceinline__ void w6g_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// Round 6 (operand traffic 2.49x / 3.65x the algorithmic bytes in the counters).  Two changes of ORDER, no change of work:
+//  (i) the chunks of a sample group and their channel-tile siblings run on ONE XCD.  Blocks are dealt round-robin to the 8 XCDs in
+//      linear order, and gridDim.x is a multiple of 8 at every model shape, so XCD = blockIdx.x % 8 whatever (y, z): virtual index
+//      v = (x % 8) * (gridDim.x / 8) + x / 8 gives every XCD a CONTIGUOUS range of (group, chunk) pairs (the banded order conv.hip uses);
+// (ii) the chunks that run side by side work on ADJACENT 32- / 16-column tiles at the same rows: chunk s takes the columns s, s + S,
+//      s + 2 S ... (when S divides the column count) or the column s % U and the row range s / U (when a column is split), instead
+//      of a contiguous run of columns.  A lane's halo loads - one cell left of its 16 cells, one cell right: two more 64-byte sectors per
+//      row segment, 3 fetched for 1.1 used when the neighbouring tile is staged hundreds of steps later - and the channel-tile siblings' copies of the
+//      same rows then meet in that XCD's L2 instead of going out to the fabric again.
+struct Wg6Chunk { int bgrp, s, nseg, mode, U; };
+__device__ __forceinline__ Wg6Chunk wg6_chunk(int S, int U) {
+    const int total = (int)gridDim.x, x = (int)blockIdx.x;
+    const int v = (total & 7) == 0 ? (x & 7) * (total >> 3) + (x >> 3) : x;
+    Wg6Chunk c;
+    c.bgrp = v / S; c.s = v - c.bgrp * S; c.U = U;
+    c.mode = (U % S == 0) ? 1 : ((S % U == 0) ? 2 : 0);
+    c.nseg = c.mode == 1 ? U / S : 1;
+    return c;
+}
+// steps [t0, t1) of segment k of the chunk, in the flattened order t = column * H + row (column = sample-of-group * tiles_x + tile)
+__device__ __forceinline__ void wg6_segment(const Wg6Chunk& c, int k, int S, int H, int n_steps, int& t0, int& t1) {
+    if (c.mode == 1) { t0 = (c.s + k * S) * H; t1 = t0 + H; }
+    else if (c.mode == 2) {
+        const int u = c.s % c.U, r = c.s / c.U, R = S / c.U;
+        t0 = u * H + (int)((int64_t)H * r / R); t1 = u * H + (int)((int64_t)H * (r + 1) / R);
+    } else { t0 = (int)((int64_t)n_steps * c.s / S); t1 = (int)((int64_t)n_steps * (c.s + 1) / S); }
+}
+
 #ifndef WG6_ILV
 #define WG6_ILV 1    // 1: consecutive MFMAs on different accumulators (see the MFMA loop); 0: six in a row per accumulator (A/B: same time)
 #endif
@@ -78,7 +107,8 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     const int kh = wid & 1;                                   //          k half = cells 16 kh .. 16 kh + 15 of the row segment; lane = channel
     const bool active = !PAIR || wco == wci;                  // (wave-uniform) does this wave's tile belong to a problem?
 
-    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = PAIR ? 2 * bgrp : bgrp * p.NB;
+    const Wg6Chunk ck = wg6_chunk(p.S, (PAIR ? 1 : p.NB) * p.tiles_x);
+    const int s_chunk = ck.s, bgrp = ck.bgrp, b = PAIR ? 2 * bgrp : bgrp * p.NB;
     const int co0 = PAIR ? 0 : blockIdx.y * TC, ci0 = PAIR ? 0 : blockIdx.z * TC;
     const size_t plane = (size_t)p.H * p.W;
     const unsigned g_sample = (unsigned)(p.Co * plane * 4), x_sample = (unsigned)(p.Ci * plane * 4);      // bytes (host-checked < 2 GiB per group)
@@ -174,8 +204,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
     auto x_img = [&](int y) { return 2 + (y & 3); };
 
     const int sps = p.tiles_x * p.H;                          // steps of one sample
-    const int n_steps = sps * p.NB;
-    const int t_begin = (int)((int64_t)n_steps * s_chunk / p.S), t_end = (int)((int64_t)n_steps * (s_chunk + 1) / p.S);
+    const int n_steps = sps * (PAIR ? 1 : p.NB);
     const int a_elem = half * TC + wco * 32 + l31;            // + ((piece * 4 + j) * 2) * 64 + image * IMG
     const int b_elem = half * TC + wci * 32 + l31;
 #ifdef WG6_PROF
@@ -185,7 +214,10 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
 #endif
 
     float rw[NRAW], rn[NRAW];
-    for (int t = t_begin; t < t_end;) {
+    for (int sg = 0; sg < ck.nseg; ++sg) {
+    int t, t_end;
+    wg6_segment(ck, sg, p.S, p.H, n_steps, t, t_end);
+    while (t < t_end) {
         const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
         const int n = min(p.H - ya, t_end - t), yb = ya + n;
         t += n;
@@ -304,6 +336,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6_kernel(const Wg6Args p) {
 #endif
         }
     }
+    }
 #ifdef WG6_PROF
     {
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -362,7 +395,8 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 32 x 32 tile
     const int rsel = wid >> 1, q = wid & 1;                   // staging: g row 2i + 3 + rsel, cells 8 q .. 8 q + 7 of the step; lane = channel
 
-    const int s_chunk = blockIdx.x % p.S, bgrp = blockIdx.x / p.S, b = bgrp * p.NB;
+    const Wg6Chunk ck = wg6_chunk(p.S, p.NB * (p.W / 16));
+    const int s_chunk = ck.s, bgrp = ck.bgrp, b = bgrp * p.NB;
     const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * TC;
     const int Hg = 2 * p.H + 1, Wg = 2 * p.W + 1;
     const size_t gplane = (size_t)Hg * Wg, xplane = (size_t)p.H * p.W;
@@ -458,7 +492,6 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
 
     const int tiles_x = p.W / 16;
     const int sps = tiles_x * p.H, n_steps = sps * p.NB;
-    const int t_begin = (int)((int64_t)n_steps * s_chunk / p.S), t_end = (int)((int64_t)n_steps * (s_chunk + 1) / p.S);
     const int a_elem = half * TC + wco * 32 + l31;
     const int b_elem = NGR * GI + half * TC + wci * 32 + l31;
 
@@ -468,7 +501,10 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     int nstep_done = 0;
 #endif
     float rg[17], rx[8], ng[17], nx[8];
-    for (int t = t_begin; t < t_end;) {
+    for (int sg = 0; sg < ck.nseg; ++sg) {
+    int t, t_end;
+    wg6_segment(ck, sg, p.S, p.H, n_steps, t, t_end);
+    while (t < t_end) {
         const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
         const int n = min(p.H - ya, t_end - t), yb = ya + n;
         t += n;
@@ -544,6 +580,7 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
             { const unsigned long long tm2 = __builtin_readcyclecounter(); pc_mult += tm1 - tm0; pc_bar += tm2 - tm1; ++nstep_done; }
 #endif
         }
+    }
     }
 #ifdef WG6_PROF
     {

@@ -287,10 +287,12 @@ class TrainStep:
         torch.save(self.checkpoint(), path)
         return path
 
-    def load_checkpoint(self, ckpt):
+    def load_checkpoint(self, ckpt, g_ema_only_ok=False):
         """`ckpt`: a path or an already loaded dictionary.  Returns the start iteration parsed from the file name (:481-484),
-        or None.  A published inference checkpoint that only holds 'g_ema' loads into the EMA generator alone."""
-        return load_checkpoint_into(ckpt, self.g_ema, self.generator, self.discriminator, self.g_optim, self.d_optim, self.device)
+        or None.  A file that only holds 'g_ema' (the published inference checkpoints) raises KeyError like the reference's
+        restore (:487) unless `g_ema_only_ok=True`: then the EMA generator alone is loaded and None is returned."""
+        return load_checkpoint_into(ckpt, self.g_ema, self.generator, self.discriminator, self.g_optim, self.d_optim, self.device,
+                                    g_ema_only_ok=g_ema_only_ok)
 
     def iteration(self, i, real_img):
         """One iteration `i` of the reference loop on a batch of real images already on the device."""
