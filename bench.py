@@ -78,7 +78,7 @@ def _arithmetic_switches():
     from transeditor_amd import _lib
     return {'split_bf16': bool(modconv.USE_WINOGRAD and modconv.USE_SPLIT_BF16),
             'split_bf16_strided': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_S2), 'split_bf16_transposed': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_T2),
-            'split_bf16_weight_gradient_3x3': bool(_lib.wgrad_split()),
+            'split_bf16_weight_gradient_3x3': bool(_lib.wgrad_split()), 'split_bf16_1x1': bool(modconv.USE_SPLIT_BF16 and modconv.USE_SPLIT_1X1),
             'arithmetic_short': ARITHMETIC_SHORT if modconv.USE_SPLIT_BF16 else 'fp32 MFMA / vector instructions everywhere',
             'split_bf16_kernel_form': W6_KERNEL.get(_w6_form(), None)}
 
@@ -120,13 +120,14 @@ class KernelTimer:
         orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
         names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1',
                  _lib.CONV_3X3W: 'conv3x3', _lib.CONV_3X3W6: 'conv3x3',         # (Winograd forms of the same convolution: same algorithmic FLOPs)
-                 _lib.CONV_S2S6: 'convS2', _lib.CONV_T2S6: 'convT2'}            # (the strided / transposed kinds on the bf16 pipe)
+                 _lib.CONV_S2S6: 'convS2', _lib.CONV_T2S6: 'convT2',            # (the strided / transposed kinds on the bf16 pipe)
+                 _lib.CONV_1X1S6: 'conv1x1'}                                   # (round 6: the plain 1x1 product on the bf16 pipe)
 
         def conv(x, wp, kind, M, H, W, *a, **k):
             if not timer.enabled:
                 return orig_conv(x, wp, kind, M, H, W, *a, **k)
             B, K = x.shape[0], x.shape[1]
-            taps = 1 if kind == _lib.CONV_1X1 else 9
+            taps = 1 if kind in (_lib.CONV_1X1, _lib.CONV_1X1S6) else 9
             flops = 2.0 * taps * K * M * H * W * B       # algorithmic: T2/S2 counted on the low-res grid
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -135,8 +136,8 @@ class KernelTimer:
             # the Winograd form EXECUTES 12/18 of the direct form's multiply-adds for the same (algorithmic) convolution; the split form
             # (TE_CONV_3X3W6) executes them as SIX bf16 piece products each on the bf16 matrix pipe and none on the fp32 one
             # (TE_CONV_S2S6: no Winograd form, six piece products per multiply-add = 6x the algorithmic FLOPs on the bf16 pipe)
-            ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind in (_lib.CONV_3X3W6, _lib.CONV_S2S6, _lib.CONV_T2S6) else 1.0))
-            ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else (6.0 if kind in (_lib.CONV_S2S6, _lib.CONV_T2S6) else 0.0))
+            ex32 = flops * (2.0 / 3.0 if kind == _lib.CONV_3X3W else (0.0 if kind in (_lib.CONV_3X3W6, _lib.CONV_S2S6, _lib.CONV_T2S6, _lib.CONV_1X1S6) else 1.0))
+            ex16 = flops * (4.0 if kind == _lib.CONV_3X3W6 else (6.0 if kind in (_lib.CONV_S2S6, _lib.CONV_T2S6, _lib.CONV_1X1S6) else 0.0))
             timer.records.append((names[kind], flops, s, e, ex32, ex16))
             if kind == _lib.CONV_3X3W6:       # the dominant kernel on its own (a VIEW of the conv3x3 class, never summed with it)
                 timer.records.append(('conv3x3_split_bf16', flops, s, e, ex32, ex16))
@@ -144,6 +145,8 @@ class KernelTimer:
                 timer.records.append(('convS2_split_bf16', flops, s, e, ex32, ex16))
             if kind == _lib.CONV_T2S6:
                 timer.records.append(('convT2_split_bf16', flops, s, e, ex32, ex16))
+            if kind == _lib.CONV_1X1S6:
+                timer.records.append(('conv1x1_split_bf16', flops, s, e, ex32, ex16))
             return out
 
         def wgrad(g, x, kind, H, W, *a, **k):
@@ -1031,7 +1034,7 @@ def compact_line(out):
     cfg = out.get('config') or {}
     c = {'workload': str(cfg.get('workload', ''))[:300]}
     for k in ('global_batch', 'parallelism', 'per_gpu_images_per_sec', 'split_bf16', 'split_bf16_strided', 'split_bf16_transposed',
-              'split_bf16_weight_gradient_3x3', 'split_bf16_narrow_channels'):
+              'split_bf16_weight_gradient_3x3', 'split_bf16_1x1'):
         if k in cfg:
             c[k] = _num(cfg[k])
     if cfg.get('lazy_steps_in_window'):

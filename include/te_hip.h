@@ -161,6 +161,13 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
                             Shapes: te_conv_t2s6_supported; weights packed TE_PACK_T6FWD / TE_PACK_T6SWAP; never split; no residual / mask.
                             Reference: conv_transpose2d(stride 2) of ModulatedConv2d.forward, model_spatial_query.py:310-321 */
 
+#define TE_CONV_1X1S6 8   /* TE_CONV_1X1 with its products on the bf16 matrix pipe (round 6; three-piece split, six exact piece products per
+                            multiply-add, fp32 accumulation: fp32-equivalent like TE_CONV_3X3W6, same range / non-finite behaviour): the
+                            skip branch of the discriminator's ResBlocks and its data gradient.  Plain product + optional residual only
+                            (isc, osc, bias, mask_ref must be NULL, act 0).  Shapes: te_conv_p1s6_supported; weights packed
+                            TE_PACK_P6FWD / TE_PACK_P6DGRAD; never split.
+                            Reference: F.conv2d of EqualConv2d (1x1) in ResBlock.skip, model_spatial_query.py:173-181, :780-798 */
+
 /* how te_conv_pack_weights_f32 reads the source weight w[Co][Ci][kh][kw] (model layout,
  * ModulatedConv2d.weight[0]) */
 #define TE_PACK_FWD 0    /* M = Co, K = Ci, taps as stored         (forward 3x3 / 1x1 / T2, and S2) */
@@ -176,6 +183,9 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_PACK_S6SWAP 8 /* TE_CONV_S2S6 as data gradient of the transposed kind: M = Ci, K = Co, taps as stored                  */
 #define TE_PACK_T6FWD 9  /* TE_CONV_T2S6, M = Co, K = Ci: the TE_PACK_S6FWD layout followed (16-byte aligned) by the TE_PACK_FWD layout  */
 #define TE_PACK_T6SWAP 10 /* TE_CONV_T2S6 as data gradient of the strided kind: TE_PACK_S6SWAP followed by TE_PACK_SWAP                   */
+#define TE_PACK_P6FWD 11  /* TE_CONV_1X1S6, M = Co, K = Ci (1x1 weights): P6[K/16][piece][M/32][64 lanes][8 bf16] (3 K M bf16; Co % 32 == 0,
+                             Ci % 16 == 0)                                                                                                */
+#define TE_PACK_P6DGRAD 12 /* TE_CONV_1X1S6 as data gradient: M = Ci, K = Co (Ci % 32 == 0, Co % 16 == 0)                                  */
 
 int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize);
 int te_conv_pack_weights_f32(float* wp, const float* w, float wscale, int kind_pack, int Co, int Ci,
@@ -214,6 +224,8 @@ int te_conv_wino6_supported(int B, int K, int M, int H, int W);
 int te_conv_s2s6_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_T2S6 covers the problem (H, W = INPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
 int te_conv_t2s6_supported(int B, int K, int M, int H, int W);
+/* 1 if TE_CONV_1X1S6 covers the problem: K % 64 == 0, M % 128 == 0, H * W % 256 == 0 and a grid of at least half the CUs */
+int te_conv_p1s6_supported(int B, int K, int M, int H, int W);
 /* Kernel form of TE_CONV_3X3W6 (a DEBUG / A-B switch, process-wide - the one piece of mutable state behind this ABI besides
  * te_wgrad_split_bf16; the results do not depend on it; returns the previous value; anything but 0 .. 3 only queries):
  *   2 = two-image (round 6, default): as 1, but a block owns 128 output channels - every staged half tile is multiplied by two

@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libte_hip.so')
 _lib = None
 
-CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6, CONV_S2S6, CONV_T2S6 = 0, 1, 2, 3, 4, 5, 6, 7
+CONV_3X3, CONV_T2, CONV_S2, CONV_1X1, CONV_3X3W, CONV_3X3W6, CONV_S2S6, CONV_T2S6, CONV_1X1S6 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 (PACK_FWD, PACK_DGRAD, PACK_SWAP, PACK_WFWD, PACK_WDGRAD, PACK_W6FWD, PACK_W6DGRAD, PACK_S6FWD, PACK_S6SWAP, PACK_T6FWD,
- PACK_T6SWAP) = range(11)
+ PACK_T6SWAP, PACK_P6FWD, PACK_P6DGRAD) = range(13)
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
@@ -44,6 +44,7 @@ _SIGNATURES = {
     'te_conv_wino6_form': (C.c_int, [_I]),
     'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_t2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
+    'te_conv_p1s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_ws_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_conv_res_f32': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_slab_count': (C.c_int, [_I, _I, _I, _I, _I, _I]),
@@ -348,6 +349,11 @@ def s2s6_ok(B, K, M, H, W):
 def t2s6_ok(B, K, M, H, W):
     """does TE_CONV_T2S6 (the transposed stride-2 convolution on the bf16 matrix pipe) cover this problem?  H, W = input (low-res) size"""
     return bool(lib().te_conv_t2s6_supported(B, K, M, H, W))
+
+
+def p1s6_ok(B, K, M, H, W):
+    """does TE_CONV_1X1S6 (the 1x1 convolution on the bf16 matrix pipe) cover this problem?"""
+    return bool(lib().te_conv_p1s6_supported(B, K, M, H, W))
 
 
 def wino6_form(form=-1):

@@ -11,11 +11,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libte_hip.so')
-SOURCES = ['te_common.hip', 'bias_act.hip', 'upfirdn2d.hip', 'conv.hip', 'wino.hip', 'wino6.hip', 's2s6.hip', 't2s6.hip', 'wgrad.hip', 'wgrad6.hip', 'attention.hip', 'rgb.hip', 'linear.hip', 'style.hip', 'layernorm.hip', 'optim.hip', 'stddev.hip', 'chanscale.hip']
+SOURCES = ['te_common.hip', 'bias_act.hip', 'upfirdn2d.hip', 'conv.hip', 'wino.hip', 'wino6.hip', 's2s6.hip', 't2s6.hip', 'p1s6.hip', 'wgrad.hip', 'wgrad6.hip', 'attention.hip', 'rgb.hip', 'linear.hip', 'style.hip', 'layernorm.hip', 'optim.hip', 'stddev.hip', 'chanscale.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-pass-failed']
 # per-source flags.  wino6.hip: the staging arithmetic of the ping-pong kernel is written as scalar fp32 steps placed between MFMAs; the
 # SLP vectoriser would re-pack them into v_pk_* forms that need register shuffles and wait states
 EXTRA_FLAGS = {'wino6.hip': ['-fno-slp-vectorize'], 's2s6.hip': ['-fno-slp-vectorize'], 't2s6.hip': ['-fno-slp-vectorize'],
+               'p1s6.hip': ['-fno-slp-vectorize'],
                'wgrad6.hip': ['-fno-slp-vectorize']}
 
 

@@ -764,7 +764,8 @@ constexpr int PT = 32;
 template <int T>
 __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
     constexpr int RL = PT * T + 1, NE = PT * PT * T;
-    const bool fwd = q.kind == TE_PACK_FWD || q.kind == TE_PACK_WFWD || q.kind == TE_PACK_W6FWD || q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD;
+    const bool fwd = q.kind == TE_PACK_FWD || q.kind == TE_PACK_WFWD || q.kind == TE_PACK_W6FWD || q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD ||
+                     q.kind == TE_PACK_P6FWD;
     const bool t6 = q.kind == TE_PACK_T6FWD || q.kind == TE_PACK_T6SWAP;      // split layout + plain layout behind it
     const int Co = fwd ? q.M : q.K, Ci = fwd ? q.K : q.M;              // real extents of the source along co / ci
     const int CoP = fwd ? q.Mp : q.Kp, CiP = fwd ? q.Kp : q.Mp;        // padded extents of the packed layout (zero filled)
@@ -810,13 +811,14 @@ __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
                 const size_t ps = (size_t)12 * MT * 512;
                 dst[at] = (unsigned short)h; dst[at + ps] = (unsigned short)mm; dst[at + 2 * ps] = (unsigned short)ll;
             }
-        } else if (T == 9 && (q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_S6SWAP || t6)) {
-            // the taps as stored, every value split into three bf16 pieces, MFMA fragment order (s2s6.hip):
+        } else if ((T == 9 && (q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_S6SWAP || t6)) ||
+                   (T == 1 && (q.kind == TE_PACK_P6FWD || q.kind == TE_PACK_P6DGRAD))) {
+            // the taps as stored, every value split into three bf16 pieces, MFMA fragment order (s2s6.hip; T == 1: p1s6.hip):
             // S6[k / 16][piece][tap][m / 32][lane = m % 32 + 32 * (k % 16 / 8)][k % 8]; forward: m = co, k = ci; swap: m = ci, k = co
-            const bool wf = q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD;
+            const bool wf = q.kind == TE_PACK_S6FWD || q.kind == TE_PACK_T6FWD || q.kind == TE_PACK_P6FWD;
             unsigned short* dst = reinterpret_cast<unsigned short*>(q.wp);
             const int MT = q.M >> 5;
-            for (int e = threadIdx.x; e < PT * PT * 9; e += 256) {
+            for (int e = threadIdx.x; e < PT * PT * T; e += 256) {
                 const int j = e & 7, ml = (e >> 3) & 31, kh = (e >> 8) & 1, st = (e >> 9) & 1, tap = e >> 10;
                 const int kl = st * 16 + kh * 8 + j;                                    // k inside the tile
                 const int r = wf ? ml : kl, ii = wf ? kl : ml;                          // tile row = co, tile column = ci
@@ -832,9 +834,9 @@ __device__ __forceinline__ void pack_tiles(const PackJob& q, float* tile) {
                 const float r2 = r1 - __builtin_bit_cast(float, mm << 16);
                 u = __builtin_bit_cast(unsigned, r2);
                 const unsigned ll = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-                const size_t slot = ((size_t)(k >> 4) * 27 + tap) * MT + (m >> 5);                  // piece 0; piece stride 9 * MT slots
+                const size_t slot = ((size_t)(k >> 4) * 3 * T + tap) * MT + (m >> 5);               // piece 0; piece stride T * MT slots
                 const size_t at = slot * 512 + (size_t)((m & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
-                const size_t ps = (size_t)9 * MT * 512;
+                const size_t ps = (size_t)T * MT * 512;
                 dst[at] = (unsigned short)h; dst[at + ps] = (unsigned short)mm; dst[at + 2 * ps] = (unsigned short)ll;
             }
             if (t6) {      // TE_PACK_T6FWD / T6SWAP: the plain layout of the same weights behind the split one (thin fp32 regions of TE_CONV_T2S6)
@@ -899,15 +901,16 @@ struct PackDims { int K, M, Kp, Mp, ntap; };
 inline bool pack_is_wino6(int kind_pack) { return kind_pack == TE_PACK_W6FWD || kind_pack == TE_PACK_W6DGRAD; }
 inline bool pack_is_s6(int kind_pack) { return kind_pack == TE_PACK_S6FWD || kind_pack == TE_PACK_S6SWAP; }
 inline bool pack_is_t6(int kind_pack) { return kind_pack == TE_PACK_T6FWD || kind_pack == TE_PACK_T6SWAP; }
+inline bool pack_is_p6(int kind_pack) { return kind_pack == TE_PACK_P6FWD || kind_pack == TE_PACK_P6DGRAD; }
 inline bool pack_is_wino(int kind_pack) { return kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_WDGRAD || pack_is_wino6(kind_pack); }
 inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
     PackDims d;
     d.ntap = ksize * ksize;
     const bool fwd = kind_pack == TE_PACK_FWD || kind_pack == TE_PACK_WFWD || kind_pack == TE_PACK_W6FWD || kind_pack == TE_PACK_S6FWD ||
-                     kind_pack == TE_PACK_T6FWD;
+                     kind_pack == TE_PACK_T6FWD || kind_pack == TE_PACK_P6FWD;
     d.M = fwd ? Co : Ci;
     d.K = fwd ? Ci : Co;
-    if (pack_is_wino(kind_pack) || pack_is_s6(kind_pack)) {          // U[K/8][ky][component][8][M]: no padding (K % 8 == 0, M % 128 == 0 are required)
+    if (pack_is_wino(kind_pack) || pack_is_s6(kind_pack) || pack_is_p6(kind_pack)) {          // U[K/8][ky][component][8][M]: no padding (K % 8 == 0, M % 128 == 0 are required)
         d.Kp = d.K; d.Mp = d.M;
     } else {
         d.Kp = roundup(d.K, KPAD);
@@ -1088,6 +1091,7 @@ extern "C" int64_t te_conv_packed_numel(int kind_pack, int Co, int Ci, int ksize
     const PackDims d = pack_dims(kind_pack, Co, Ci, ksize);
     // (the split layouts: 3 pieces x 12 x K x M bf16 = 18 K M floats)
     if (pack_is_s6(kind_pack)) return ((int64_t)27 * d.Kp * d.Mp + 1) / 2;          // 3 pieces x 9 taps x K x M bf16
+    if (pack_is_p6(kind_pack)) return ((int64_t)3 * d.Kp * d.Mp + 1) / 2;           // 3 pieces x K x M bf16
     if (pack_is_t6(kind_pack)) return t6_plain_offset(d.K, d.M) + (int64_t)d.ntap * d.Kp * d.Mp;
     return (int64_t)(pack_is_wino6(kind_pack) ? 18 : (pack_is_wino(kind_pack) ? 12 : d.ntap)) * d.Kp * d.Mp;
 }
@@ -1127,7 +1131,10 @@ static int pack_launch(const char* what, int n, float* const* wp, const float* c
             const int e = base + i;
             TE_REQUIRE(wp[e] && w[e], TE_ERR_NULL, "%s: NULL pointer in job %d", what, e);
             TE_REQUIRE(Co[e] > 0 && Ci[e] > 0 && (ksize[e] == 1 || ksize[e] == 3), TE_ERR_SHAPE, "%s: bad dims in job %d", what, e);
-            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 10, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(kind_pack[e] >= 0 && kind_pack[e] <= 12, TE_ERR_UNSUPPORTED, "%s: bad kind in job %d", what, e);
+            TE_REQUIRE(!pack_is_p6(kind_pack[e]) || (ksize[e] == 1 && (kind_pack[e] == TE_PACK_P6FWD ? (Co[e] % 32 == 0 && Ci[e] % 16 == 0)
+                                                                                                    : (Ci[e] % 32 == 0 && Co[e] % 16 == 0))),
+                       TE_ERR_UNSUPPORTED, "te_conv_pack_weights: the split layouts of TE_CONV_1X1S6 need a 1x1 weight with M %% 32 == 0 and K %% 16 == 0");
             TE_REQUIRE(!pack_is_t6(kind_pack[e]) || (ksize[e] == 3 && (kind_pack[e] == TE_PACK_T6FWD ? (Co[e] % 32 == 0 && Ci[e] % 16 == 0)
                                                                                                     : (Ci[e] % 32 == 0 && Co[e] % 16 == 0))),
                        TE_ERR_UNSUPPORTED, "te_conv_pack_weights: the split layouts of TE_CONV_T2S6 need a 3x3 weight with M %% 32 == 0 and K %% 16 == 0");
@@ -1221,8 +1228,8 @@ static SideStream* side_stream() {
 }
 
 extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
-    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 7) return TE_ERR_SHAPE;
-    if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6 || kind == TE_CONV_T2S6) return 1;
+    if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 8) return TE_ERR_SHAPE;
+    if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6 || kind == TE_CONV_T2S6 || kind == TE_CONV_1X1S6) return 1;
     return conv_plan(kind, B, K, M, H, W).ksplit;
 }
 
@@ -1234,8 +1241,13 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
                "te_conv_res_f32: no residual / mask epilogue for the transposed kind");
     TE_REQUIRE(B > 0 && K > 0 && M > 0 && H > 0 && W > 0, TE_ERR_SHAPE, "te_conv_f32: bad dims");
     TE_REQUIRE(act == 0 || act == 3 || act == 4, TE_ERR_UNSUPPORTED, "te_conv_f32: act must be 0, 3 or 4");
-    TE_REQUIRE(kind >= 0 && kind <= 7, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
+    TE_REQUIRE(kind >= 0 && kind <= 8, TE_ERR_UNSUPPORTED, "te_conv_f32: unknown kind %d", kind);
     hipStream_t s = (hipStream_t)stream_;
+    if (kind == TE_CONV_1X1S6) {
+        TE_REQUIRE(!isc && !osc && !bias && !mask_ref && act == 0, TE_ERR_UNSUPPORTED,
+                   "te_conv_f32(TE_CONV_1X1S6): plain product + residual only (no scales, bias, activation or mask)");
+        return te_p1s6_launch(out, in, wp, res, B, K, M, H, W, s);
+    }
     if (kind == TE_CONV_3X3W) return te_wino_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);
     if (kind == TE_CONV_3X3W6) return te_wino6_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);
     if (kind == TE_CONV_S2S6) return te_s2s6_launch(out, in, wp, isc, osc, bias, res, mask_ref, mask_gain, act, B, K, M, H, W, s);

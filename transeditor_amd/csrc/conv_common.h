@@ -37,3 +37,6 @@ int te_s2s6_launch(float* out, const float* in, const float* U, const float* isc
 // last output row / column through the fp32 kernel), weights packed TE_PACK_T6FWD / TE_PACK_T6SWAP
 int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
                    int B, int K, int M, int H, int W, hipStream_t s);
+// csrc/p1s6.hip (round 6): the 1x1 convolution on the bf16 matrix pipe (three-piece split: fp32-equivalent), plain product + optional
+// residual; kind TE_CONV_1X1S6, weights packed TE_PACK_P6FWD / TE_PACK_P6DGRAD in MFMA fragment order
+int te_p1s6_launch(float* out, const float* in, const float* U, const float* res, int B, int K, int M, int H, int W, hipStream_t s);

@@ -343,6 +343,20 @@ def fwd_kinds(kind, B, w, H, W):
     return _lib.PACK_FWD, _KIND[kind]
 
 
+# TE_SPLIT_1X1=0: the 1x1 launches stay on the fp32 matrix instructions (A/B)
+USE_SPLIT_1X1 = os.environ.get('TE_SPLIT_1X1', '1') != '0'
+
+
+def plain_1x1_kinds(B, w, H, W, dgrad=False):
+    """(pack kind, convolution kind) of a PLAIN 1x1 product - no scales, bias or activation, at most a residual: the skip branch of the
+    discriminator's ResBlocks (op/resblock.py) - forward (Ci -> Co) or data gradient (Co -> Ci): the split-bf16 kernel of csrc/p1s6.hip
+    (round 6) where it applies, the fp32 kernel elsewhere"""
+    K, M = (w.shape[0], w.shape[1]) if dgrad else (w.shape[1], w.shape[0])
+    if USE_SPLIT_BF16 and USE_SPLIT_1X1 and _lib.p1s6_ok(B, K, M, H, W):
+        return (_lib.PACK_P6DGRAD if dgrad else _lib.PACK_P6FWD), _lib.CONV_1X1S6
+    return (_lib.PACK_DGRAD if dgrad else _lib.PACK_FWD), _lib.CONV_1X1
+
+
 # TE_SPLIT_S2=0: the stride-2 launches stay on the fp32 matrix instructions while the 3x3 stride-1 ones keep the split form (A/B)
 USE_SPLIT_S2 = os.environ.get('TE_SPLIT_S2', '1') != '0'
 USE_SPLIT_T2 = os.environ.get('TE_SPLIT_T2', '1') != '0'

@@ -25,7 +25,8 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .modconv import _bwd_pack_kind, _composite, _dgrad_raw, _wgrad_plain, bwd_kinds, cache_of, fwd_kinds, keep_cache, packed, packed2
+from .modconv import (_composite, _dgrad_raw, _wgrad_plain, bwd_kinds, cache_of, fwd_kinds, keep_cache, packed, packed2,
+                      plain_1x1_kinds)
 from .upfirdn2d import _geometry, flipped_taps, upfirdn2d
 
 _SQRT2 = math.sqrt(2.0)
@@ -85,11 +86,14 @@ class _ResBlock(Function):
         xs = _lib.upfirdn2d_raw(x, k_skip, (1, 1), (2, 2), ps)
         if xs.shape[2:] != y2.shape[2:]:
             raise RuntimeError(f'resblock: branch sizes differ {tuple(xs.shape[2:])} vs {tuple(y2.shape[2:])}')
+        # the skip branch's 1x1 product (+ the main branch as its residual) and, in backward, its data gradient: the split-bf16 kernel
+        # of csrc/p1s6.hip where it applies (round 6)
+        pks, cks = plain_1x1_kinds(x.shape[0], ws, xs.shape[2], xs.shape[3])
         if need_x:
-            wps, wpsb = packed2(ws, _lib.PACK_FWD, _bwd_pack_kind('1x1'), ss * gain)
+            wps, wpsb = packed2(ws, pks, plain_1x1_kinds(x.shape[0], ws, xs.shape[2], xs.shape[3], dgrad=True)[0], ss * gain)
         else:
-            wps, wpsb = packed(ws, _lib.PACK_FWD, ss * gain), None
-        out = _lib.conv(xs, wps, _lib.CONV_1X1, ws.shape[0], xs.shape[2], xs.shape[3], None, None, None, 0, res=y2)
+            wps, wpsb = packed(ws, pks, ss * gain), None
+        out = _lib.conv(xs, wps, cks, ws.shape[0], xs.shape[2], xs.shape[3], None, None, None, 0, res=y2)
         ctx.save_for_backward(x, w1, b1, w2, b2, ws, k_main, k_skip, y1, yb, y2, xs, img, w0, b0)
         ctx.packs = (wp1b, wp2b, wpsb)
         ctx.cfg = (s1, s2, ss, tuple(pad_main), tuple(pad_skip), gain, pm, ps, s0, need_x)
@@ -144,7 +148,8 @@ class _ResBlock(Function):
             gws = _wgrad_plain(g, xs, '1x1', 1, ss * gain)
         gw0 = gb0 = None
         if need_x:
-            g_xs = _dgrad_raw(g, ws, '1x1', wscale=ss * gain, wp=wpsb)
+            g_xs = _lib.conv(g, wpsb, plain_1x1_kinds(x.shape[0], ws, xs.shape[2], xs.shape[3], dgrad=True)[1], ws.shape[1],
+                             xs.shape[2], xs.shape[3])
             _, gp_s = _geometry(x.shape[2:], k_skip.shape, (1, 1), (2, 2), ps)
             gx_b = _lib.upfirdn2d_raw(g_xs, flipped_taps(k_skip), (2, 2), (1, 1), gp_s)
             # data gradient of conv1 + the skip branch's gradient in its epilogue (+ the stem's activation gradient)
