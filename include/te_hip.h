@@ -176,10 +176,12 @@ int te_upfirdn2d_f64(double* out, const double* x, const double* k, int64_t majo
 #define TE_PACK_WFWD 3   /* TE_CONV_3X3W forward:       U[K/8][ky][c][8][M], U[ky][c] = G w[.., ky, :]  (12 K M floats)  */
 #define TE_PACK_WDGRAD 4 /* TE_CONV_3X3W data gradient: the same transform of the flipped, transposed taps (M = Ci)     */
 #define TE_PACK_W6FWD 5  /* TE_CONV_3X3W6 forward: U = G w split into bf16 pieces, MFMA fragment order
-                            U6[K/16][piece][ky][c][M/32][64 lanes][8 bf16]  (36 K M bf16 = 18 K M floats; Co % 32 == Ci % 32 == 0) */
+                            U6[K/16][piece][ky][c][M/32][64 lanes][8 bf16]  (36 K M bf16 = 18 K M floats).  The packing accepts
+                            Co % 32 == Ci % 32 == 0; the kernel (te_conv_wino6_supported) needs K % 32 == 0, M % 64 == 0                */
 #define TE_PACK_W6DGRAD 6 /* TE_CONV_3X3W6 data gradient (flipped, transposed taps; M = Ci)                               */
 #define TE_PACK_S6FWD 7  /* TE_CONV_S2S6, M = Co, K = Ci, taps as stored: three bf16 pieces per weight, MFMA fragment order
-                            S6[K/16][piece][tap][M/32][64 lanes][8 bf16]  (27 K M bf16; Co % 32 == Ci % 32 == 0)                  */
+                            S6[K/16][piece][tap][M/32][64 lanes][8 bf16]  (27 K M bf16).  The packing accepts M % 32 == 0, K % 16 == 0;
+                            the kernel (te_conv_s2s6_supported) needs M % 64 == 0, K % 16 == 0, K >= 32                                 */
 #define TE_PACK_S6SWAP 8 /* TE_CONV_S2S6 as data gradient of the transposed kind: M = Ci, K = Co, taps as stored                  */
 #define TE_PACK_T6FWD 9  /* TE_CONV_T2S6, M = Co, K = Ci: the TE_PACK_S6FWD layout followed (16-byte aligned) by the TE_PACK_FWD layout  */
 #define TE_PACK_T6SWAP 10 /* TE_CONV_T2S6 as data gradient of the strided kind: TE_PACK_S6SWAP followed by TE_PACK_SWAP                   */

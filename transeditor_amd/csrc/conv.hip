@@ -910,7 +910,9 @@ inline PackDims pack_dims(int kind_pack, int Co, int Ci, int ksize) {
                      kind_pack == TE_PACK_T6FWD || kind_pack == TE_PACK_P6FWD;
     d.M = fwd ? Co : Ci;
     d.K = fwd ? Ci : Co;
-    if (pack_is_wino(kind_pack) || pack_is_s6(kind_pack) || pack_is_p6(kind_pack)) {          // U[K/8][ky][component][8][M]: no padding (K % 8 == 0, M % 128 == 0 are required)
+    // the Winograd layouts (fp32: U[K/8][ky][component][8][M], K % 8 == 0 and M % 8 == 0) and the split fragment-order layouts (W6 / S6 /
+    // P6: [K/16][piece][...][M/32][64 lanes][8 bf16], M % 32 == 0 and K % 16 == 0 - 32 for W6) are not padded: pack_launch checks the multiples
+    if (pack_is_wino(kind_pack) || pack_is_s6(kind_pack) || pack_is_p6(kind_pack)) {
         d.Kp = d.K; d.Mp = d.M;
     } else {
         d.Kp = roundup(d.K, KPAD);

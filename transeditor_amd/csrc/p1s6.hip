@@ -14,11 +14,16 @@
 //   block   512 threads = two groups of four waves; tile = 128 output channels (two weight images of 64) x 256 pixels (two halves of 128)
 //   stage   64 input channels = four MFMA K steps; wave (wm, wn) of a group = 32 channels x 64 pixels (two B fragments) per image:
 //           4 K steps x 2 fragments x 6 products = 48 MFMAs per multiplying phase, 3 + 6 operand reads per 12 MFMAs
-//   LDS     one weight image U[k step 4][piece 3][M tile 2][64 lanes][8 bf16] = 24 KB, renewed in two halves (k steps 0-1 / 2-3) by LDS-DMA under
-//           the same hand-over protocol as wino6q (image index j = 2 s + m); two half tiles T[piece 3][k step 4][k half 2][128][8 bf16] = 48 KB
+//   LDS     TWO weight images U[k step 4][piece 3][M tile 2][64 lanes][8 bf16] = 24 KB each (image j = 2 s + m lives in buffer j & 1), two half
+//           tiles T[piece 3][k step 4][k half 2][128][8 bf16] = 48 KB each: 144 KB.  A weight image is small here, so it is DOUBLE-BUFFERED instead of
+//           renewed half by half inside the phase that still reads it (wino6q's protocol, which leaves the LDS-DMA half a phase - less than its
+//           issue + L2 latency - and needs a mid-phase barrier): image j + 1 goes to the buffer image j - 1 was read from, half of its slots
+//           issued by group 1 at the start of phase 2 j, the other half by group 0 at the start of phase 2 j + 1, each waited for at the END of
+//           the issuing group's staging phase - a whole phase for every transfer, ONE barrier per phase
 //   phases  group 0:  M0(s) SA M1(s) SB      group 1:  S M0(s) SA M1(s) SB        (one phase behind, the same straight-line loop body)
 //           M0 / M1: 48 MFMAs with image 0 / 1 + half of the staging arithmetic of stage s + 1 each (32 of its 64 slots) + the fetch of stage
 //           s + 2 behind the last slot that reads an item's registers;  SA: weight DMA;  SB: weight DMA + the split pieces -> T(s + 1)
+//           (first version, same box: half-by-half renewal + mid-phase barrier - profiles/experiments/r06_p1s6_check.log)
 //   staging ONE item per thread and stage: 8 channels x 4 consecutive pixels (eight 16-byte loads, 512 contiguous bytes per channel and
 //           half wave); the item's four pixels end up as four whole 16-byte LDS elements per piece (ds_write_b128: 12 writes per stage).
 //           Pixel 4 q + e of the half tile lives at position 32 e + q, so the 32 lanes of a write fill 512 contiguous bytes, and a wave's two
@@ -35,7 +40,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WT = 512, GT = 256, KS = 64, NKS = 4, BM = 64, TPX = 256, HPX = 128;
-constexpr int U_SLOTS = NKS * 3 * 2;                     // 24 fragment slots of 1 KB
+constexpr int U_SLOTS = NKS * 3 * 2;                     // 24 fragment slots of 1 KB per weight image; two images in LDS
 constexpr int T_CHUNKS = 3 * NKS * 2 * HPX;              // 16-byte chunks of a half tile: 3 072 = 48 KB
 constexpr int N_SLOT = 64;                               // 16 units (4 channel pairs x 4 pixels) x 4 steps
 
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wn = wq & 1, gt = tid & (GT - 1);
-    u32x4* tl = reinterpret_cast<u32x4*>(smem_raw + U_SLOTS * 1024) + grp * T_CHUNKS;   // this group's half tile
+    u32x4* tl = reinterpret_cast<u32x4*>(smem_raw + 2 * U_SLOTS * 1024) + grp * T_CHUNKS;   // this group's half tile
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int tq = jx / p.mblocks, mbq = jx % p.mblocks;
     const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
@@ -82,15 +87,16 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
         for (int c = 0; c < 4; ++c)
             rin[4 * hh + c] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KS + 4 * hh + c) * plane + g_off);
     };
-    // weight half `uh` (k steps 2 uh, 2 uh + 1) of image j = 2 s + m: 12 fragment slots, 3 per wave of the group
+    // part `uh` (k steps 2 uh, 2 uh + 1) of image j = 2 s + m into buffer j & 1: 12 fragment slots, 3 per wave of the group
     auto issue_u = [&](int uh, int j) {
         const int mb = 2 * mbq + (j & 1);
+        u32x4* ub = ul + (j & 1) * (U_SLOTS * 64);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int jw = wq * 3 + r, ksl = 2 * uh + jw / 6, piece = (jw % 6) >> 1, mt = jw & 1;
             const u32x4* g = p.U + ((size_t)(((j >> 1) * NKS + ksl) * 3 + piece) * MT + 2 * mb + mt) * 64 + (unsigned)lane;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(ul + ((ksl * 3 + piece) * 2 + mt) * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ub + ((ksl * 3 + piece) * 2 + mt) * 64), 16, 0, 0);
         }
     };
     // ---- the staging arithmetic: 64 slots = 16 units x 4 steps; unit u = channel pair (u >> 2) x pixel (u & 3) of the item
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
                 tl[w_chunk + pc * (NKS * 2 * HPX) + e * 32] = v;
             }
     };
-    const int a_chunk = wm * 64 + lane;                                  // + ((k step * 3 + piece) * 2) * 64
+    const int a_chunk = wm * 64 + lane;                                  // + ((k step * 3 + piece) * 2) * 64 + image buffer
     const int b_chunk = half * HPX + wn * 64 + l31;                      // + (piece * NKS + k step) * 2 * HPX + n * 32
 
     // one multiplying phase with accumulator set MSET.  Behind the MFMAs: slots 32 MSET .. 32 MSET + 31 of the staging arithmetic (the
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
     auto multiply = [&](auto mset_tag, int fs) {
         constexpr int MSET = decltype(mset_tag)::value;
         bf16x8 av[2][3], bv[2][2][3];
-        auto rd_a = [&](int ks, int pc) { av[ks & 1][pc] = __builtin_bit_cast(bf16x8, ul[a_chunk + (ks * 3 + pc) * 128]); };
+        const u32x4* ua = ul + MSET * (U_SLOTS * 64) + a_chunk;            // (image j = 2 s + MSET: buffer j & 1 == MSET)
+        auto rd_a = [&](int ks, int pc) { av[ks & 1][pc] = __builtin_bit_cast(bf16x8, ua[(ks * 3 + pc) * 128]); };
         auto rd_b = [&](int ks, int n, int pc) { bv[ks & 1][n][pc] = __builtin_bit_cast(bf16x8, tl[b_chunk + (pc * NKS + ks) * 2 * HPX + n * 32]); };
         constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
 #pragma unroll
@@ -147,13 +154,6 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            if (ks == 2) {
-                // mid-phase barrier, in front of the first read of weight half b (k steps 2, 3): the B operands of this k step were read
-                // behind the previous one's MFMAs, the A operands follow the barrier
-                p1_barrier();
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) rd_a(2, pc);
-            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
 #ifndef P1_SKIP_MFMA
                     acc[MSET][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][PA[q]], bv[ks & 1][n][PB[q]], acc[MSET][n], 0, 0, 0);
 #endif
-                    if (ks + 1 < NKS && i < 9) {                         // operands of the next k step: 3 + 6 reads (A of k step 2: see above)
-                        if (i < 3) { if (ks + 1 != 2) rd_a(ks + 1, i); }
+                    if (ks + 1 < NKS && i < 9) {                         // operands of the next k step: 3 + 6 reads
+                        if (i < 3) rd_a(ks + 1, i);
                         else rd_b(ks + 1, (i - 3) / 3, (i - 3) % 3);
                     }
 #ifndef P1_SKIP_ARITH
@@ -180,22 +180,17 @@ __global__ __launch_bounds__(WT, 2) void p1s6_kernel(const P1Args p) {
         __builtin_amdgcn_s_setprio(0);
         p1_barrier();                                    // end of phase
     };
-    // one phase in the staging role (wino6q_kernel: stage): image cs = (ph + 1) >> 1; group 1 (even ph) renews weight half b of image cs
-    // in FRONT of the mid-phase barrier, group 0 (odd ph) half a of image cs BEHIND it; `write`: the split pieces go to the half tile
+    // one phase in the staging role.  In phase ph the other group multiplies with image ph >> 1; this group brings in its part (ph & 1:
+    // group 1 part 0 in even phases, group 0 part 1 in odd ones) of image (ph >> 1) + 1, whose buffer was last read in phase ph - 1 (ph even)
+    // / ph - 2 (ph odd), and waits for it at the end of the phase.  `write`: the split pieces go to the half tile.
     auto stage = [&](int ph, bool write) {
-        const int cs = (ph + 1) >> 1;
-        const bool work = cs >= 1 && cs < nimg;
-        if (grp == 1 && work) issue_u(1, cs);
+        const int cs = (ph >> 1) + 1;
+        if (cs < nimg) issue_u(ph & 1, cs);
         __builtin_amdgcn_sched_barrier(0);
 #ifndef P1_SKIP_ARITH
         if (write) write_res();
 #endif
-        if (grp == 1 && work) p1_wait_vm();
-        p1_barrier();                                    // mid-phase
-        if (grp == 0 && work) {
-            issue_u(0, cs);
-            p1_wait_vm();
-        }
+        p1_wait_vm();     // (also waits for the fetch of the next stage issued in this group's last multiplying phase: long landed)
         p1_barrier();                                    // end of phase
     };
 
@@ -265,7 +260,7 @@ int te_p1s6_launch(float* out, const float* in, const float* U, const float* res
     a.ntiles = B * a.tiles_per_sample;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    const size_t lds = (size_t)U_SLOTS * 1024 + 2 * (size_t)T_CHUNKS * 16;
+    const size_t lds = 2 * (size_t)U_SLOTS * 1024 + 2 * (size_t)T_CHUNKS * 16;
     static std::atomic<uint64_t> attr_done{0};
     te::allow_big_lds(attr_done, (const void*)p1s6_kernel, 160 * 1024);
     p1s6_kernel<<<dim3((unsigned)blocks), WT, lds, s>>>(a);
