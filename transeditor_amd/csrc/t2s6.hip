@@ -14,8 +14,20 @@
 // two half tiles of 4 cell rows (5 input rows x 17 columns each with the halo), wave (wm, wrl) of a group = 32 channels x cell rows
 // {2 wrl, 2 wrl + 1} x 16 columns x 4 phases (64 accumulator registers); 54 MFMAs per wave and stage of 16 input channels; the staging
 // arithmetic of a half (200 items: one per thread) rides behind the multiplying wave's own MFMAs; weights 54 KB per stage by LDS-DMA
-// in two halves (taps 0-4 / 5-8).  Input tile in LDS: T[piece][row 5][k half][24 columns (17 used)][8 bf16] - two rows are 48 chunks,
+// in two parts (taps 0-4 / 5-8).  Input tile in LDS: T[piece][row 5][k half][24 columns (17 used)][8 bf16] - two rows are 48 chunks,
 // a multiple of 16, so the two cell rows of a B fragment never collide (conflict-free ds_read_b128).
+//
+// Round 6: the weight image is DOUBLE-BUFFERED (2 x 54 KB + 2 x 11.25 KB of half tiles = 130.5 KB).  The round-5 kernel renewed the one image
+// half by half inside the phases that still read it (wino6.hip's protocol): every LDS-DMA had half a phase (~1 200 cycles) for ~1 500 - 1 750
+// cycles of issue + L2 latency, and the phase profile showed the difference on the critical path of BOTH phases (the multiplying group waits
+// ~770 cycles at the mid-phase barrier of X, the staging group's DMA outlasts the partner's MFMAs by ~340 in Y: ~15 % of a stage,
+// profiles/experiments/r06_st_phase_profile_before.log).  Now stage s + 1 goes to the buffer stage s - 1 was read from: part 0 issued by
+// group 1 at the start of phase 2 s, part 1 by group 0 at the start of phase 2 s + 1, each waited for at the end of the issuing group's
+// staging phase - a whole phase per transfer, and ONE barrier per phase (the mid-phase barrier is gone).  Measured (same tool,
+// profiles/experiments/r06_st_phase_profile_t2s6_double_buffered.log): 6 553 -> 5 350 cycles per stage at 512 -> 512 @32^2, 6 962 -> 5 633 at
+// 128 -> 128 @128^2 under the phase profiler - and the un-profiled launch times did not move (158 - 166 TFLOP/s before and after,
+// r06_t2s6_check_double_buffered.log): the kernel sits at the part's power limit, the saved cycles came back as a lower clock.  Kept for
+// the simpler protocol.  (s2s6.hip keeps the half-by-half protocol: two of its 54 KB images do not fit beside its 61 KB of half tiles.)
 #include "conv_common.h"
 
 namespace {
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform by construction: keep the role branches scalar
     const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wrl = wq & 1, gt = tid & (GT - 1);
-    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + U_SLOTS * 1024) + grp * TP_DWORDS;      // this group's half tile
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + 2 * U_SLOTS * 1024) + grp * TP_DWORDS;  // this group's half tile (behind the two weight images)
     const u32x4* tl4 = reinterpret_cast<const u32x4*>(tl);
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int tq = jx / p.mblocks, mb = jx % p.mblocks;
@@ -116,9 +128,10 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
         for (int h2 = 0; h2 < 2; ++h2) rin[h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * iplane + g_off);
     };
     auto issue = [&](int s) { fetch_scales(s); fetch_item(s); };
-    // weight half `uh` of stage s: uh = 0: taps 0-4 (30 slots: 8 / 8 / 7 / 7 per wave), uh = 1: taps 5-8 (24 slots: 6 per wave)
+    // weight part `uh` of stage s into buffer s & 1: uh = 0: taps 0-4 (30 slots: 8 / 8 / 7 / 7 per wave), uh = 1: taps 5-8 (24 slots: 6 per wave)
     auto issue_u = [&](int uh, int s) {
         const u32x4* us = p.U + (size_t)s * 27 * MT * 64;
+        u32x4* ub = ul + (s & 1) * (U_SLOTS * 64);
         const int ntap = uh ? NTAP - UA_TAPS : UA_TAPS, tap0 = uh ? UA_TAPS : 0, n = ntap * 6;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
             const int pt = piece * NTAP + tap;
             const u32x4* g = us + ((size_t)pt * MT + 2 * mb + mt) * 64 + (unsigned)lane;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(ul + (pt * 2 + mt) * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ub + (pt * 2 + mt) * 64), 16, 0, 0);
         }
     };
     // ---- the staging arithmetic as a program of 17 slots behind the MFMAs of the multiplying phase (wino6.hip):
@@ -211,9 +224,10 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
             // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of the stage after (rin -> res)
             bf16x8 av[2][3], bv[2][3];
             const int fs2 = min((ph >> 1) + 2, nstage - 1);
+            const u32x4* ua = ul + ((ph >> 1) & 1) * (U_SLOTS * 64) + a_chunk;          // this stage's weight image
             auto rd1 = [&](int t, int slot, int qq) {
                 const int ky = t / 3, kx = t % 3;
-                if (qq < 3) av[slot][qq] = __builtin_bit_cast(bf16x8, ul[a_chunk + (qq * NTAP + t) * 128]);
+                if (qq < 3) av[slot][qq] = __builtin_bit_cast(bf16x8, ua[(qq * NTAP + t) * 128]);
                 else bv[slot][qq - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk - (ky == 2 ? 2 * CW : 0) - (kx == 2 ? 1 : 0) + (qq - 3) * (TP_PLANE / 4)]);
             };
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
@@ -223,11 +237,6 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 const int slot = t & 1, c = ((t / 3) & 1) * 2 + ((t % 3) & 1);          // output phase of the tap
-#ifdef T2_PROF
-                if (t == UA_TAPS - 1) { T2_T(ta); t2_barrier(); T2_T(tb); T2_ACC(0, t0, ta); T2_ACC(1, ta, tb); pc[2] -= tb; }
-#else
-                if (t == UA_TAPS - 1) t2_barrier();    // mid-phase barrier: in front of tap 4's MFMAs (operands read) and of the first read of half b
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int qq = 0; qq < 6; ++qq) {
@@ -247,37 +256,24 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
             }
             __builtin_amdgcn_s_setprio(0);
 #ifdef T2_PROF
-            { asm volatile("s_nop 0" ::: "memory"); T2_T(tc); pc[2] += tc; }
+            { asm volatile("s_nop 0" ::: "memory"); T2_T(tc); T2_ACC(0, t0, tc); }
 #endif
         } else {
-            // ---- stage: move this group's half of stage cs = (ph + 1) / 2 to LDS, fetch stage cs + 1, renew a half of the weight image
-            const int cs = (ph + 1) >> 1;
-            const bool work = cs >= 1 && cs < nstage;
-            // group 1 renews weight half b in front of the mid-phase barrier: DMA first, the LDS writes of this half tile in its shadow,
-            // then the wait for the DMA; group 0 renews half a behind the barrier.  The LDS writes are unconditional (s2s6.hip).
+            // ---- stage: move this group's half of stage (ph + 1) / 2 to LDS; bring in this group's part (ph & 1: group 1 part 0 in even
+            // phases, group 0 part 1 in odd ones) of the weights of stage (ph >> 1) + 1, into the buffer stage (ph >> 1) - 1 was read
+            // from (last read in phase ph - 1 / ph - 2); waited for at the end of THIS phase.  The LDS writes are unconditional (s2s6.hip).
+            const int cw = (ph >> 1) + 1;
 #ifndef ST_NO_DMA
-            if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
-            if (work && grp == 1) issue_u(1, cs);
-            if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (cw < nstage) issue_u(ph & 1, cw);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #ifndef ST_NO_DSW
             write_res();
 #endif
-            if (work && grp == 1) t2_wait_vm();
             T2_T(ta);
-            t2_barrier();
+            t2_wait_vm();
             T2_T(tb);
-#ifndef ST_NO_DMA
-            if (work && grp == 0) {
-                if (DMA_PRIO) __builtin_amdgcn_s_setprio(DMA_PRIO);
-                issue_u(0, cs);
-                if (DMA_PRIO) __builtin_amdgcn_s_setprio(0);
-                t2_wait_vm();
-            }
-#endif
-            T2_T(tc);
-            T2_ACC(3, t0, ta); T2_ACC(4, ta, tb); T2_ACC(5, tb, tc);
+            T2_ACC(3, t0, ta); T2_ACC(4, ta, tb);
         }
         T2_T(t8);
         if (!last) t2_barrier();
@@ -350,7 +346,7 @@ int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc
     a.ntiles = B * a.tiles_x * a.tiles_y;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
-    const size_t lds = (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
+    const size_t lds = 2 * (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
     static std::atomic<uint64_t> attr_done{0};
     if (isc) {
         static std::atomic<uint64_t> attr_done_sc{0};
