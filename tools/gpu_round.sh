@@ -20,7 +20,18 @@ rm -rf gpurun_out/pmc
 bash tools/pmc_round.sh > gpurun_out/${TAG}_pmc_round.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc gpurun_out/${TAG} > gpurun_out/${TAG}_pmc_summary_stdout.txt 2>&1
 rm -f gpurun_out/pmc/*.db gpurun_out/pmc/*.csv
-( FORM2=1 timeout 120 python tools/wino6_ab.py; timeout 120 python tools/s2s6_check.py; timeout 120 python tools/t2s6_check.py; timeout 200 python tools/wgrad6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_split_kernels_check.log
+( FORM2=1 timeout 120 python tools/wino6_ab.py; timeout 120 python tools/s2s6_check.py; timeout 120 python tools/t2s6_check.py; timeout 200 python tools/wgrad6_check.py; timeout 200 python tools/p1s6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_split_kernels_check.log
+for f in old new; do
+  if [ $f = old ]; then export TE_W6_FORM=1 TE_SPLIT_1X1=0; else unset TE_W6_FORM TE_SPLIT_1X1; fi
+  timeout 300 python bench.py --steps 16 --warmup 4 --no-sub --no-cpu-baseline --no-pmc > gpurun_out/${TAG}_bench_quick_r6_switches_$f.json 2>/dev/null
+done
+unset TE_W6_FORM TE_SPLIT_1X1
+( timeout 120 python tools/power_probe.py ) > gpurun_out/${TAG}_power_clock_product.txt 2>&1
+python - <<PY
+import json
+for f in ("old","new"):
+    d=json.loads(open("gpurun_out/${TAG}_bench_quick_r6_switches_%s.json" % f).read().strip().splitlines()[-1]); print("quick A/B", f, d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"])
+PY
 python - <<PY
 import json
 t=open("gpurun_out/${TAG}_bench_n1.json").read().strip().splitlines()

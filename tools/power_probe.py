@@ -90,7 +90,7 @@ def kernels():
         isc, osc, bias = torch.rand(B, K, device=DEV) + 0.5, torch.rand(B, M, device=DEV) + 0.5, torch.randn(M, device=DEV)
         fl = 2.0 * 9 * K * M * H * H * B
         u6 = _lib.conv_pack(w, _lib.PACK_W6FWD)
-        out.append((f'wino6p 3x3 {K}->{M} @{H}', (lambda x=x, u6=u6, M=M, H=H, isc=isc, osc=osc, bias=bias: _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, H, isc, osc, bias, 3)), fl, 4.0, 0.0))
+        out.append((f'wino6q 3x3 {K}->{M} @{H}', (lambda x=x, u6=u6, M=M, H=H, isc=isc, osc=osc, bias=bias: _lib.conv(x, u6, _lib.CONV_3X3W6, M, H, H, isc, osc, bias, 3)), fl, 4.0, 0.0))
         if H == 256:
             uw = _lib.conv_pack(w, _lib.PACK_WFWD)
             out.append((f'wino3x3 fp32 {K}->{M} @{H}', (lambda x=x, uw=uw, M=M, H=H, isc=isc, osc=osc, bias=bias: _lib.conv(x, uw, _lib.CONV_3X3W, M, H, H, isc, osc, bias, 3)), fl, 0.0, 2.0 / 3))
