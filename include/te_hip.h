@@ -220,7 +220,8 @@ int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W);
  * 513-channel final convolution of the discriminator and images narrower than 32 stay on TE_CONV_3X3.  Reference: the grouped F.conv2d of ModulatedConv2d.forward, model_spatial_query.py:331-333,
  * and EqualConv2d.forward :173-181. */
 int te_conv_wino_supported(int B, int K, int M, int H, int W);
-/* 1 if TE_CONV_3X3W6 covers the problem: K % 32 == 0, M % 64 == 0, H % 8 == 0, W % 32 == 0 */
+/* 1 if TE_CONV_3X3W6 covers the problem: K % 32 == 0, M % 64 == 0, H % 8 == 0, and W % 32 == 0 or (round 6) W == 16 with an even batch
+ * (two samples side by side in a 32-column tile row) */
 int te_conv_wino6_supported(int B, int K, int M, int H, int W);
 /* 1 if TE_CONV_S2S6 covers the problem (H, W = OUTPUT size): K % 16 == 0 and K >= 32, M % 64 == 0, H % 8 == 0, W % 16 == 0 */
 int te_conv_s2s6_supported(int B, int K, int M, int H, int W);

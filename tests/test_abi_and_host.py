@@ -54,7 +54,8 @@ def test_argument_validation_returns_error_codes(libpath):
     assert L.te_conv_packed_numel(_lib.PACK_WFWD, 128, 256, 3) == 12 * 128 * 256
     assert L.te_wgrad_pair_form(0, 128, 128, 256, 256) == 1 and L.te_wgrad_pair_form(0, 64, 64, 512, 512) == 0
     assert L.te_conv_wino6_supported(16, 128, 128, 256, 256) == 1 and L.te_conv_wino6_supported(4, 64, 64, 512, 512) == 1
-    assert L.te_conv_wino6_supported(4, 32, 32, 1024, 1024) == 0 and L.te_conv_wino6_supported(16, 512, 512, 16, 16) == 0      # M % 64, W % 32
+    assert L.te_conv_wino6_supported(4, 32, 32, 1024, 1024) == 0 and L.te_conv_wino6_supported(16, 512, 512, 8, 8) == 0        # M % 64, W % 32 ...
+    assert L.te_conv_wino6_supported(16, 512, 512, 16, 16) == 1 and L.te_conv_wino6_supported(15, 512, 512, 16, 16) == 0    # ... or W == 16, even batch (round 6)
     assert L.te_conv_wino6_supported(16, 48, 64, 32, 32) == 0                                                                    # K % 32
     assert L.te_conv_packed_numel(_lib.PACK_W6FWD, 128, 256, 3) == 18 * 128 * 256 == L.te_conv_packed_numel(_lib.PACK_W6DGRAD, 128, 256, 3)
     assert L.te_wgrad_pair_form(1, 128, 128, 64, 64) == 0 and L.te_wgrad_pair_form(0, 128, 128, 1, 1) == 0
@@ -375,7 +376,10 @@ def test_convolution_form_selection_is_a_pure_function_of_the_shape(libpath):
     assert modconv.fwd_kinds('3x3', 16, w(128, 128), 256, 256) == (_lib.PACK_W6FWD, _lib.CONV_3X3W6)
     assert modconv.bwd_kinds('3x3', 16, w(256, 512), 64, 64) == (_lib.PACK_W6DGRAD, _lib.CONV_3X3W6)
     assert modconv.fwd_kinds('3x3', 4, w(32, 32), 1024, 1024) == (_lib.PACK_WFWD, _lib.CONV_3X3W)
-    assert modconv.fwd_kinds('3x3', 16, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)
+    assert modconv.fwd_kinds('3x3', 16, w(512, 512), 16, 16) == (_lib.PACK_W6FWD, _lib.CONV_3X3W6)        # round 6: two samples side by side
+    assert modconv.fwd_kinds('3x3', 15, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)            # (odd batch), small batches, smaller images: direct kernel
+    assert modconv.fwd_kinds('3x3', 8, w(512, 512), 16, 16) == (_lib.PACK_FWD, _lib.CONV_3X3)
+    assert modconv.fwd_kinds('3x3', 16, w(512, 512), 8, 8) == (_lib.PACK_FWD, _lib.CONV_3X3)
     # (round 5) the strided kind on the bf16 pipe where te_conv_s2s6_supported says so: the up-sampling layers' data gradient and the
     # discriminator's down-sampling convolutions from 16 x 16 outputs up; smaller images stay on the fp32 kernel
     assert modconv.fwd_kinds('up', 16, w(256, 512), 64, 64) == (_lib.PACK_T6FWD, _lib.CONV_T2S6)

@@ -140,7 +140,10 @@ def test_weight_gradient_pair_form_selection():
 # three bf16 pieces, six exact piece products accumulated in fp32.  Pinned at the SAME bar as the fp32 kernels (5e-6 against fp64), and
 # the deviation from fp64 must not exceed the fp32 direct kernel's by more than a rounding unit: it is fp32 arithmetic, not bf16.
 W6_SHAPES = [(2, 32, 64, 8, 32), (1, 64, 128, 16, 64), (3, 96, 192, 24, 32), (2, 128, 64, 32, 96), (1, 32, 128, 40, 96), (2, 512, 512, 32, 32),
-             (1, 64, 64, 64, 64), (4, 128, 128, 64, 64)]
+             (1, 64, 64, 64, 64), (4, 128, 128, 64, 64),
+             # round 6: 16-column images, two samples side by side in a tile row (wino6p_kernel, lgpw = 3) - the 16 x 16 layers of both networks
+             # (taken from half a block per CU up: hence the batches)
+             (128, 32, 64, 16, 16), (128, 64, 128, 8, 16), (86, 96, 64, 24, 16), (16, 512, 512, 16, 16)]
 
 
 @pytest.mark.parametrize('B,K,M,H,W', W6_SHAPES)
@@ -173,10 +176,11 @@ def test_split_bf16_winograd_forward_and_data_gradient_vs_fp64(B, K, M, H, W):
         assert rel_err(got_g, want_g) < 5e-6
 
 
+@pytest.mark.parametrize('W', [64, 16])
 @pytest.mark.parametrize('act', [0, 3, 4])
 @pytest.mark.parametrize('epi', ['plain', 'res', 'res+mask'])
-def test_split_bf16_winograd_epilogue_stages_equal_the_direct_kernel(act, epi):
-    B, K, M, H, W = 2, 32, 128, 16, 64
+def test_split_bf16_winograd_epilogue_stages_equal_the_direct_kernel(act, epi, W):
+    B, K, M, H = (2 if W >= 32 else 64), 32, 128, 16
     x = synth.normal((B, K, H, W), 'w6.ex').to(DEV)
     w = (synth.normal((M, K, 3, 3), 'w6.ew') / (3 * math.sqrt(K))).to(DEV)
     isc, osc = (1 + 0.3 * synth.normal((B, K), 'w6.ei')).to(DEV), (1 + 0.3 * synth.normal((B, M), 'w6.eo')).to(DEV)

@@ -852,8 +852,18 @@ struct SumJobs { SumJob j[3]; };
 __global__ __launch_bounds__(256) void sum_parts_kernel(SumJobs jobs) {
     const SumJob J = jobs.j[blockIdx.y];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (int64_t)gridDim.x * 256) {
+        // (fixed order p ascending; eight loads in flight per lane: with one, a 128-part sum of a [B, C]-sized output - the narrow layers of
+        //  FFHQ-1024 - was a chain of 128 L2 round trips, 60+ us)
         float a = 0.f;
-        for (int p = 0; p < J.nparts; ++p) a += J.parts[(size_t)p * J.n + i];
+        int p = 0;
+        for (; p + 8 <= J.nparts; p += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = J.parts[(size_t)(p + q) * J.n + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += v[q];
+        }
+        for (; p < J.nparts; ++p) a += J.parts[(size_t)p * J.n + i];
         J.out[i] = a;
     }
 }
@@ -872,7 +882,7 @@ inline bool reduce_fused_ok(int Co, int Ci, int taps) { return taps == 9 && Co %
 // still sums >= 4 (sample, chunk) slabs so that the dW parts stay <= a quarter of the slab bytes
 inline void reduce_fused_split(int B, int S, int Co, int Ci, int& nzs, int& nzb) {
     const int64_t tiles = (int64_t)(Ci / 32) * (Co / FROWS);
-    int64_t nz = std::max<int64_t>(1, std::min<int64_t>(te::cdiv(2 * te::kNumCU, tiles), (int64_t)B * S / 4));
+    int64_t nz = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(te::cdiv(2 * te::kNumCU, tiles), (int64_t)B * S / 4), 64));     // (<= 64 parts for the second pass)
     nzs = (int)std::max<int64_t>(1, std::min<int64_t>(S, nz));
     nzb = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, B / 2), nz / nzs));
 }

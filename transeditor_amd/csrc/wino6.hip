@@ -53,6 +53,7 @@ struct Wino6Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; const float* res;
     const float* mref; float mgain; int act;
     int B, K, M, H, W, ntiles, mblocks, tiles_x, tiles_y, nt8;
+    int lgpw;      // log2 of the column PAIRS one sample contributes to a tile row: 4 (W >= 32); 3 (W == 16: two samples side by side, round 6)
 };
 
 __device__ __forceinline__ unsigned bf16_rn(float x) {          // round to nearest even (finite inputs)
@@ -359,14 +360,17 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     const int tq = jx / p.mblocks, mb = jx % p.mblocks;
     const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
     if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
-    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    // W == 16 (round 6): a tile row holds TWO samples side by side - pairs 0-7 = sample b, pairs 8-15 = sample b + 1 (lgpw = 3); every
+    // column pair is transformed from its own four input columns, so only the staging geometry and the output addresses know about it
+    const int pwm = (1 << p.lgpw) - 1;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = (tile / (p.tiles_x * p.tiles_y)) << (4 - p.lgpw);
     const int x0 = tx * TW, y0 = ty * TH, yh = y0 + PH * grp;
     const float* inb = p.in + (size_t)b * p.K * p.H * p.W;
     const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
     // block-uniform edge flags: interior tiles skip the patches of arith() by scalar branches (an empty asm statement inside each
     // branch keeps the compiler from turning them back into 96 selects per phase that every tile pays: a vector-ALU instruction in
     // the MFMA stream costs ~4.5 cycles, profiles/experiments/r05_wgrad6.log)
-    const bool has_left = x0 == 0, has_right = x0 + TW == p.W, has_rowout = (yh == 0) || (yh + PH == p.H);
+    const bool has_left = x0 == 0, has_right = x0 + TW >= p.W, has_rowout = (yh == 0) || (yh + PH == p.H);
 
     f32x16 acc[4];
 #pragma unroll
@@ -382,13 +386,15 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
         const int e = gt + GT * i;
         const int jj = e & 15, q = (e >> 4) & 7, row = e >> 7;
         const int gy = yh - 1 + row;
-        const bool left = x0 == 0 && jj == 0, right = x0 + TW == p.W && jj == NP - 1, rowout = gy < 0 || gy >= p.H;
+        const int sj = jj >> p.lgpw, jl = jj & pwm;                       // sample of the tile row, pair inside the sample's row
+        const bool left = x0 == 0 && jl == 0, right = x0 + TW >= p.W && jl == pwm, rowout = gy < 0 || gy >= p.H;
         e_flag[i] = (left ? 1 : 0) | (right ? 2 : 0) | (rowout ? 4 : 0);
         const int gyc = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy);
-        g_off[i] = (unsigned)((2 * q * p.H + gyc) * p.W + x0 + 2 * jj - 1 + (left ? 1 : 0) - (right ? 1 : 0));
+        g_off[i] = (unsigned)(sj * p.K * p.H * p.W + (2 * q * p.H + gyc) * p.W + x0 + 2 * jl - 1 + (left ? 1 : 0) - (right ? 1 : 0));
         l_off[i] = ((row * 2 + (q >> 2)) * NP + jj) * 4 + (q & 3);                        // + (piece * 4 + c) * TP_PLANE
     }
-    const unsigned q2 = 2u * ((gt >> 4) & 7);
+    const unsigned q2 = 2u * ((gt >> 4) & 7) + (unsigned)(((gt & 15) >> p.lgpw) * p.K);      // (+ the style-scale row of this thread's sample:
+                                                                                              //  a thread's items share their pair index)
     const size_t plane = (size_t)p.H * p.W;
     const int MT = p.M >> 5;
     f32x4 rin[P_IN][2];
@@ -618,13 +624,14 @@ __global__ __launch_bounds__(WT, 2) void wino6p_kernel(const Wino6Args p) {
     // epilogue: as wino6_kernel (output transform, demodulation scale, bias, leaky ReLU, residual, mask); group 0 is here one phase early
     const int wr = grp * 2 + wrl;
     const int mbase = mb * BM + wm * 32;
-    const size_t off0 = ((size_t)b * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * jj;
+    const int bo = b + (jj >> p.lgpw);                                  // this lane's output sample
+    const size_t off0 = ((size_t)bo * p.M + mbase) * plane + (size_t)(y0 + 2 * wr + rr) * p.W + x0 + 2 * (jj & pwm);
     const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
     float scv[16], biv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-        scv[r] = p.osc ? p.osc[(size_t)b * p.M + m] : 1.f;
+        scv[r] = p.osc ? p.osc[(size_t)bo * p.M + m] : 1.f;
         biv[r] = p.bias ? p.bias[m] : 0.f;
     }
     f32x2 resv[16], mrefv[16];
@@ -972,14 +979,22 @@ extern "C" int te_debug_w6p_prof(void* host_dst, int64_t bytes) {
 #endif
 
 extern "C" int te_conv_wino6_supported(int B, int K, int M, int H, int W) {
-    if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0 && W >= TW && W % TW == 0)) return 0;
-    return ((int64_t)K * H * W * 4 < 0x7FFFFFFF && (int64_t)B * (H / TH) * (W / TW) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
+    if (!(B > 0 && K >= 32 && K % 32 == 0 && M >= BM && M % BM == 0 && H >= TH && H % TH == 0)) return 0;
+    // W % 32 == 0, or (round 6) W == 16 with an even batch: two samples side by side in a 32-column tile row - the 16 x 16 layers of both
+    // networks (512 channels: 32 stages per block) leave the fp32 pipe; 8 x 8 and 4 x 4 images give too few blocks and stay there
+    const bool wide = W >= TW && W % TW == 0, pair16 = W == 16 && B % 2 == 0;
+    if (!wide && !pair16) return 0;
+    const int64_t tiles = wide ? (int64_t)B * (H / TH) * (W / TW) : (int64_t)(B / 2) * (H / TH);
+    // (16-column images: only from half a block per CU up - measured at 512 -> 512 @16x16: 163 against 357 us at batch 32, 123 against 166 at
+    //  batch 16, but 111 against 92 at batch 8, where the direct kernel's split over K fills the chip better than 64 blocks do)
+    if (!wide && tiles * (M / BM) < te::kNumCU / 2) return 0;
+    return ((int64_t)K * H * W * 4 * (wide ? 1 : 2) < 0x7FFFFFFF && tiles * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
 }
 
 int te_wino6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, const float* res,
                     const float* mask_ref, float mask_gain, int act, int B, int K, int M, int H, int W, hipStream_t s) {
     TE_REQUIRE(te_conv_wino6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
-               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0, W %% 32 == 0, H %% 8 == 0 (te_conv_wino6_supported)");
+               "te_conv_f32(TE_CONV_3X3W6): needs K %% 32 == 0, M %% 64 == 0, W %% 32 == 0 (or W == 16 and an even batch), H %% 8 == 0 (te_conv_wino6_supported)");
     TE_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(res) |
                  reinterpret_cast<uintptr_t>(mask_ref)) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_3X3W6): 16-byte aligned tensors required");
@@ -987,13 +1002,14 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
     a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.res = res;
     a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.H = H; a.W = W;
-    a.tiles_x = W / TW; a.tiles_y = H / TH; a.mblocks = M / BM;
-    a.ntiles = B * a.tiles_x * a.tiles_y;
+    a.lgpw = W >= TW ? 4 : 3;
+    a.tiles_x = W >= TW ? W / TW : 1; a.tiles_y = H / TH; a.mblocks = M / BM;
+    a.ntiles = (W >= TW ? B : B / 2) * a.tiles_x * a.tiles_y;
     a.nt8 = te::xcd_banded() ? (int)te::cdiv(a.ntiles, 8) : 0;
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
     const int form = g_w6_form.load(std::memory_order_relaxed);
     const int64_t blocks_q = te::cdiv(a.ntiles, 8) * 8 * (M / (2 * BM));
-    if (form >= 2 && M % (2 * BM) == 0 && (form == 3 || blocks_q >= te::kNumCU)) {
+    if (form >= 2 && M % (2 * BM) == 0 && W >= TW && (form == 3 || blocks_q >= te::kNumCU)) {     // (W == 16: the ping-pong kernel only)
         a.mblocks = M / (2 * BM);
         const int64_t blocks2 = blocks_q;
         const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
@@ -1005,7 +1021,7 @@ int te_wino6_launch(float* out, const float* in, const float* U, const float* is
             te::allow_big_lds(attr_done_q, (const void*)wino6q_kernel<false>, 160 * 1024);
             wino6q_kernel<false><<<dim3((unsigned)blocks2), WT, lds, s>>>(a);
         }
-    } else if (form >= 1) {
+    } else if (form >= 1 || W < TW) {          // (the side-by-side form of 16-column images exists in the ping-pong / two-image kernels only)
         const size_t lds = (size_t)U_CHUNKS * 16 + 2 * (size_t)TP_DWORDS * 4;
         static std::atomic<uint64_t> attr_done_p{0}, attr_done_ps{0};
         if (isc) {

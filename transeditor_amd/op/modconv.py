@@ -332,7 +332,7 @@ USE_SPLIT_BF16 = os.environ.get('TE_SPLIT_BF16', '1') != '0'
 def fwd_kinds(kind, B, w, H, W):
     """(weight pack kind, convolution kind code) of the forward launch; H, W = low-resolution size"""
     if kind == '3x3' and USE_WINOGRAD:
-        if USE_SPLIT_BF16 and _lib.wino6_ok(B, w.shape[1], w.shape[0], H, W):
+        if USE_SPLIT_BF16 and (W >= 32 or USE_SPLIT_W16) and _lib.wino6_ok(B, w.shape[1], w.shape[0], H, W):
             return _lib.PACK_W6FWD, _lib.CONV_3X3W6
         if _lib.wino_ok(B, w.shape[1], w.shape[0], H, W):
             return _lib.PACK_WFWD, _lib.CONV_3X3W
@@ -357,6 +357,8 @@ def plain_1x1_kinds(B, w, H, W, dgrad=False):
     return (_lib.PACK_DGRAD if dgrad else _lib.PACK_FWD), _lib.CONV_1X1
 
 
+# TE_SPLIT_W16=0: the 16-column 3x3 launches (two samples side by side in a tile row of the split Winograd kernel, round 6) stay on the fp32 kernel (A/B)
+USE_SPLIT_W16 = os.environ.get('TE_SPLIT_W16', '1') != '0'
 # TE_SPLIT_S2=0: the stride-2 launches stay on the fp32 matrix instructions while the 3x3 stride-1 ones keep the split form (A/B)
 USE_SPLIT_S2 = os.environ.get('TE_SPLIT_S2', '1') != '0'
 USE_SPLIT_T2 = os.environ.get('TE_SPLIT_T2', '1') != '0'
@@ -365,7 +367,7 @@ USE_SPLIT_T2 = os.environ.get('TE_SPLIT_T2', '1') != '0'
 def bwd_kinds(kind, B, w, H, W):
     """the same for the data gradient (a convolution from Co to Ci channels)"""
     if kind == '3x3' and USE_WINOGRAD:
-        if USE_SPLIT_BF16 and _lib.wino6_ok(B, w.shape[0], w.shape[1], H, W):
+        if USE_SPLIT_BF16 and (W >= 32 or USE_SPLIT_W16) and _lib.wino6_ok(B, w.shape[0], w.shape[1], H, W):
             return _lib.PACK_W6DGRAD, _lib.CONV_3X3W6
         if _lib.wino_ok(B, w.shape[0], w.shape[1], H, W):
             return _lib.PACK_WDGRAD, _lib.CONV_3X3W
