@@ -247,7 +247,7 @@ class KernelTimer:
                 'per_kernel': ks}
 
 
-W6_KERNEL = {2: 'wino6q_kernel (wino6p_kernel where M % 128 != 0)', 1: 'wino6p_kernel', 0: 'wino6_kernel'}
+W6_KERNEL = {2: 'wino6q_kernel (wino6p_kernel where M % 128 != 0 or W == 16)', 1: 'wino6p_kernel', 0: 'wino6_kernel'}
 
 
 def _w6_form():
