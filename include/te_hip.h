@@ -7,8 +7,8 @@
  *     buffer (the Python host allocates through the torch caching allocator);
  *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
  *     no synchronisation; safe to call from several host threads.  No global mutable state takes part in any RESULT; the only
- *     process-wide state are two debug / A-B switches that select between kernels with the same results (bit-identical for
- *     te_conv_wino6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
+ *     process-wide state are three debug / A-B switches that select between kernels with the same results (bit-identical for
+ *     te_conv_wino6_form and te_conv_s2s6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
  *     written by the product's own code paths) and the per-thread last-error string;
  *   - return 0 on success, a negative TE_ERR_* for argument validation failures, or a positive
  *     hipError_t if the launch failed; nothing throws across the ABI.  te_last_error_string()
@@ -241,6 +241,14 @@ int te_conv_p1s6_supported(int B, int K, int M, int H, int W);
  * All forms issue the same products in the same order per output element: results are bit-identical.  TE_W6_FORM in the
  * environment sets the initial value (A/B measurements). */
 int te_conv_wino6_form(int form);
+/* Kernel form of TE_CONV_S2S6 (returns the previous value; form < 0 only queries), a process-wide A/B switch like the one above:
+ *   1 = (round 6, default) the two-image form: a block owns 128 output channels and multiplies every staged half tile by two
+ *       64-channel weight images (half the fetches, split arithmetic and LDS writes per MFMA) where M % 128 == 0 and the grid
+ *       still gives every CU a block, the ping-pong form elsewhere (2 = the two-image form wherever M % 128 == 0: tests);
+ *   0 = ping-pong (round 5).
+ * Same products in the same order per output element: results are bit-identical.  TE_S2S6_FORM in the environment sets the
+ * initial value. */
+int te_conv_s2s6_form(int form);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 /* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):

@@ -124,3 +124,33 @@ def test_split_bf16_strided_layout_and_selection():
         assert modconv.fwd_kinds('down', 32, e(256, 128, 3, 3), 128, 128) == (_lib.PACK_FWD, _lib.CONV_S2)
     finally:
         modconv.USE_SPLIT_S2 = old
+
+
+@pytest.mark.parametrize('B,K,M,H,W', [(2, 32, 128, 8, 16), (3, 96, 256, 24, 32), (1, 48, 128, 16, 48), (2, 160, 128, 8, 16), (1, 512, 512, 16, 16),
+                                       (2, 128, 256, 32, 64), (5, 32, 384, 8, 32), (2, 64, 64, 8, 16), (3, 64, 192, 8, 32)])
+def test_split_bf16_strided_kernel_forms_are_bit_identical(B, K, M, H, W):
+    """two-image form (s2s6q_kernel, round 6, default where M % 128 == 0 and every CU gets a block) and ping-pong form (s2s6_kernel) of
+    TE_CONV_S2S6 issue the same products in the same order per output element: identical bits, with style scales and every epilogue
+    stage, on single- and multi-tile images, 2 - 32 channel stages, 1 - 4 blocks of 128 output channels (form 2 = the two-image kernel
+    whatever the grid size; it runs the ping-pong kernel where M % 128 != 0)"""
+    x = synth.normal((B, K, 2 * H + 1, 2 * W + 1), f's6.fx.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f's6.fw.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 's6.fi')).to(DEV), (1 + 0.3 * synth.normal((B, M), 's6.fo')).to(DEV)
+    bias = synth.normal((M,), 's6.fb').to(DEV)
+    res, mref = synth.normal((B, M, H, W), 's6.fr').to(DEV), synth.normal((B, M, H, W), 's6.fm').to(DEV)
+    u6 = _lib.conv_pack(w, _lib.PACK_S6FWD, 0.9)
+    out = {}
+    old = _lib.s2s6_form(-1)
+    try:
+        for form in (0, 2):
+            _lib.s2s6_form(form)
+            out[form] = (_lib.conv(x, u6, _lib.CONV_S2S6, M, H, W, isc, osc, bias, 3),
+                         _lib.conv(x, u6, _lib.CONV_S2S6, M, H, W, None, None, bias, 4, res=res, mask_ref=mref, mask_gain=1.3),
+                         _lib.conv(x, u6, _lib.CONV_S2S6, M, H, W))
+    finally:
+        _lib.s2s6_form(old)
+    assert _lib.s2s6_form(-1) == old
+    for a, b in zip(out[0], out[2]):
+        assert torch.equal(a, b)
+    want = F.conv2d(x.double(), w.double() * 0.9, stride=2)
+    assert rel_err(out[2][2], want) < 5e-6

@@ -12,7 +12,8 @@ from transeditor_amd.train_step import TrainStep, default_args       # noqa: E40
 
 DEV = 'cuda'
 recs = []
-names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1', _lib.CONV_3X3W: 'conv3x3w'}
+names = {_lib.CONV_3X3: 'conv3x3', _lib.CONV_T2: 'convT2', _lib.CONV_S2: 'convS2', _lib.CONV_1X1: 'conv1x1', _lib.CONV_3X3W: 'conv3x3w',
+         _lib.CONV_3X3W6: 'conv3x3w6', _lib.CONV_S2S6: 'convS2s6', _lib.CONV_T2S6: 'convT2s6', _lib.CONV_1X1S6: 'conv1x1s6'}
 orig_conv, orig_wgrad = _lib.conv, _lib.wgrad_slabs
 ON = [False]
 
@@ -24,7 +25,7 @@ def conv(x, wp, kind, M, H, W, *a, **k):
     s.record()
     out = orig_conv(x, wp, kind, M, H, W, *a, **k)
     e.record()
-    taps = 1 if kind == _lib.CONV_1X1 else 9
+    taps = 1 if kind in (_lib.CONV_1X1, _lib.CONV_1X1S6) else 9
     recs.append(((names[kind], x.shape[0], x.shape[1], M, H, W), 2.0 * taps * x.shape[1] * M * H * W * x.shape[0], s, e))
     return out
 
@@ -36,7 +37,7 @@ def wgrad(g, x, kind, H, W, *a, **k):
     s.record()
     out = orig_wgrad(g, x, kind, H, W, *a, **k)
     e.record()
-    taps = 1 if kind == _lib.CONV_1X1 else 9
+    taps = 1 if kind in (_lib.CONV_1X1, _lib.CONV_1X1S6) else 9
     recs.append((('wgrad_' + names[kind], g.shape[0], x.shape[1], g.shape[1], H, W), 2.0 * taps * g.shape[1] * x.shape[1] * H * W * g.shape[0], s, e))
     return out
 
@@ -64,7 +65,7 @@ def main():
     tot = sum(a[2] for a in agg.values())
     print(f'{len(recs)} launches, {tot:.1f} ms over 16 iterations')
     print(f'{"kind":14s} {"B":>3s} {"K":>4s} {"M":>4s} {"H":>4s} {"W":>4s} {"n":>5s} {"ms":>8s} {"share":>6s} {"TF/s":>7s}')
-    for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
+    for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:110]:
         print(f'{key[0]:14s} {key[1]:3d} {key[2]:4d} {key[3]:4d} {key[4]:4d} {key[5]:4d} {a[0]:5d} {a[2]:8.1f} {100 * a[2] / tot:5.1f}% {a[1] / a[2] / 1e9:7.1f}')
 
 

@@ -42,6 +42,7 @@ _SIGNATURES = {
     'te_conv_wino_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_form': (C.c_int, [_I]),
+    'te_conv_s2s6_form': (C.c_int, [_I]),
     'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_t2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_p1s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
@@ -360,6 +361,12 @@ def wino6_form(form=-1):
     """kernel form of TE_CONV_3X3W6: 2 = two-image (default; M % 128 == 0, else ping-pong), 1 = ping-pong, 0 = block-phase (bit-identical
     results); returns the previous value (-1: query only)"""
     return int(lib().te_conv_wino6_form(form))
+
+
+def s2s6_form(form=-1):
+    """kernel form of TE_CONV_S2S6: 1 = two-image (default; M % 128 == 0 and a block per CU, else ping-pong), 2 = two-image wherever
+    M % 128 == 0, 0 = ping-pong (bit-identical results); returns the previous value (-1: query only)"""
+    return int(lib().te_conv_s2s6_form(form))
 
 
 def wino6_ok(B, K, M, H, W):
