@@ -249,6 +249,10 @@ int te_conv_wino6_form(int form);
  * Same products in the same order per output element: results are bit-identical.  TE_S2S6_FORM in the environment sets the
  * initial value. */
 int te_conv_s2s6_form(int form);
+/* TE_CONV_T2S6 only: `ws` of te_conv_ws_f32 / te_conv_res_f32 is an OPTIONAL scratch of te_conv_t2s6_ws_floats(B, K, H) = B * K * H
+ * floats through which the body kernel hands the (style-scaled) last input column to the kernel that computes the last output
+ * row / column (round 6); NULL is legal - that kernel then gathers the column from `in` itself, one cache line per element. */
+int64_t te_conv_t2s6_ws_floats(int B, int K, int H);
 int te_conv_ws_f32(float* out, float* ws, const float* in, const float* wp, const float* isc, const float* osc,
                    const float* bias, int act, int kind, int B, int K, int M, int H, int W, te_stream_t stream);
 /* te_conv_ws_f32 with two more epilogue stages (not for TE_CONV_T2; a split launch, S > 1, needs the workspace):

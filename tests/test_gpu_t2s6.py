@@ -105,3 +105,33 @@ def test_split_bf16_transposed_selection():
         assert modconv.fwd_kinds('up', 16, e(128, 256, 3, 3), 128, 128) == (_lib.PACK_FWD, _lib.CONV_T2)
     finally:
         modconv.USE_SPLIT_T2 = old
+
+
+@pytest.mark.parametrize('B,K,M,H,W', [(2, 32, 64, 8, 16), (3, 96, 192, 24, 32), (1, 48, 64, 16, 48), (2, 64, 128, 64, 64), (2, 160, 128, 72, 80),
+                                       (1, 512, 512, 16, 16)])
+@pytest.mark.parametrize('styled', [True, False])
+def test_last_row_and_column_kernel_with_and_without_the_column_scratch(B, K, M, H, W, styled):
+    """the last output row / column of TE_CONV_T2S6 (t2_edge_kernel, round 6): with the optional scratch (te_conv_t2s6_ws_floats) the
+    body kernel hands it the scaled last input column, without it (ws = NULL, legal) it gathers the column from the input - the same
+    products in the same order: identical bits; both tile widths (lines of >= 64 / < 64 cells), 16-channel tails of the 32-channel
+    chunks (K = 48, 96, 160), and the lines against fp64 on their own"""
+    x = synth.normal((B, K, H, W), f't6.ex.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f't6.ew.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc = (1 + 0.3 * synth.normal((B, K), 't6.eisc')).to(DEV) if styled else None
+    osc = (1 + 0.3 * synth.normal((B, M), 't6.eosc')).to(DEV)
+    bias = synth.normal((M,), 't6.eb').to(DEV)
+    wp = _lib.conv_pack(w, _lib.PACK_T6FWD, 0.9)
+    assert _lib.lib().te_conv_t2s6_ws_floats(B, K, H) == B * K * H
+    got = _lib.conv(x, wp, _lib.CONV_T2S6, M, H, W, isc, osc, bias, 3)
+    bare = torch.empty_like(got)
+    rc = _lib.lib().te_conv_res_f32(bare.data_ptr(), None, x.data_ptr(), wp.data_ptr(), isc.data_ptr() if styled else None, osc.data_ptr(),
+                                   bias.data_ptr(), None, None, 1.0, 3, _lib.CONV_T2S6, B, K, M, H, W, _lib._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got, bare)
+    xs = x.double() * (isc.double()[:, :, None, None] if styled else 1.0)
+    want = F.conv_transpose2d(xs, (w.double() * 0.9).transpose(0, 1), stride=2) * osc.double()[:, :, None, None] + bias.double()[None, :, None, None]
+    want = F.leaky_relu(want, 0.2) * math.sqrt(2)
+    assert rel_err(got[:, :, 2 * H], want[:, :, 2 * H]) < 5e-6
+    assert rel_err(got[:, :, :, 2 * W], want[:, :, :, 2 * W]) < 5e-6
+    assert rel_err(got, want) < 5e-6

@@ -43,6 +43,7 @@ _SIGNATURES = {
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_form': (C.c_int, [_I]),
     'te_conv_s2s6_form': (C.c_int, [_I]),
+    'te_conv_t2s6_ws_floats': (C.c_int64, [_I, _I, _I]),
     'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_t2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_p1s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
@@ -395,6 +396,8 @@ def conv(x, wp, kind, M, H, W, isc=None, osc=None, bias=None, act=0, res=None, m
         raise RuntimeError(f'te_conv_splitk_count failed ({S})')
     # small images split the channel loop over the grid: per-split slabs + fixed-order sum (deterministic, graph-capturable)
     ws = torch.empty((S,) + tuple(out.shape), device=x.device, dtype=x.dtype) if S > 1 else None
+    if kind == CONV_T2S6:          # scratch for the last input column (body kernel -> edge kernel; te_hip.h)
+        ws = torch.empty(B * K * H, device=x.device, dtype=x.dtype)
     _check(lib().te_conv_res_f32(_ptr(out), _ptr(ws), _ptr(x), _ptr(wp), _ptr(isc), _ptr(osc), _ptr(bias),
                                  _ptr(res.contiguous()) if res is not None else None,
                                  _ptr(mask_ref.contiguous()) if mask_ref is not None else None, mask_gain, act, kind, B, K, M, H, W,

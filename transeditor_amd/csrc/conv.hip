@@ -1229,6 +1229,8 @@ static SideStream* side_stream() {
     return tab[dev].ok ? &tab[dev] : nullptr;
 }
 
+extern "C" int64_t te_conv_t2s6_ws_floats(int B, int K, int H) { return (B > 0 && K > 0 && H > 0) ? (int64_t)B * K * H : TE_ERR_SHAPE; }
+
 extern "C" int te_conv_splitk_count(int kind, int B, int K, int M, int H, int W) {
     if (B <= 0 || K <= 0 || M <= 0 || H <= 0 || W <= 0 || kind < 0 || kind > 8) return TE_ERR_SHAPE;
     if (kind == TE_CONV_3X3W || kind == TE_CONV_3X3W6 || kind == TE_CONV_S2S6 || kind == TE_CONV_T2S6 || kind == TE_CONV_1X1S6) return 1;
@@ -1271,6 +1273,16 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
         a.Hi = H; a.Wi = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
         const int r[2][4] = {{0, W, H + 1, 1}, {H, 0, 1, W}};
         const int tc = conv_plan(TE_CONV_T2, B, K, M, H, W).tc;
+        // Round 6: the two lines as ONE small vector-ALU launch (t2s6.hip, t2_edge_kernel: 15 - 30 us instead of 130 - 150); TE_T2_EDGE=0
+        // brings the thin regions of the fp32 kernel back (A/B measurements, tests).
+        static const bool edge_kernel = [] { const char* e = getenv("TE_T2_EDGE"); return !e || atoi(e) != 0; }();
+        if (edge_kernel) {
+            // `ws` (optional for this kind: te_conv_t2s6_ws_floats = B K H floats) takes the last input column from the body kernel
+            // to the edge kernel; without it the edge kernel gathers the column itself (one cache line per element: slower)
+            int rc = te_t2s6_launch(out, in, wp, isc, osc, bias, act, B, K, M, H, W, s, ws);
+            if (rc) return rc;
+            return te_t2s6_edge_launch(out, in, a.wp, isc, osc, bias, act, B, K, M, H, W, a.Kp, a.Mp, s, ws);
+        }
         SideStream* side = side_stream();
         int rc;
         if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess) {

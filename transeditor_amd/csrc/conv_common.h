@@ -36,7 +36,11 @@ int te_s2s6_launch(float* out, const float* in, const float* U, const float* isc
 // csrc/t2s6.hip: body cells of the transposed 3x3 / stride 2 convolution on the bf16 matrix pipe; kind TE_CONV_T2S6 (conv.hip adds the
 // last output row / column through the fp32 kernel), weights packed TE_PACK_T6FWD / TE_PACK_T6SWAP
 int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
-                   int B, int K, int M, int H, int W, hipStream_t s);
+                   int B, int K, int M, int H, int W, hipStream_t s, float* colbuf = nullptr);
+// ... and its last output row / column as one small vector-ALU launch (round 6; wplain = the Wp[tap][Kp][Mp] copy behind the split layout;
+// colbuf: optional [B][K][H] floats in which the body kernel leaves the scaled last input column for the edge kernel)
+int te_t2s6_edge_launch(float* out, const float* in, const float* wplain, const float* isc, const float* osc, const float* bias, int act,
+                        int B, int K, int M, int H, int W, int Kp, int Mp, hipStream_t s, const float* colbuf = nullptr);
 // csrc/p1s6.hip (round 6): the 1x1 convolution on the bf16 matrix pipe (three-piece split: fp32-equivalent), plain product + optional
 // residual; kind TE_CONV_1X1S6, weights packed TE_PACK_P6FWD / TE_PACK_P6DGRAD in MFMA fragment order
 int te_p1s6_launch(float* out, const float* in, const float* U, const float* res, int B, int K, int M, int H, int W, hipStream_t s);

@@ -68,6 +68,7 @@ __device__ unsigned long long te_t2s6_prof_buf[2048 * 8 * 8];
 
 struct T2Args {
     float* out; const float* in; const u32x4* U; const float* isc; const float* osc; const float* bias; int act;
+    float* colbuf;           // optional [B][K][H]: the (style-scaled) last input column, written while it is staged (t2_edge_kernel reads it)
     int B, K, M, H, W, Ho, Wo, ntiles, mblocks, tiles_x, tiles_y, nt8;
 };
 
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     const size_t iplane = (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;
     const float* inb = p.in + (size_t)b * p.K * iplane;
     const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
+    const bool store_col = p.colbuf != nullptr && tx == p.tiles_x - 1 && mb == 0;      // block-uniform
 
     f32x16 acc[4];                                     // one tile per output phase (a, b) = (ky & 1, kx & 1)
 #pragma unroll
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     //   slot 0: edge patch + style scale;  slots 1 + 4 c + j: position c of the item, the four steps of the three-piece split
     unsigned res[4][3];
     float te = 0.f, to = 0.f, fe = 0.f, fo = 0.f;
-    auto arith = [&](int k) {
+    // (sa = the stage whose registers the program works on)
+    auto arith = [&](int k, int sa) {
         if (k < 0) {
         } else if (k == 0) {
 #pragma unroll
@@ -159,6 +162,17 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
                 if (rowout) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                 rin[h2] = ISC ? v * rsc[h2] : v;
                 asm volatile("" : "+v"(rin[h2]));
+            }
+            // Round 6: the blocks of the last tile column (first M block only) leave the scaled last input column W - 1 in a compact
+            // buffer [B][K][H] for t2_edge_kernel - which otherwise gathers it with one cache line per element (B K H lines: 524 k at the
+            // two large FFHQ-256 shapes, 90 - 150 us of miss latency on the few CUs that run the column blocks).  Rows shared by two half
+            // tiles (the halo) are written twice with the same value.
+            if (store_col) {
+                if (last_col && live && !rowout) {
+                    float* cb = p.colbuf + ((size_t)b * p.K + (size_t)sa * KC + q2) * p.H + (yh - 1 + row);
+                    cb[0] = rin[0][0];
+                    cb[p.H] = rin[1][0];
+                }
             }
         } else if (k < N_SLOT) {
             const int c = (k - 1) >> 2, j = (k - 1) & 3;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     issue(0);
     if (grp == 0) { issue_u(0, 0); issue_u(1, 0); }
 #pragma unroll
-    for (int k = 0; k < N_SLOT; ++k) arith(k);
+    for (int k = 0; k < N_SLOT; ++k) arith(k, 0);
     write_res();
     issue(1);
     if (grp == 0) {          // (counted: only the weight DMA must have landed; the fetch of stage 1 - 3 loads, 2 without style scales - stays in flight)
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
         if ((ph & 1) == grp) {
             // ---- multiply this group's half of stage ph / 2; behind the MFMAs: the arithmetic of the stage after (rin -> res)
             bf16x8 av[2][3], bv[2][3];
-            const int fs2 = min((ph >> 1) + 2, nstage - 1);
+            const int fs2 = min((ph >> 1) + 2, nstage - 1), sa = min((ph >> 1) + 1, nstage - 1);
             const u32x4* ua = ul + ((ph >> 1) & 1) * (U_SLOTS * 64) + a_chunk;          // this stage's weight image
             auto rd1 = [&](int t, int slot, int qq) {
                 const int ky = t / 3, kx = t % 3;
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 #endif
                     if (t + 1 < NTAP && qq < 3) { rd1(t + 1, slot ^ 1, 2 * qq); rd1(t + 1, slot ^ 1, 2 * qq + 1); }
 #ifndef ST_NO_ARITH
-                    arith(t * 6 + qq - SLOT0);
+                    arith(t * 6 + qq - SLOT0, sa);
 #endif
 #ifndef ST_NO_FETCH
                     if (t * 6 + qq - SLOT0 == 0) fetch_scales(fs2);          // the fetch of the stage after next (see fetch_item)
@@ -317,6 +331,177 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the LAST OUTPUT ROW AND COLUMN of the transposed kind (cells i = H / j = W) as one small vector-ALU launch.
+//
+// Until now they were two thin regions of conv_mfma_kernel<TE_CONV_T2>: a few dozen blocks of 128-cell tiles with one valid cell row or
+// column each, every block walking the whole channel loop - 130 - 150 us for 0.8 GFLOP, ~2.5 ms of the 111 ms FFHQ-256 iteration (19
+// launches), more than a quarter of a 128-channel launch.  The work is two "line" problems that only see one input row / column:
+//     out[m][2H][2j + 0] = sum_k s_k ( w[m][k][2][0] in[k][H-1][j] + w[m][k][2][2] in[k][H-1][j-1] )      j = 0 .. W - 1
+//     out[m][2H][2j + 1] = sum_k s_k   w[m][k][2][1] in[k][H-1][j]
+//     out[m][2i + 0][2W] = sum_k s_k ( w[m][k][0][2] in[k][i][W-1] + w[m][k][2][2] in[k][i-1][W-1] )      i = 0 .. H (the corner: i = H)
+//     out[m][2i + 1][2W] = sum_k s_k   w[m][k][1][2] in[k][i][W-1]
+// (model_spatial_query.py:310-321: conv_transpose2d(stride 2, pad 0); taps as packed: t = 3 ky + kx).  Block = 64 output channels x 64 (32)
+// line cells of one sample, 512 threads = two halves that each take 16 of a chunk's 32 input channels and meet through LDS at the end;
+// thread = 4 channels x 4 (2) cells, per input channel 48 (24) multiply-adds from three 16-byte weight reads (broadcast over the 16
+// lanes that share the channels) and one 20 (12)-byte line read; the next chunk's global loads are in flight during the multiply-adds
+// (the first version without that prefetch and with 16-channel chunks: 82 - 87 us per launch, latency-bound).  Weights from the plain fp32 copy behind the split layout
+// (TE_PACK_T6FWD / T6SWAP: Wp[tap][Kp][Mp]), plain fp32 arithmetic, fixed summation order.
+constexpr int EM = 64, EKC = 32, ET = 512;
+struct T2EdgeArgs {
+    float* out; const float* in; const float* wp; const float* isc; const float* osc; const float* bias; int act;
+    const float* colbuf;     // optional [B][K][H]: the style-scaled last input column as left by t2s6_kernel (NULL: gathered from `in`)
+    int B, K, M, H, W, Kp, Mp, Ho, Wo, row_tiles, line_tiles, mtiles;
+};
+
+// CT = line cells per thread (4: tile of 64 cells, lines of >= 64 cells; 2: tile of 32 cells)
+template <bool ISC, int CT>
+__global__ __launch_bounds__(ET) void t2_edge_kernel(const T2EdgeArgs p) {
+    constexpr int EC = 16 * CT, XS = EC + 4, NXV = EKC * (EC + 2), NW = 3 * EKC * (EM / 4);      // line tile, LDS row stride, staged values
+    constexpr int RW = NW / ET, RX = (NXV + ET - 1) / ET;                                         // 16-byte weight / 4-byte line loads per thread and chunk
+    constexpr int NACC = 4 * CT * 2;
+    constexpr int SMEM = (3 * EKC * EM + EKC * XS) > 256 * NACC ? (3 * EKC * EM + EKC * XS) : 256 * NACC;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* ws = smem;                           // [tap: even-near, even-far, odd][k][m]
+    float* xs = smem + 3 * EKC * EM;            // [k][cell c0 - 1 .. c0 + EC] (+ pad)
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int lt = bx % p.line_tiles; bx /= p.line_tiles;
+    const int mt = bx % p.mtiles, b = bx / p.mtiles;
+    const bool col = lt >= p.row_tiles;                                     // block-uniform: which of the two lines
+    const int c0 = (col ? lt - p.row_tiles : lt) * EC, m0 = mt * EM;
+    const int NX = col ? p.H : p.W;                                         // input cells of the line
+    const int NOUT = col ? 2 * p.H + 1 : 2 * p.W;                           // outputs of the line (the corner belongs to the column)
+    const bool compact = col && p.colbuf != nullptr;                        // block-uniform: the column comes from the compact buffer, already scaled
+    const int sx = col && !compact ? p.W : 1, so = col ? p.Wo : 1;
+    const size_t xbase = compact ? 0 : (col ? (size_t)(p.W - 1) : (size_t)(p.H - 1) * p.W);
+    const size_t obase = col ? (size_t)(2 * p.W) : (size_t)(2 * p.H) * p.Wo;
+    const int tap_near = col ? 2 : 6, tap_far = 8, tap_odd = col ? 5 : 7;  // even outputs: (ky, kx) = (0, 2) | (2, 0) and (2, 2); odd: (1, 2) | (2, 1)
+    const int kh = tid >> 8, t8 = tid & 255, mg = t8 >> 4, cg = t8 & 15;
+    const size_t iplane = compact ? (size_t)p.H : (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;       // (iplane: channel stride of the line source)
+    const float* inb = (compact ? p.colbuf : p.in) + (size_t)b * p.K * iplane + xbase;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
+    // accumulators as channel PAIRS (m, m + 1): one v_pk_fma_f32 per pair and cell (the weight pair is an aligned half of the 16-byte
+    // read, the line value is broadcast) - 24 (12) packed instructions per input channel instead of 48 (24) scalar ones; the scalar
+    // form measured 54 - 92 us per launch at 160 - 192 blocks, bound by instruction issue
+    f32x2 ae[2][CT], ao[2][CT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { ae[m][c] = f32x2{0.f, 0.f}; ao[m][c] = f32x2{0.f, 0.f}; }
+
+    // per-thread staging geometry (the same for every chunk): weight items e = tid + 512 r -> (tap, k, 4 channels); line items -> (k, cell).
+    // Every load is UNCONDITIONAL (clamped address; what does not exist becomes zero when the chunk is written to LDS) and the style scale
+    // is applied at that write: a load inside a branch that also consumes it made the compiler wait for each one in turn (five serial
+    // round trips per chunk in the first version).
+    const float* wsrc[RW];
+    int wk[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int e = tid + ET * r, t3 = e / (EKC * 16), k = (e >> 4) % EKC, m4 = e & 15;
+        const int tap = t3 == 0 ? tap_near : (t3 == 1 ? tap_far : tap_odd);
+        wk[r] = k;
+        wsrc[r] = p.wp + (size_t)tap * p.Kp * p.Mp + m0 + 4 * m4;
+    }
+    int xk[RX], xl[RX];
+    size_t xoff[RX];
+    bool xok[RX];
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+        const int e = tid + ET * r, ee = e < NXV ? e : 0, k = ee / (EC + 2), i = ee - k * (EC + 2), c = c0 - 1 + i;
+        xk[r] = k;
+        xl[r] = e < NXV ? k * XS + i : -1;
+        xok[r] = e < NXV && c >= 0 && c < NX;
+        xoff[r] = xok[r] ? (size_t)c * sx : 0;
+    }
+    f32x4 wv[RW];
+    float xv[RX], sv[RX];
+    auto fetch = [&](int kc) {          // the chunk's loads, all in flight together
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wv[r] = *reinterpret_cast<const f32x4*>(wsrc[r] + (size_t)min(kc + wk[r], p.K - 1) * p.Mp);
+#pragma unroll
+        for (int r = 0; r < RX; ++r) {
+            const int k = min(kc + xk[r], p.K - 1);
+            xv[r] = inb[(size_t)k * iplane + xoff[r]];
+            sv[r] = (ISC && !compact) ? iscb[k] : 1.f;
+        }
+    };
+    fetch(0);
+    for (int kc = 0; kc < p.K; kc += EKC) {
+        __syncthreads();                  // the previous chunk's reads are done
+        // (K % 32 == 16: the upper half of the last chunk is zeros)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            *reinterpret_cast<f32x4*>(&ws[(tid + ET * r) * 4]) = kc + wk[r] < p.K ? wv[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < RX; ++r)
+            if (xl[r] >= 0) xs[xl[r]] = (xok[r] && kc + xk[r] < p.K) ? xv[r] * sv[r] : 0.f;
+        __syncthreads();
+        if (kc + EKC < p.K) fetch(kc + EKC);          // in flight during the multiply-adds below
+#pragma unroll 4
+        for (int kk = 0; kk < EKC / 2; ++kk) {
+            const int k = kh * (EKC / 2) + kk;
+            const float* xr = &xs[k * XS + CT * cg];              // cells c - 1 .. c + CT - 1 of this thread's first cell c = c0 + CT cg
+            float x[CT + 1];
+            if (CT == 4) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xr);
+                x[0] = x4[0]; x[1] = x4[1]; x[2] = x4[2]; x[3] = x4[3]; x[CT] = xr[4];
+            } else {
+#pragma unroll
+                for (int c = 0; c <= CT; ++c) x[c] = xr[c];
+            }
+            const f32x4 wn = *reinterpret_cast<const f32x4*>(&ws[(0 * EKC + k) * EM + 4 * mg]);
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(&ws[(1 * EKC + k) * EM + 4 * mg]);
+            const f32x4 wo = *reinterpret_cast<const f32x4*>(&ws[(2 * EKC + k) * EM + 4 * mg]);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const f32x2 wn2 = {wn[2 * m], wn[2 * m + 1]}, wf2 = {wf[2 * m], wf[2 * m + 1]}, wo2 = {wo[2 * m], wo[2 * m + 1]};
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const f32x2 xa = {x[c + 1], x[c + 1]}, xb = {x[c], x[c]};
+                    ae[m][c] = __builtin_elementwise_fma(wn2, xa, ae[m][c]);
+                    ae[m][c] = __builtin_elementwise_fma(wf2, xb, ae[m][c]);
+                    ao[m][c] = __builtin_elementwise_fma(wo2, xa, ao[m][c]);
+                }
+            }
+        }
+    }
+    // the two channel halves meet (fixed order: half 0 + half 1), then the direct kernel's epilogue: demodulation scale, bias, leaky ReLU
+    __syncthreads();
+    float* red = smem;                    // NACC partial sums per thread of half 1
+    if (kh == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                red[((m * CT + c) * 2 + 0) * 256 + t8] = ae[m >> 1][c][m & 1];
+                red[((m * CT + c) * 2 + 1) * 256 + t8] = ao[m >> 1][c][m & 1];
+            }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int mm = m0 + 4 * mg + m;
+        const float sc = p.osc ? p.osc[(size_t)b * p.M + mm] : 1.f, bi = p.bias ? p.bias[mm] : 0.f;
+        float* orow = p.out + ((size_t)b * p.M + mm) * oplane + obase;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int o = 2 * (c0 + CT * cg + c);
+            float ve = (ae[m >> 1][c][m & 1] + red[((m * CT + c) * 2 + 0) * 256 + t8]) * sc + bi;
+            float vo = (ao[m >> 1][c][m & 1] + red[((m * CT + c) * 2 + 1) * 256 + t8]) * sc + bi;
+            if (p.act >= 3) {
+                ve = (ve > 0.f ? ve : ve * 0.2f) * gain;
+                vo = (vo > 0.f ? vo : vo * 0.2f) * gain;
+            }
+            if (o < NOUT) orow[(size_t)o * so] = ve;
+            if (o + 1 < NOUT) orow[(size_t)(o + 1) * so] = vo;
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef T2_PROF
@@ -334,13 +519,13 @@ extern "C" int te_conv_t2s6_supported(int B, int K, int M, int H, int W) {
 // the body cells [0, H) x [0, W) of the transposed convolution (output rows 0 .. 2H - 1, columns 0 .. 2W - 1); conv.hip adds the last
 // output row and column as two thin regions of the fp32 kernel
 int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
-                   int B, int K, int M, int H, int W, hipStream_t s) {
+                   int B, int K, int M, int H, int W, hipStream_t s, float* colbuf) {
     TE_REQUIRE(te_conv_t2s6_supported(B, K, M, H, W), TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_T2S6): needs K %% 16 == 0 (>= 32), M %% 64 == 0, H %% 8 == 0, W %% 16 == 0 (te_conv_t2s6_supported)");
     TE_REQUIRE((reinterpret_cast<uintptr_t>(U) & 15) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, TE_ERR_UNSUPPORTED,
                "te_conv_f32(TE_CONV_T2S6): 16-byte aligned packed weights required");
     T2Args a{};
-    a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.act = act;
+    a.out = out; a.in = in; a.U = reinterpret_cast<const u32x4*>(U); a.isc = isc; a.osc = osc; a.bias = bias; a.act = act; a.colbuf = colbuf;
     a.B = B; a.K = K; a.M = M; a.H = H; a.W = W; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
     a.tiles_x = W / TWC; a.tiles_y = H / TH; a.mblocks = M / BM;
     a.ntiles = B * a.tiles_x * a.tiles_y;
@@ -357,4 +542,29 @@ int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc
         t2s6_kernel<false><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
     }
     return te::launch_status("te_conv_f32(TE_CONV_T2S6)");
+}
+
+// the last output row and column of the transposed kind (t2_edge_kernel); wplain = the Wp[tap][Kp][Mp] copy of the weights
+int te_t2s6_edge_launch(float* out, const float* in, const float* wplain, const float* isc, const float* osc, const float* bias, int act,
+                        int B, int K, int M, int H, int W, int Kp, int Mp, hipStream_t s, const float* colbuf) {
+    TE_REQUIRE(K % 16 == 0 && M % EM == 0 && (reinterpret_cast<uintptr_t>(wplain) & 15) == 0 && Mp % 4 == 0, TE_ERR_UNSUPPORTED,
+               "te_conv_f32(TE_CONV_T2S6): the edge kernel needs K %% 16 == 0, M %% 64 == 0 and 16-byte aligned weights");
+    T2EdgeArgs a{};
+    a.out = out; a.in = in; a.wp = wplain; a.isc = isc; a.osc = osc; a.bias = bias; a.act = act; a.colbuf = colbuf;
+    a.B = B; a.K = K; a.M = M; a.H = H; a.W = W; a.Kp = Kp; a.Mp = Mp; a.Ho = 2 * H + 1; a.Wo = 2 * W + 1;
+    const bool wide = W >= 64 && H >= 64;
+    const int EC = wide ? 64 : 32;
+    a.row_tiles = (int)te::cdiv(W, EC);                       // cells 0 .. W - 1 of the last output row
+    a.line_tiles = a.row_tiles + (int)te::cdiv(H + 1, EC);    // + cells 0 .. H of the last output column
+    a.mtiles = M / EM;
+    const int64_t blocks = (int64_t)a.line_tiles * a.mtiles * B;
+    TE_REQUIRE(blocks < 0x7FFFFFF0, TE_ERR_UNSUPPORTED, "te_conv_f32(TE_CONV_T2S6): too many edge blocks");
+    if (wide) {
+        if (isc) t2_edge_kernel<true, 4><<<dim3((unsigned)blocks), ET, 0, s>>>(a);
+        else t2_edge_kernel<false, 4><<<dim3((unsigned)blocks), ET, 0, s>>>(a);
+    } else {
+        if (isc) t2_edge_kernel<true, 2><<<dim3((unsigned)blocks), ET, 0, s>>>(a);
+        else t2_edge_kernel<false, 2><<<dim3((unsigned)blocks), ET, 0, s>>>(a);
+    }
+    return te::launch_status("te_conv_f32(TE_CONV_T2S6) edge");
 }
