@@ -7,13 +7,15 @@ import json
 import re
 import sys
 
-KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 'wgrad6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
+KEEP = ('conv_mfma', 'wino3x3', 'wino6', 's2s6', 't2s6', 't2_edge', 'wgrad6', 'wgrad_mfma', 'wgrad_reduce', 'fir_tile', 'blur44', 'bias_act', 'rgb_')
 # algorithmic bytes / flops of the launches in tools/kernel_once.py (B = 16)
 ALG = {
     'wino6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),       # algorithmic (direct-form) FLOPs
     'wino6p_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the ping-pong form, round 5)
     'wino6q_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # (the two-image form, round 6)
     's2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    's2s6q_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),     # (the two-image form, round 6)
+    't2_edge_kernel': dict(flops=2 * 3 * 256 * 128 * (257 + 256) * 16, bytes=16 * (256 * 128 * 2 + 128 * 513) * 4 + 3 * 256 * 128 * 4),
     't2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
