@@ -7,8 +7,8 @@
  *     buffer (the Python host allocates through the torch caching allocator);
  *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
  *     no synchronisation; safe to call from several host threads.  No global mutable state takes part in any RESULT; the only
- *     process-wide state are three debug / A-B switches that select between kernels with the same results (bit-identical for
- *     te_conv_wino6_form and te_conv_s2s6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
+ *     process-wide state are four debug / A-B switches that select between kernels with the same results (bit-identical for
+ *     te_conv_wino6_form, te_conv_s2s6_form and te_conv_t2s6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
  *     written by the product's own code paths) and the per-thread last-error string;
  *   - return 0 on success, a negative TE_ERR_* for argument validation failures, or a positive
  *     hipError_t if the launch failed; nothing throws across the ABI.  te_last_error_string()
@@ -249,6 +249,8 @@ int te_conv_wino6_form(int form);
  * Same products in the same order per output element: results are bit-identical.  TE_S2S6_FORM in the environment sets the
  * initial value. */
 int te_conv_s2s6_form(int form);
+/* the same switch for TE_CONV_T2S6 (t2s6q_kernel / t2s6_kernel; TE_T2S6_FORM) */
+int te_conv_t2s6_form(int form);
 /* TE_CONV_T2S6 only: `ws` of te_conv_ws_f32 / te_conv_res_f32 is an OPTIONAL scratch of te_conv_t2s6_ws_floats(B, K, H) = B * K * H
  * floats through which the body kernel hands the (style-scaled) last input column to the kernel that computes the last output
  * row / column (round 6); NULL is legal - that kernel then gathers the column from `in` itself, one cache line per element. */

@@ -135,3 +135,31 @@ def test_last_row_and_column_kernel_with_and_without_the_column_scratch(B, K, M,
     assert rel_err(got[:, :, 2 * H], want[:, :, 2 * H]) < 5e-6
     assert rel_err(got[:, :, :, 2 * W], want[:, :, :, 2 * W]) < 5e-6
     assert rel_err(got, want) < 5e-6
+
+
+@pytest.mark.parametrize('B,K,M,H,W', [(2, 32, 128, 8, 16), (3, 96, 256, 24, 32), (1, 48, 128, 16, 48), (2, 160, 128, 8, 16), (1, 512, 512, 16, 16),
+                                       (2, 128, 256, 32, 64), (5, 32, 384, 8, 32), (2, 64, 64, 8, 16), (3, 64, 192, 8, 32)])
+def test_split_bf16_transposed_kernel_forms_are_bit_identical(B, K, M, H, W):
+    """two-image form (t2s6q_kernel, round 6, default where M % 128 == 0 and every CU gets a block) and ping-pong form (t2s6_kernel) of
+    TE_CONV_T2S6: the same products in the same order per output element - identical bits, with style scales and the epilogue stages, on
+    single- and multi-tile images, 2 - 32 channel stages, 1 - 4 blocks of 128 output channels (form 2 = the two-image kernel whatever
+    the grid size; it runs the ping-pong kernel where M % 128 != 0)"""
+    x = synth.normal((B, K, H, W), f't6.fx.{K}.{H}').to(DEV)
+    w = (synth.normal((M, K, 3, 3), f't6.fw.{M}.{K}') / (3 * math.sqrt(K))).to(DEV)
+    isc, osc = (1 + 0.3 * synth.normal((B, K), 't6.fi')).to(DEV), (1 + 0.3 * synth.normal((B, M), 't6.fo')).to(DEV)
+    bias = synth.normal((M,), 't6.fb').to(DEV)
+    u6 = _lib.conv_pack(w, _lib.PACK_T6FWD, 0.9)
+    out = {}
+    old = _lib.t2s6_form(-1)
+    try:
+        for form in (0, 2):
+            _lib.t2s6_form(form)
+            out[form] = (_lib.conv(x, u6, _lib.CONV_T2S6, M, H, W, isc, osc, bias, 3), _lib.conv(x, u6, _lib.CONV_T2S6, M, H, W, None, None, bias, 4),
+                         _lib.conv(x, u6, _lib.CONV_T2S6, M, H, W))
+    finally:
+        _lib.t2s6_form(old)
+    assert _lib.t2s6_form(-1) == old
+    for a, b in zip(out[0], out[2]):
+        assert torch.equal(a, b)
+    want = F.conv_transpose2d(x.double(), (w.double() * 0.9).transpose(0, 1), stride=2)
+    assert rel_err(out[2][2], want) < 5e-6

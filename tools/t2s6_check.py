@@ -55,6 +55,16 @@ def main():
         flops = 2.0 * 9 * K * M * H * W * B
         t6, td = min(timeit(f6, n=20), timeit(f6, n=20)), min(timeit(fd, n=20), timeit(fd, n=20))
         msg += f' | split {t6 * 1e3:8.1f} us {flops / t6 / 1e9:6.1f} TF/s, fp32 kernel {td * 1e3:8.1f} us {flops / td / 1e9:6.1f} TF/s'
+        if hasattr(_lib.lib(), 'te_conv_t2s6_form') and M % 128 == 0:       # the ping-pong form of the same library, alternating
+            oldf = _lib.t2s6_form(0)
+            y0 = f6()
+            t0 = min(timeit(f6, n=20), timeit(f6, n=20))
+            _lib.t2s6_form(2)
+            y2 = f6()
+            t2 = min(timeit(f6, n=20), timeit(f6, n=20))
+            _lib.t2s6_form(oldf)
+            bad += 0 if torch.equal(y0, y2) else 1
+            msg += f' | ping-pong {t0 * 1e3:8.1f} us {flops / t0 / 1e9:6.1f}, two-image {t2 * 1e3:8.1f} us {flops / t2 / 1e9:6.1f} TF/s, identical {torch.equal(y0, y2)}'
         print(msg, flush=True)
     # the swapped layout: the launch as data gradient of a strided (down-sampling) convolution with weight [Co, Ci, 3, 3]
     for B, Co, Ci, H, W in [(2, 64, 128, 8, 16), (1, 128, 64, 16, 32)]:

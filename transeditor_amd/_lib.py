@@ -43,6 +43,7 @@ _SIGNATURES = {
     'te_conv_wino6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_wino6_form': (C.c_int, [_I]),
     'te_conv_s2s6_form': (C.c_int, [_I]),
+    'te_conv_t2s6_form': (C.c_int, [_I]),
     'te_conv_t2s6_ws_floats': (C.c_int64, [_I, _I, _I]),
     'te_conv_s2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_conv_t2s6_supported': (C.c_int, [_I, _I, _I, _I, _I]),
@@ -368,6 +369,11 @@ def s2s6_form(form=-1):
     """kernel form of TE_CONV_S2S6: 1 = two-image (default; M % 128 == 0 and a block per CU, else ping-pong), 2 = two-image wherever
     M % 128 == 0, 0 = ping-pong (bit-identical results); returns the previous value (-1: query only)"""
     return int(lib().te_conv_s2s6_form(form))
+
+
+def t2s6_form(form=-1):
+    """kernel form of TE_CONV_T2S6: as s2s6_form"""
+    return int(lib().te_conv_t2s6_form(form))
 
 
 def wino6_ok(B, K, M, H, W):

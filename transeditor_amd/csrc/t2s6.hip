@@ -333,6 +333,238 @@ __global__ __launch_bounds__(WT, 2) void t2s6_kernel(const T2Args p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: TWO 64-channel weight images per staged half tile (t2s6q_kernel, taken when M % 128 == 0) - wino6q_kernel's / s2s6q_kernel's
+// transformation on this kernel's double-buffered weight protocol.  A block owns 128 output channels: each half tile T_g(s) is staged
+// once and multiplied by the weight images (s, m = 0) and (s, m = 1) in two multiplying phases with their own accumulators (2 x 64
+// registers); image j = 2 s + m lives in buffer j & 1 and is renewed exactly as a stage was: part 0 of image j + 1 by group 1 at the
+// start of phase 2 j, part 1 by group 0 at the start of phase 2 j + 1, each waited for at the end of the issuing group's staging phase.
+//     group 0:   M0(s)  S  M1(s)  SW          group 1:   S  M0(s)  S  M1(s)  SW     (one phase behind)
+//     M0: 54 MFMAs + the fetch of stage s + 1     M1: 54 MFMAs + the staging arithmetic     S: weight DMA     SW: weight DMA + res -> T_g(s + 1)
+// Same products in the same order per output element as t2s6_kernel: bit-identical results (tests/test_gpu_t2s6.py).
+template <bool ISC>
+__global__ __launch_bounds__(WT, 2) void t2s6q_kernel(const T2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ul = reinterpret_cast<u32x4*>(smem_raw);                                   // weights, 16-byte chunks
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wq = wid & 3, wm = wq >> 1, wrl = wq & 1, gt = tid & (GT - 1);
+    unsigned* tl = reinterpret_cast<unsigned*>(smem_raw + 2 * U_SLOTS * 1024) + grp * TP_DWORDS;
+    const u32x4* tl4 = reinterpret_cast<const u32x4*>(tl);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int tq = jx / p.mblocks, mbq = jx % p.mblocks;               // (mblocks = M / 128 for this form)
+    const int tile = p.nt8 ? (int)(((int64_t)xcd * p.ntiles) >> 3) + tq : tq * 8 + xcd;
+    if (tile >= (p.nt8 ? (int)(((int64_t)(xcd + 1) * p.ntiles) >> 3) : p.ntiles)) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TWC, y0 = ty * TH, yh = y0 + PH * grp;
+    const size_t iplane = (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;
+    const float* inb = p.in + (size_t)b * p.K * iplane;
+    const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
+    const bool store_col = p.colbuf != nullptr && tx == p.tiles_x - 1 && mbq == 0;      // block-uniform (t2s6_kernel)
+
+    f32x16 acc[2][4];                                  // per weight image: one tile per output phase
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+
+    // staging geometry: as t2s6_kernel (one item per thread)
+    const bool live = gt < N_ITEMS;
+    const int ee = live ? gt : 0;
+    const int dq = ee & 3, rest = ee >> 2, cg = rest % NG, q = ((rest / NG) & 1) * 4 + dq, row = rest / (NG * 2);
+    const bool left = x0 == 0 && cg == 0, last_col = cg == NG - 1, rowout = yh - 1 + row < 0;
+    const int gy = rowout ? 0 : yh - 1 + row;
+    const unsigned g_off = (unsigned)((2 * q * p.H + gy) * p.W + x0 - 1 + 4 * cg + (left ? 1 : 0) - (last_col ? 3 : 0));
+    const int l_off = ((row * 2 + (q >> 2)) * CW + 4 * cg) * 4 + (q & 3);
+    const unsigned q2 = 2u * q;
+    const int MT = p.M >> 5;
+    f32x4 rin[2];
+    f32x2 rsc = {1.f, 1.f};
+    const int nstage = p.K / KC, nimg = 2 * nstage;
+    auto fetch_scales = [&](int s) {
+        if (ISC) rsc = *reinterpret_cast<const f32x2u*>(iscb + s * KC + q2);
+    };
+    auto fetch_item = [&](int s) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) rin[h2] = *reinterpret_cast<const f32x4u*>(inb + ((size_t)s * KC + h2) * iplane + g_off);
+    };
+    // weight part `uh` of image j = 2 s + m into buffer j & 1: uh = 0: taps 0-4 (30 slots), uh = 1: taps 5-8 (24 slots)
+    auto issue_u = [&](int uh, int j) {
+        const u32x4* us = p.U + (size_t)(j >> 1) * 27 * MT * 64;
+        const int mb = 2 * mbq + (j & 1);
+        u32x4* ub = ul + (j & 1) * (U_SLOTS * 64);
+        const int ntap = uh ? NTAP - UA_TAPS : UA_TAPS, tap0 = uh ? UA_TAPS : 0, n = ntap * 6;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int jw = wq + 4 * r;
+            if (jw >= n) break;
+            const int piece = jw / (ntap * 2), rem = jw % (ntap * 2), tap = tap0 + (rem >> 1), mt = rem & 1;
+            const int pt = piece * NTAP + tap;
+            const u32x4* g = us + ((size_t)pt * MT + 2 * mb + mt) * 64 + (unsigned)lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ub + (pt * 2 + mt) * 64), 16, 0, 0);
+        }
+    };
+    unsigned res[4][3];
+    float te = 0.f, to = 0.f, fe = 0.f, fo = 0.f;
+    auto arith = [&](int k, int sa) {           // t2s6_kernel's 17-slot program
+        if (k < 0) {
+        } else if (k == 0) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 v = rin[h2];
+                if (left) { v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = 0.f; }
+                if (last_col) v[0] = v[3];
+                if (rowout) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                rin[h2] = ISC ? v * rsc[h2] : v;
+                asm volatile("" : "+v"(rin[h2]));
+            }
+            if (store_col) {
+                if (last_col && live && !rowout) {
+                    float* cb = p.colbuf + ((size_t)b * p.K + (size_t)sa * KC + q2) * p.H + (yh - 1 + row);
+                    cb[0] = rin[0][0];
+                    cb[p.H] = rin[1][0];
+                }
+            }
+        } else if (k < N_SLOT) {
+            const int c = (k - 1) >> 2, j = (k - 1) & 3;
+            if (j == 0) {
+                te = rin[0][c]; to = rin[1][c];
+                const f32x2 t = {te, to};
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[c][0] = h;
+                fe = __builtin_bit_cast(float, h << 16);
+                fo = __builtin_bit_cast(float, h & 0xFFFF0000u);
+            } else if (j == 1) {
+                te -= fe; to -= fo;
+            } else if (j == 2) {
+                const f32x2 t = {te, to};
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                res[c][1] = m;
+                fe = __builtin_bit_cast(float, m << 16);
+                fo = __builtin_bit_cast(float, m & 0xFFFF0000u);
+            } else {
+                te -= fe; to -= fo;
+                const f32x2 t = {te, to};
+                res[c][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                asm volatile("" : "+v"(res[c][2]));
+            }
+            asm volatile("" : "+v"(te), "+v"(to), "+v"(fe), "+v"(fo));
+        }
+    };
+    auto write_res = [&]() {
+        if (!live) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c > 0 && last_col) continue;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) tl[l_off + c * 4 + pc * TP_PLANE] = res[c][pc];
+        }
+    };
+    const int rr = l31 >> 4, jj = l31 & 15;
+    const int b_chunk = ((2 * wrl + rr + 1) * 2 + half) * CW + jj + 1;
+    const int a_chunk = wm * 64 + lane;
+
+    // one multiplying phase (global phase ph: image ph >> 1) with accumulator set MSET; behind the MFMAs: MSET 0 the fetch of stage
+    // `fs`, MSET 1 the staging arithmetic on it
+    auto multiply = [&](auto mset_tag, int ph, int fs) {
+        constexpr int MSET = decltype(mset_tag)::value;
+        bf16x8 av[2][3], bv[2][3];
+        const u32x4* ua = ul + ((ph >> 1) & 1) * (U_SLOTS * 64) + a_chunk;
+        auto rd1 = [&](int t, int slot, int qq) {
+            const int ky = t / 3, kx = t % 3;
+            if (qq < 3) av[slot][qq] = __builtin_bit_cast(bf16x8, ua[(qq * NTAP + t) * 128]);
+            else bv[slot][qq - 3] = __builtin_bit_cast(bf16x8, tl4[b_chunk - (ky == 2 ? 2 * CW : 0) - (kx == 2 ? 1 : 0) + (qq - 3) * (TP_PLANE / 4)]);
+        };
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+        for (int qq = 0; qq < 6; ++qq) rd1(0, 0, qq);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int slot = t & 1, c = ((t / 3) & 1) * 2 + ((t % 3) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq) {
+                acc[MSET][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][PA[qq]], bv[slot][PB[qq]], acc[MSET][c], 0, 0, 0);
+                if (t + 1 < NTAP && qq < 3) { rd1(t + 1, slot ^ 1, 2 * qq); rd1(t + 1, slot ^ 1, 2 * qq + 1); }
+                const int k = t * 6 + qq;
+                if (MSET == 0) {
+                    if (k == 11) fetch_scales(fs);            // (rin is free: the m = 1 phase consumed it)
+                    if (k == 12) fetch_item(fs);
+                } else {
+                    arith(k - SLOT0, fs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        t2_barrier();                                  // end of phase
+    };
+    // one phase in the staging role: this group's part (ph & 1) of image (ph >> 1) + 1 into the buffer image (ph >> 1) - 1 was read from,
+    // waited for at the end of the phase; WRITE: the parked split results go to the half tile
+    auto stage = [&](int ph, bool write) {
+        const int cw = (ph >> 1) + 1;
+        if (cw < nimg) issue_u(ph & 1, cw);
+        __builtin_amdgcn_sched_barrier(0);
+        if (write) write_res();
+        t2_wait_vm();
+        t2_barrier();                                  // end of phase
+    };
+
+    // prologue: every group splits and writes its half of stage 0; group 0 brings in the whole weight image 0
+    fetch_scales(0);
+    fetch_item(0);
+    if (grp == 0) { issue_u(0, 0); issue_u(1, 0); }
+#pragma unroll
+    for (int k = 0; k < N_SLOT; ++k) arith(k, 0);
+    write_res();
+    t2_wait_vm();
+    t2_barrier();
+    int ph = 0;
+    if (grp == 1) { stage(0, false); ph = 1; }
+    for (int s = 0; s < nstage; ++s) {
+        const int fs = min(s + 1, nstage - 1);
+        multiply(std::integral_constant<int, 0>{}, ph, fs);
+        stage(ph + 1, false);
+        multiply(std::integral_constant<int, 1>{}, ph + 2, fs);
+        if (!(grp == 1 && s == nstage - 1)) stage(ph + 3, true);
+        ph += 4;
+    }
+
+    // epilogue: t2s6_kernel's, once per accumulator set
+    const int ci = yh + 2 * wrl + rr, cj = x0 + jj;
+    const float g_pos = p.act == 3 ? 1.4142135623730951f : 1.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int mbase = (2 * mbq + m) * BM + wm * 32;
+        const size_t off0 = ((size_t)b * p.M + mbase) * oplane + (size_t)(2 * ci) * p.Wo + 2 * cj;
+        float scv[16], biv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+            scv[r] = p.osc ? p.osc[(size_t)b * p.M + mbase + dm] : 1.f;
+            biv[r] = p.bias ? p.bias[mbase + dm] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dm = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float v0 = acc[m][a * 2][r] * scv[r] + biv[r], v1 = acc[m][a * 2 + 1][r] * scv[r] + biv[r];
+                if (p.act >= 3) {
+                    v0 = (v0 > 0.f ? v0 : v0 * 0.2f) * g_pos;
+                    v1 = (v1 > 0.f ? v1 : v1 * 0.2f) * g_pos;
+                }
+                f32x2 v; v[0] = v0; v[1] = v1;
+                *reinterpret_cast<f32x2u*>(p.out + off0 + (size_t)dm * oplane + (size_t)a * p.Wo) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Round 6: the LAST OUTPUT ROW AND COLUMN of the transposed kind (cells i = H / j = W) as one small vector-ALU launch.
 //
 // Until now they were two thin regions of conv_mfma_kernel<TE_CONV_T2>: a few dozen blocks of 128-cell tiles with one valid cell row or
@@ -516,6 +748,16 @@ extern "C" int te_conv_t2s6_supported(int B, int K, int M, int H, int W) {
             (int64_t)B * (H / TH) * (W / TWC) * (M / BM) < 0x7FFFFFF0) ? 1 : 0;
 }
 
+// kernel form of TE_CONV_T2S6: 0 = ping-pong (t2s6_kernel); 1 = the two-image form t2s6q_kernel where M % 128 == 0 and the grid still
+// gives every CU a block, the ping-pong form elsewhere; 2 = the two-image form wherever M % 128 == 0 (tests).  Same results bit for bit.
+// A process-wide A/B switch like te_conv_wino6_form (te_hip.h); TE_T2S6_FORM in the environment sets the initial value.
+static std::atomic<int> g_t2_form{[] { const char* e = getenv("TE_T2S6_FORM"); return e ? atoi(e) : 1; }()};
+extern "C" int te_conv_t2s6_form(int form) {
+    const int old = g_t2_form.load(std::memory_order_relaxed);
+    if (form >= 0 && form <= 2) g_t2_form.store(form, std::memory_order_relaxed);
+    return old;
+}
+
 // the body cells [0, H) x [0, W) of the transposed convolution (output rows 0 .. 2H - 1, columns 0 .. 2W - 1); conv.hip adds the last
 // output row and column as two thin regions of the fp32 kernel
 int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc, const float* osc, const float* bias, int act,
@@ -533,7 +775,19 @@ int te_t2s6_launch(float* out, const float* in, const float* U, const float* isc
     const int64_t blocks = te::cdiv(a.ntiles, 8) * 8 * a.mblocks;
     const size_t lds = 2 * (size_t)U_SLOTS * 1024 + 2 * (size_t)TP_DWORDS * 4;
     static std::atomic<uint64_t> attr_done{0};
-    if (isc) {
+    const int form = g_t2_form.load(std::memory_order_relaxed);
+    const int64_t blocks_q = te::cdiv(a.ntiles, 8) * 8 * (M / (2 * BM));
+    if (form >= 1 && M % (2 * BM) == 0 && (form == 2 || blocks_q >= te::kNumCU)) {
+        static std::atomic<uint64_t> attr_done_q{0}, attr_done_qs{0};
+        a.mblocks = M / (2 * BM);
+        if (isc) {
+            te::allow_big_lds(attr_done_qs, (const void*)t2s6q_kernel<true>, 160 * 1024);
+            t2s6q_kernel<true><<<dim3((unsigned)blocks_q), WT, lds, s>>>(a);
+        } else {
+            te::allow_big_lds(attr_done_q, (const void*)t2s6q_kernel<false>, 160 * 1024);
+            t2s6q_kernel<false><<<dim3((unsigned)blocks_q), WT, lds, s>>>(a);
+        }
+    } else if (isc) {
         static std::atomic<uint64_t> attr_done_sc{0};
         te::allow_big_lds(attr_done_sc, (const void*)t2s6_kernel<true>, 160 * 1024);
         t2s6_kernel<true><<<dim3((unsigned)blocks), WT, lds, s>>>(a);
