@@ -7,9 +7,10 @@
  *     buffer (the Python host allocates through the torch caching allocator);
  *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
  *     no synchronisation; safe to call from several host threads.  No global mutable state takes part in any RESULT; the only
- *     process-wide state are four debug / A-B switches that select between kernels with the same results (bit-identical for
- *     te_conv_wino6_form, te_conv_s2s6_form and te_conv_t2s6_form, fp32-equivalent for te_wgrad_split_bf16; both atomics, initialised from the environment, never
- *     written by the product's own code paths) and the per-thread last-error string;
+ *     process-wide state are five debug / A-B switches that select between kernels with the same results (bit-identical for
+ *     te_conv_wino6_form, te_conv_s2s6_form, te_conv_t2s6_form and te_wgrad_t2_wide, fp32-equivalent for te_wgrad_split_bf16; all
+ *     atomics, initialised from the environment, never written by the product's own code paths) and the per-thread last-error
+ *     string;
  *   - return 0 on success, a negative TE_ERR_* for argument validation failures, or a positive
  *     hipError_t if the launch failed; nothing throws across the ABI.  te_last_error_string()
  *     describes the calling thread's most recent failure.
@@ -287,6 +288,10 @@ int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W);
  * kernel elsewhere. */
 int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W);
 int te_wgrad_split_bf16(int on);
+/* Round 6: form of the split transposed-kind kernel - 1 (default): a block owns 64 channels of the (2H+1) x (2W+1) tensor x 128 of the
+ * H x W one where Ci % 128 == 0 (half the staging work and re-reads of the big tensor per MFMA), 0: 64 x 64 everywhere.  Bit-identical
+ * slabs; returns the previous value, any other argument only queries; TE_WGRAD_T2_WIDE in the environment sets the initial value. */
+int te_wgrad_t2_wide(int on);
 int te_wgrad_f32(float* slabs, const float* g, const float* x, int kind, int B, int Co, int Ci, int H,
                  int W, int S, te_stream_t stream);
 /* GROUPED form for the PLAIN (unmodulated) weight gradient of small images: NB consecutive samples share one slab

@@ -208,3 +208,27 @@ def test_split_bf16_weight_gradient_selection_and_switch():
     _lib.wgrad_split(0)
     b = _lib.wgrad_slabs(g, x, _lib.CONV_3X3, 16, 16)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 64, 128, 8, 16), (3, 128, 256, 13, 32), (1, 64, 384, 20, 48), (2, 192, 128, 5, 16), (2, 128, 128, 64, 64),
+                                         (4, 64, 128, 1, 16), (1, 256, 512, 16, 16)])
+def test_split_bf16_weight_gradient_transposed_kind_wide_form_is_bit_identical(B, Co, Ci, H, W):
+    """wgrad6tw_kernel (round 6: 64 channels of the big tensor x 128 of the small one per block, taken where Ci % 128 == 0) against
+    wgrad6t_kernel (64 x 64): the same products in the same order per slab element - identical bits; 1 - 4 blocks of 128 channels, 1 - 3
+    of 64, single rows, odd row counts, several samples; and against fp64"""
+    g = synth.normal((B, Co, 2 * H + 1, 2 * W + 1), f'wg6w.g.{Co}.{H}').to(DEV)
+    x = synth.normal((B, Ci, H, W), f'wg6w.x.{Ci}.{H}').to(DEV)
+    _lib.wgrad_split(1)
+    old = _lib.wgrad_t2_wide(-1)
+    try:
+        _lib.wgrad_t2_wide(0)
+        narrow = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+        _lib.wgrad_t2_wide(1)
+        wide = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+    finally:
+        _lib.wgrad_t2_wide(old)
+    assert _lib.wgrad_t2_wide(-1) == old
+    assert torch.equal(narrow, wide)
+    want = torch.stack([torch.nn.grad.conv2d_weight(g[b:b + 1].double(), (Ci, Co, 3, 3), x[b:b + 1].double(), stride=2)
+                        for b in range(B)]).transpose(1, 2).reshape(B, Co, Ci, 9)
+    assert rel_err(wide.sum(1), want) < 5e-6

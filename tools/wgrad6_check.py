@@ -84,7 +84,8 @@ def main():
         print(msg, flush=True)
     # ---- transposed kind: slab[co][ci][ky][kx] = sum g[co, 2i + ky, 2j + kx] x[ci, i, j]
     small_t = [(2, 64, 64, 8, 16), (3, 128, 64, 13, 32), (1, 64, 192, 20, 48), (4, 64, 64, 5, 16), (1, 64, 64, 1, 16)]
-    big_t = [(16, 128, 128, 128, 128), (16, 256, 256, 64, 64), (16, 512, 512, 32, 32), (16, 512, 512, 16, 16), (32, 256, 128, 64, 64)]
+    big_t = [(16, 128, 128, 128, 128), (16, 256, 256, 64, 64), (16, 512, 512, 32, 32), (16, 512, 512, 16, 16), (32, 256, 128, 64, 64),
+             (16, 128, 256, 128, 128), (16, 256, 512, 64, 64), (32, 128, 256, 128, 128)]       # (the last three: the model's own (Co, Ci) at these sizes)
     for B, Co, Ci, H, W in small_t + ([] if os.environ.get('SMALL') else big_t):
         assert _lib.wgrad_split_ok(_lib.CONV_T2, Co, Ci, H, W), (Co, Ci, H, W)
         torch.manual_seed(0)
@@ -113,6 +114,18 @@ def main():
             _lib.wgrad_split(on)
             t[on] = min(t.get(on, 1e9), timeit(lambda: _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W), n=10))
         msg += f' | split {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s, fp32 kernel {t[0] * 1e3:8.1f} us {flops / t[0] / 1e9:6.1f} TF/s'
+        if hasattr(_lib.lib(), 'te_wgrad_t2_wide') and Ci % 128 == 0 and Co % 64 == 0:       # 64 x 64 form of the same library, alternating
+            _lib.wgrad_split(1)
+            tw = {}
+            ow = {}
+            for wide in (0, 1, 0, 1):
+                oldw = _lib.wgrad_t2_wide(wide)
+                ow[wide] = _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)
+                tw[wide] = min(tw.get(wide, 1e9), timeit(lambda: _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W), n=10))
+                _lib.wgrad_t2_wide(oldw)
+            same = torch.equal(ow[0], ow[1])
+            bad += 0 if same else 1
+            msg += f' | 64x64 {tw[0] * 1e3:8.1f} us {flops / tw[0] / 1e9:6.1f}, 64x128 {tw[1] * 1e3:8.1f} us {flops / tw[1] / 1e9:6.1f} TF/s, identical {same}'
         if os.environ.get('PROF'):
             _lib.wgrad_split(1)
             _lib.wgrad_slabs(g, x, _lib.CONV_T2, H, W)

@@ -54,6 +54,7 @@ _SIGNATURES = {
     'te_wgrad_pair_form': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_wgrad_split_supported': (C.c_int, [_I, _I, _I, _I, _I]),
     'te_wgrad_split_bf16': (C.c_int, [_I]),
+    'te_wgrad_t2_wide': (C.c_int, [_I]),
     'te_wgrad_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'te_wgrad_group_plan': (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P]),
     'te_wgrad_group_f32': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -432,6 +433,12 @@ def wgrad_slabs(g, x, kind, H, W, group=False):
     slabs = torch.empty(B, S, Co, Ci, taps, device=g.device, dtype=g.dtype)
     _check(lib().te_wgrad_f32(_ptr(slabs), _ptr(g), _ptr(x), kind, B, Co, Ci, H, W, S, _stream()), 'te_wgrad_f32')
     return slabs
+
+
+def wgrad_t2_wide(on=-1):
+    """form of the split transposed-kind weight-gradient kernel: 1 = 64 x 128 channels per block where Ci % 128 == 0 (default), 0 = 64 x 64
+    (bit-identical slabs); returns the previous value (-1: query only)"""
+    return int(lib().te_wgrad_t2_wide(on))
 
 
 def wgrad_split(on=-1):

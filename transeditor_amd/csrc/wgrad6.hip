@@ -605,6 +605,240 @@ __global__ __launch_bounds__(WT, 1) void wgrad6t_kernel(const Wg6Args p) {
     }
 }
 
+// WIDE form of the transposed kind (round 6, Ci % 128 == 0 - every transposed-kind layer of the FFHQ-256 model): the block tile is 64
+// channels of g x 128 channels of x.  The counters place wgrad6t_kernel BELOW the power cap (45.5 % MFMA busy at 2.2 GHz, HBM reads 2.1x the
+// algorithmic bytes): its vector-ALU staging - which a wave's own MFMAs do not hide (r05_wgrad6.log) - is the g unit (17 columns, 3
+// components) plus an x unit per wave and step of 54 MFMAs, and waves 2, 3 repeated the x units of waves 0, 1.  Here a wave multiplies
+// its 32 rows of g by 32 channels of BOTH x tiles (108 MFMAs per step, 2 x 9 accumulators = 288 registers of the 512 a lone wave per SIMD
+// owns), stages the same g unit and - waves 2, 3 - an x unit of the second tile: half the staging instructions, LDS writes and g loads
+// per MFMA, and g is read Ci / 128 instead of Ci / 64 times.  Same products in the same order per slab element: bit-identical slabs.
+__global__ __launch_bounds__(WT, 1) void wgrad6tw_kernel(const Wg6Args p) {
+    constexpr bool NARROW = false;
+    constexpr int XI2 = 2 * XI;                   // x-row image of this form: [x tile 2][piece 3][k half 2][channel 64]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 32 x 32 tile
+    const int rsel = wid >> 1, q = wid & 1;                   // staging: g row 2i + 3 + rsel and x tile rsel, cells 8 q .. 8 q + 7 of the step; lane = channel
+
+    const Wg6Chunk ck = wg6_chunk(p.S, p.NB * (p.W / 16));
+    const int s_chunk = ck.s, bgrp = ck.bgrp, b = bgrp * p.NB;
+    const int co0 = blockIdx.y * TC, ci0 = blockIdx.z * 2 * TC;
+    const int Hg = 2 * p.H + 1, Wg = 2 * p.W + 1;
+    const size_t gplane = (size_t)Hg * Wg, xplane = (size_t)p.H * p.W;
+    // addresses = uniform 64-bit base (scalar registers) + this lane's 32-bit byte offset (its channel): the scalar-base form of the
+    // global loads, no 64-bit vector arithmetic in the step
+    const float* gblk = p.g + ((size_t)b * p.Co + co0) * gplane;             // channel block of the group's first sample
+    const float* xblk = p.x + ((size_t)b * p.Ci + ci0) * xplane;
+    const int g_ch = lane, x_ch = rsel * TC + lane;           // (waves 2, 3 stage the second x tile: no wave repeats another's unit)
+    const unsigned g_lane = (unsigned)(g_ch * gplane * 4), x_lane = (unsigned)(x_ch * xplane * 4);       // bytes (host-checked < 2 GiB)
+
+    f32x16 acc[2][9];                                         // [x tile][ky * 3 + kx]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+    // rows past the end are clamped to the last row (their registers are never used: no element of g or x is padding)
+    auto load_g = [&](float (&rg)[17], int bb, int cx, int grow) {
+        const char* src = reinterpret_cast<const char*>(gblk + (size_t)bb * p.Co * gplane + (size_t)min(grow, Hg - 1) * Wg + 2 * (16 * cx + 8 * q));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 16 * k + g_lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rg[4 * k + e] = v[e];
+        }
+        rg[16] = *reinterpret_cast<const float*>(src + 64 + g_lane);
+    };
+    auto load_x = [&](float (&rx)[8], int bb, int cx, int xrow) {
+        const char* src = reinterpret_cast<const char*>(xblk + (size_t)bb * p.Ci * xplane + (size_t)min(xrow, p.H - 1) * p.W + 16 * cx + 8 * q);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 16 * k + x_lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rx[4 * k + e] = v[e];
+        }
+    };
+    // split of one packed pair of values in three steps; units 0..4: even columns of the g unit (pair d = columns 4d, 4d + 2; the
+    // last one holds column 16 alone), 5..8: odd columns (4d + 1, 4d + 3), 9..12: the x unit
+    unsigned pe[3][5], po[3][4], px[3][4];
+    float v0 = 0.f, v1 = 0.f, f0 = 0.f, f1 = 0.f;
+    auto unit_step = [&](const float (&rg)[17], const float (&rx)[8], int u, int step) {
+        unsigned& d0 = u < 5 ? pe[0][u] : (u < 9 ? po[0][u - 5] : px[0][u - 9]);
+        unsigned& d1 = u < 5 ? pe[1][u] : (u < 9 ? po[1][u - 5] : px[1][u - 9]);
+        unsigned& d2 = u < 5 ? pe[2][u] : (u < 9 ? po[2][u - 5] : px[2][u - 9]);
+        if (step == 0) {
+            if (u < 5) { v0 = rg[4 * u]; v1 = u < 4 ? rg[4 * u + 2] : 0.f; }
+            else if (u < 9) { v0 = rg[4 * (u - 5) + 1]; v1 = rg[4 * (u - 5) + 3]; }
+            else { v0 = rx[2 * (u - 9)]; v1 = rx[2 * (u - 9) + 1]; }
+            const f32x2 t = {v0, v1};
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d0 = h;
+            f0 = __builtin_bit_cast(float, h << 16);
+            f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
+        } else if (step == 1) {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d1 = m;
+            f0 = __builtin_bit_cast(float, m << 16);
+            f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
+        } else {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            d2 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+        }
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));
+    };
+    const int w_elem = q * TC + lane;             // + ((piece * 3 + component) * 2) * 64 (g) / (piece * 2) * 64 (x)
+    auto write_g = [&](int gimg, int comp, int pc) {          // component 0: even columns, 1: odd columns, 2: even columns from the second on
+        u32x4 v;
+        if (comp == 0) { v[0] = pe[pc][0]; v[1] = pe[pc][1]; v[2] = pe[pc][2]; v[3] = pe[pc][3]; }
+        else if (comp == 1) { v[0] = po[pc][0]; v[1] = po[pc][1]; v[2] = po[pc][2]; v[3] = po[pc][3]; }
+        else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) v[d] = __builtin_amdgcn_alignbit(pe[pc][d + 1], pe[pc][d], 16);
+        }
+        lds[gimg * GI + (pc * 3 + comp) * 2 * TC + w_elem] = v;
+    };
+    auto write_x = [&](int ximg, int pc) {
+        u32x4 v; v[0] = px[pc][0]; v[1] = px[pc][1]; v[2] = px[pc][2]; v[3] = px[pc][3];
+        lds[NGR * GI + ximg * XI2 + rsel * XI + pc * 2 * TC + w_elem] = v;
+    };
+    // the staging program: slots 0..38 = 13 units x 3 steps, the writes of a finished group in the slot of its last step (the
+    // shifted component in slots 39..41)
+    auto stage_slot = [&](const float (&rg)[17], const float (&rx)[8], int k, int gimg, int ximg) {
+        if (k < 39) unit_step(rg, rx, k / 3, k % 3);
+        if (k == 14) { write_g(gimg, 0, 0); write_g(gimg, 0, 1); write_g(gimg, 0, 2); }
+        if (k == 26) { write_g(gimg, 1, 0); write_g(gimg, 1, 1); write_g(gimg, 1, 2); }
+        if (k == 38) { write_x(ximg, 0); write_x(ximg, 1); write_x(ximg, 2); }
+        if (k >= 39 && k < 42) write_g(gimg, 2, k - 39);
+    };
+
+    const int tiles_x = p.W / 16;
+    const int sps = tiles_x * p.H, n_steps = sps * p.NB;
+    const int a_elem = half * TC + wco * 32 + l31;
+    const int b_elem = NGR * GI + half * TC + wci * 32 + l31;
+
+#ifdef WG6_PROF
+    unsigned long long pc_mult = 0, pc_head = 0, pc_bar = 0;
+    const unsigned long long pstart = __builtin_readcyclecounter();
+    int nstep_done = 0;
+#endif
+    float rg[17], rx[8], ng[17], nx[8];
+    for (int sg = 0; sg < ck.nseg; ++sg) {
+    int t, t_end;
+    wg6_segment(ck, sg, p.S, p.H, n_steps, t, t_end);
+    while (t < t_end) {
+        const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
+        const int n = min(p.H - ya, t_end - t), yb = ya + n;
+        t += n;
+#ifdef WG6_PROF
+        const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
+        // ---- head of a sweep: g rows 2 ya .. 2 ya + 3 into ring slots 0..3, x row ya into buffer ya & 1, registers of the first step
+        {
+            float g0[17], g1[17];
+            load_g(g0, bb, cx, 2 * ya + rsel);
+            load_g(g1, bb, cx, 2 * ya + 2 + rsel);
+            load_x(nx, bb, cx, ya);
+            load_g(rg, bb, cx, 2 * ya + 3 + rsel);
+            load_x(rx, bb, cx, ya + 1);
+#pragma unroll
+            for (int k = 0; k < 42; ++k) stage_slot(g0, nx, k, rsel, ya & 1);
+#pragma unroll
+            for (int k = 0; k < 42; ++k) stage_slot(g1, nx, k, 2 + rsel, ya & 1);
+#pragma unroll
+            for (int i = 0; i < 17; ++i) asm volatile("" :: "v"(rg[i]));          // (wait for the first step's registers here: wgrad6_kernel)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(rx[i]));
+        }
+        w6g_barrier();
+#ifdef WG6_PROF
+        pc_head += __builtin_readcyclecounter() - th0;
+#endif
+        int s0 = 0;                                           // ring slot of g row 2 y
+        for (int y = ya; y < yb; ++y) {
+#ifdef WG6_PROF
+            const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
+            load_g(ng, bb, cx, 2 * y + 5 + rsel);             // registers of the step after next
+            load_x(nx, bb, cx, y + 2);
+            int wslot = s0 + 3 + rsel; wslot -= wslot >= NGR ? NGR : 0;
+            int a_base[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { int sl = s0 + ky; sl -= sl >= NGR ? NGR : 0; a_base[ky] = sl * GI + a_elem; }
+            const int b_base = b_elem + (y & 1) * XI2;
+            bf16x8 av[2][3], bx[2][3];
+            auto rd_a = [&](int tp, int pc) {
+                const int ky = tp / 3, kx = tp % 3;
+                av[tp & 1][pc] = __builtin_bit_cast(bf16x8, lds[a_base[ky] + (pc * 3 + kx) * 2 * TC]);
+            };
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                bx[0][pc] = __builtin_bit_cast(bf16x8, lds[b_base + pc * 2 * TC]);
+                bx[1][pc] = __builtin_bit_cast(bf16x8, lds[b_base + XI + pc * 2 * TC]);
+                rd_a(0, pc);
+            }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 6; ++qq) {
+                        acc[j][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tp & 1][PA[qq]], bx[j][PB[qq]], acc[j][tp], 0, 0, 0);
+                        if (tp + 1 < 9 && j == 0 && qq < 3) rd_a(tp + 1, qq);          // (the other operand slot: last used by tap tp - 1)
+                        // the 42-slot staging program behind every other MFMA of the first 84 (108 per step)
+                        const int k = tp * 12 + j * 6 + qq;
+                        if ((k & 1) == 0) stage_slot(rg, rx, k >> 1, wslot, (y + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+#ifdef WG6_PROF
+            const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+            for (int i = 0; i < 17; ++i) rg[i] = ng[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rx[i] = nx[i];
+            s0 += 2; s0 -= s0 >= NGR ? NGR : 0;
+            w6g_barrier();
+#ifdef WG6_PROF
+            { const unsigned long long tm2 = __builtin_readcyclecounter(); pc_mult += tm1 - tm0; pc_bar += tm2 - tm1; ++nstep_done; }
+#endif
+        }
+    }
+    }
+#ifdef WG6_PROF
+    {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lane == 0 && lin < 2048) {
+            unsigned long long* d = te_wgrad6_prof_buf + ((size_t)lin * 4 + wid) * 4;
+            d[0] = pc_mult; d[1] = pc_head; d[2] = pc_bar;
+            d[3] = ((unsigned long long)nstep_done << 40) | ((__builtin_readcyclecounter() - pstart) & 0xFFFFFFFFFFull);
+        }
+    }
+#endif
+
+    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci * 9;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + j * TC + wci * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = sl + ((size_t)co * p.Ci + ci) * 9;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) dst[tp] = acc[j][tp][r];
+        }
+    }
+}
+
 // on by default; TE_SPLIT_WGRAD=0 (or TE_SPLIT_BF16=0, the switch of all split kernels) keeps the fp32 kernel - A/B measurements
 std::atomic<int> g_wg6_on{[] {
     const char* e = getenv("TE_SPLIT_WGRAD");
@@ -628,6 +862,15 @@ extern "C" int te_debug_wgrad6_prof(void* host_dst, int64_t bytes) {
 extern "C" int te_wgrad_split_bf16(int on) {
     const int old = g_wg6_on.load(std::memory_order_relaxed);
     if (on == 0 || on == 1) g_wg6_on.store(on, std::memory_order_relaxed);
+    return old;
+}
+
+// form of the transposed-kind kernel: 1 (default) = the wide form (64 x 128 channels per block) where Ci % 128 == 0, 0 = 64 x 64 everywhere;
+// bit-identical slabs.  A process-wide A/B switch (te_hip.h); TE_WGRAD_T2_WIDE in the environment sets the initial value.
+static std::atomic<int> g_wg6t_wide{[] { const char* e = getenv("TE_WGRAD_T2_WIDE"); return e ? atoi(e) : 1; }()};
+extern "C" int te_wgrad_t2_wide(int on) {
+    const int old = g_wg6t_wide.load(std::memory_order_relaxed);
+    if (on == 0 || on == 1) g_wg6t_wide.store(on, std::memory_order_relaxed);
     return old;
 }
 
@@ -659,6 +902,12 @@ int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int
         // for the H x W one (the fp32 kernel takes the launch otherwise, as for the 3x3 kind below)
         if ((int64_t)NB * std::max(Co, Ci) * (2 * (int64_t)H + 1) * (2 * (int64_t)W + 1) * 4 >= (int64_t)OOBW) return 0;
         const size_t lds = (size_t)(NGR * GI + 2 * XI) * 16;
+        if (Co % TC == 0 && Ci % (2 * TC) == 0 && g_wg6t_wide.load(std::memory_order_relaxed)) {      // wide form: 64 x 128 channels per block
+            static std::atomic<uint64_t> attr_done_tw{0};
+            te::allow_big_lds(attr_done_tw, (const void*)wgrad6tw_kernel, 160 * 1024);
+            wgrad6tw_kernel<<<dim3(grid.x, grid.y, (unsigned)(Ci / (2 * TC))), WT, (size_t)(NGR * GI + 4 * XI) * 16, s>>>(a);
+            return 1;
+        }
         if (Co % TC == 0 && Ci % TC == 0) {
             static std::atomic<uint64_t> attr_done_t{0};
             te::allow_big_lds(attr_done_t, (const void*)wgrad6t_kernel<false>, 160 * 1024);
