@@ -22,10 +22,10 @@ python tools/pmc_summary.py gpurun_out/pmc gpurun_out/${TAG} > gpurun_out/${TAG}
 rm -f gpurun_out/pmc/*.db gpurun_out/pmc/*.csv
 ( FORM2=1 timeout 120 python tools/wino6_ab.py; timeout 120 python tools/s2s6_check.py; timeout 120 python tools/t2s6_check.py; timeout 200 python tools/wgrad6_check.py; timeout 200 python tools/p1s6_check.py ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_split_kernels_check.log
 for f in old new; do
-  if [ $f = old ]; then export TE_W6_FORM=1 TE_SPLIT_1X1=0; else unset TE_W6_FORM TE_SPLIT_1X1; fi
+  if [ $f = old ]; then export TE_W6_FORM=1 TE_SPLIT_1X1=0 TE_S2S6_FORM=0 TE_T2S6_FORM=0 TE_T2_EDGE=0 TE_WGRAD_T2_WIDE=0; else unset TE_W6_FORM TE_SPLIT_1X1 TE_S2S6_FORM TE_T2S6_FORM TE_T2_EDGE TE_WGRAD_T2_WIDE; fi
   timeout 300 python bench.py --steps 16 --warmup 4 --no-sub --no-cpu-baseline --no-pmc > gpurun_out/${TAG}_bench_quick_r6_switches_$f.json 2>/dev/null
 done
-unset TE_W6_FORM TE_SPLIT_1X1
+unset TE_W6_FORM TE_SPLIT_1X1 TE_S2S6_FORM TE_T2S6_FORM TE_T2_EDGE TE_WGRAD_T2_WIDE
 ( timeout 120 python tools/power_probe.py ) > gpurun_out/${TAG}_power_clock_product.txt 2>&1
 python - <<PY
 import json
