@@ -219,7 +219,7 @@ class KernelTimer:
                 'peaks': {'bf16_mfma_dense': PEAK_BF16_TFLOPS, 'fp32_mfma': PEAK_FP32_TFLOPS},
                 'traffic': traffic, 'traffic_note': note, 'traffic_source': 'static',
                 'kernel': W6_KERNEL.get(_w6_form(), 'wino6_kernel') +
-                          ' / s2s6q_kernel / t2s6_kernel / wgrad6_kernel / wgrad6t_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / '
+                          ' / s2s6q_kernel / t2s6q_kernel / wgrad6_kernel / wgrad6tw_kernel (v_mfma_f32_32x32x16_bf16, three-piece split) / '
                           'wino3x3_kernel / conv_mfma_kernel / wgrad_mfma_kernel (fp32 v_mfma_f32_32x32x2) where the split kernels do '
                           'not apply; all 3x3 kinds',
                 'dominant_kernel': dominant,
@@ -263,10 +263,10 @@ PMC_PASSES = (('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE 
 PMC_KERNELS = {'conv3x3_fwd_128to128_at256_b16': 'wino6', 'conv3x3_fp32_winograd_kernel_same_shape': 'wino3x3_kernel',
                'conv3x3_direct_kernel_same_shape': 'conv_mfma_kernel<0',
                'wgrad3x3_128x128_at256_b16': 'wgrad6_kernel', 'wgrad3x3_fp32_kernel_same_shape': 'wgrad_mfma_kernel<0',
-               'convT2_256to128_at128_b16': 't2s6_kernel', 'convS2_128to256_at128_b16': 's2s6',
+               'convT2_256to128_at128_b16': 't2s6', 'convS2_128to256_at128_b16': 's2s6',
                'convT2_fp32_kernel_same_shape': 'conv_mfma_kernel<1, 0, true, false, 2, true', 'convS2_fp32_kernel_same_shape': 'conv_mfma_kernel<2',
                'convT2_last_row_and_column': 't2_edge_kernel',
-               'wgradT2_256x128_at128_b16': 'wgrad6t_kernel', 'wgradT2_fp32_kernel_same_shape': 'wgrad_mfma_kernel<1'}
+               'wgradT2_256x128_at128_b16': 'wgrad6t', 'wgradT2_fp32_kernel_same_shape': 'wgrad_mfma_kernel<1'}
 
 
 def live_counters(timeout_s=150):

@@ -17,10 +17,12 @@ ALG = {
     's2s6q_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),     # (the two-image form, round 6)
     't2_edge_kernel': dict(flops=2 * 3 * 256 * 128 * (257 + 256) * 16, bytes=16 * (256 * 128 * 2 + 128 * 513) * 4 + 3 * 256 * 128 * 4),
     't2s6_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    't2s6q_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),     # (the two-image form, round 6)
     'wino3x3_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),     # algorithmic (direct-form) FLOPs
     'conv_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'wgrad6_kernel': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),      # split-bf16 weight gradient (round 5)
     'wgrad6t_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
+    'wgrad6tw_kernel': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),  # (the 64 x 128 form, round 6)
     'wgrad_mfma_kernel<0': dict(flops=2 * 9 * 128 * 128 * 256 * 256 * 16, bytes=2 * 16 * 128 * 256 * 256 * 4),
     'conv_mfma_kernel<1, 0, true, false, 2, true': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
     'conv_mfma_kernel<2': dict(flops=2 * 9 * 256 * 128 * 128 * 128 * 16, bytes=16 * (256 * 128 * 128 + 128 * 257 * 257) * 4),
@@ -101,5 +103,27 @@ def main(src='gpurun_out/pmc', tag='profiles/r04'):
     print('\n'.join(lines))
 
 
+def refresh(tag):
+    """recompute the derived columns (TF/s, algorithmic MB) of a stored <tag>_pmc_summary.json after ALG gained entries"""
+    out = json.load(open(tag + '_pmc_summary.json'))
+    for k, v in out.items():
+        alg = next((a for p, a in ALG.items() if k.startswith(p)), None)
+        if alg:
+            v['tflops'] = alg['flops'] / v['us'] / 1e6 if alg['flops'] else 0.0
+            v['algorithmic_mb'] = alg['bytes'] / 1e6
+    lines = [f'{"kernel":42s} {"us":>8s} {"MHz":>6s} {"MFMA%":>6s} {"TF/s":>6s} {"HBM rd MB":>10s} {"wr MB":>8s} {"alg MB":>8s} '
+             f'{"GB/s":>7s} {"LDSconf%":>8s}']
+    for k, v in out.items():
+        alg, conf = v['algorithmic_mb'], v['lds_conflict_pct']
+        lines.append(f'{k[:42]:42s} {v["us"]:8.1f} {v["mhz"]:6.0f} {v["mfma_util_pct"]:6.1f} {v["tflops"]:6.1f} {v["hbm_read_mb"]:10.1f} '
+                     f'{v["hbm_write_mb"]:8.1f} {(alg if alg is not None else float("nan")):8.1f} {v["gbs"]:7.0f} '
+                     f'{(conf if conf is not None else float("nan")):8.1f}')
+    open(tag + '_pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
+    json.dump(out, open(tag + '_pmc_summary.json', 'w'), indent=1)
+
+
 if __name__ == '__main__':
-    main(*sys.argv[1:])
+    if len(sys.argv) == 3 and sys.argv[1] == '--refresh':
+        refresh(sys.argv[2])
+    else:
+        main(*sys.argv[1:])
