@@ -195,7 +195,9 @@ def test_split_bf16_weight_gradient_selection_and_switch():
     assert ok(_lib.CONV_3X3, 32, 32, 1024, 1024) and not ok(_lib.CONV_3X3, 32, 64, 32, 32)        # ... or the 32 x 32 sample-pair form
     assert not ok(_lib.CONV_3X3, 128, 128, 16, 16) and not ok(_lib.CONV_3X3, 128, 128, 32, 48)    # whole 32-column tiles only
     assert ok(_lib.CONV_T2, 128, 128, 32, 32) and ok(_lib.CONV_T2, 512, 512, 16, 16)
-    assert not ok(_lib.CONV_T2, 128, 128, 8, 8) and not ok(_lib.CONV_T2, 80, 128, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 32, 32)
+    assert not ok(_lib.CONV_T2, 128, 128, 8, 8) and not ok(_lib.CONV_T2, 80, 128, 32, 32)
+    assert ok(_lib.CONV_1X1, 128, 128, 32, 32) and ok(_lib.CONV_1X1, 512, 256, 64, 64)          # round 6: whole 128-channel blocks, W % 16 == 0
+    assert not ok(_lib.CONV_1X1, 128, 64, 32, 32) and not ok(_lib.CONV_1X1, 128, 128, 8, 8) and not ok(_lib.CONV_1X1, 128, 128, 32, 24)
     assert ok(_lib.CONV_T2, 32, 64, 512, 512) and ok(_lib.CONV_T2, 96, 128, 32, 32) and not ok(_lib.CONV_T2, 32, 32, 32, 32)   # narrow sides
     old = _lib.wgrad_split(0)
     assert _lib.wgrad_split() == 0 and _lib.wgrad_split(1) == 0 and _lib.wgrad_split() == 1
@@ -232,3 +234,47 @@ def test_split_bf16_weight_gradient_transposed_kind_wide_form_is_bit_identical(B
     want = torch.stack([torch.nn.grad.conv2d_weight(g[b:b + 1].double(), (Ci, Co, 3, 3), x[b:b + 1].double(), stride=2)
                         for b in range(B)]).transpose(1, 2).reshape(B, Co, Ci, 9)
     assert rel_err(wide.sum(1), want) < 5e-6
+
+
+@pytest.mark.parametrize('B,Co,Ci,H,W', [(2, 128, 128, 8, 16), (3, 256, 128, 13, 32), (1, 128, 384, 20, 48), (4, 128, 128, 1, 16), (2, 256, 128, 64, 64),
+                                         (2, 128, 128, 5, 80), (8, 512, 512, 16, 16)])
+def test_split_bf16_weight_gradient_1x1_kind_vs_fp64(B, Co, Ci, H, W):
+    """kind TE_CONV_1X1 (round 6, wgrad6p_kernel): slab[co][ci] = sum over cells g[co, cell] x[ci, cell] - the weight gradient of the
+    discriminator's ResBlock skip convolutions (model_spatial_query.py:173-181, :780-798) - against fp64 and the fp32 kernel: single rows,
+    odd row counts, 1 - 3 blocks of 128 channels per side, several column tiles, and the grouped form (samples share a slab)"""
+    assert _lib.wgrad_split_ok(_lib.CONV_1X1, Co, Ci, H, W)
+    g = synth.normal((B, Co, H, W), f'wg6p.g.{Co}.{H}').to(DEV)
+    x = synth.normal((B, Ci, H, W), f'wg6p.x.{Ci}.{H}').to(DEV)
+    want = torch.einsum('bohw,bihw->boi', g.double(), x.double())
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W)
+    _lib.wgrad_split(0)
+    ref = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W)
+    # (the chunk count S follows the kernel that runs: 128 x 128 channel blocks for the split kernel)
+    assert got.shape[0] == ref.shape[0] == B and tuple(got.shape[2:]) == tuple(ref.shape[2:]) == (Co, Ci, 1)
+    got, ref = got.sum(1).squeeze(-1), ref.sum(1).squeeze(-1)
+    l2 = lambda a: float((a.double() - want).norm() / want.norm())
+    print(f'split-bf16 weight gradient, 1x1 kind {Ci}->{Co} @{H}x{W} B{B}: max {rel_err(got, want):.2e} (fp32 kernel {rel_err(ref, want):.2e}), '
+          f'L2 {l2(got):.2e} ({l2(ref):.2e})')
+    assert rel_err(got, want) < 5e-6
+    assert l2(got) < 2.5 * l2(ref) + 1e-7
+    # grouped form: the plain gradient, samples of a group share a slab
+    _lib.wgrad_split(1)
+    gg = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W, group=True)
+    _lib.wgrad_split(0)
+    gr = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W, group=True)
+    assert tuple(gg.shape[2:]) == tuple(gr.shape[2:]) == (Co, Ci, 1)
+    assert rel_err(gg.sum((0, 1)).squeeze(-1), want.sum(0)) < 5e-6
+    assert rel_err(gr.sum((0, 1)).squeeze(-1), want.sum(0)) < 5e-6
+
+
+@pytest.mark.parametrize('scale', [1e-30, 1e-12, 1e12, 1e18])
+def test_split_bf16_weight_gradient_1x1_kind_range(scale):
+    B, Co, Ci, H, W = 2, 128, 128, 8, 32
+    g = (synth.normal((B, Co, H, W), 'wg6p.rg') * math.sqrt(scale)).to(DEV)
+    x = (synth.normal((B, Ci, H, W), 'wg6p.rx') * math.sqrt(scale)).to(DEV)
+    want = torch.einsum('bohw,bihw->boi', g.double(), x.double())
+    _lib.wgrad_split(1)
+    got = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W).sum(1).squeeze(-1)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 5e-6

@@ -132,6 +132,38 @@ def main():
             torch.cuda.synchronize()
             msg += ' | ' + prof(B * out[1].shape[1] * (Co // 64) * (Ci // 64)).replace('2304', '1728')
         print(msg, flush=True)
+    # ---- 1x1 kind (round 6): slab[co][ci] = sum g[co, cell] x[ci, cell]
+    for B, Co, Ci, H, W in [(2, 128, 128, 8, 16), (3, 256, 128, 13, 32)] + ([] if os.environ.get('SMALL') else
+                                                                         [(32, 256, 128, 128, 128), (32, 512, 256, 64, 64), (32, 512, 512, 32, 32), (32, 512, 512, 16, 16),
+                                                                          (16, 256, 128, 128, 128)]):
+        assert _lib.wgrad_split_ok(_lib.CONV_1X1, Co, Ci, H, W), (Co, Ci, H, W)
+        torch.manual_seed(0)
+        g = torch.randn(B, Co, H, W, device=DEV)
+        x = torch.randn(B, Ci, H, W, device=DEV)
+        out = {}
+        for on in (0, 1):
+            _lib.wgrad_split(on)
+            out[on] = _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W)
+        s0, s1 = out[0].sum(1), out[1].sum(1)
+        msg = f'1x1 B{B} {Ci}->{Co} @{H}x{W} (S={out[0].shape[1]}):'
+        if B * Co * Ci * H * W <= 2 ** 28:
+            want = torch.einsum('bohw,bihw->boi', g.double(), x.double()).unsqueeze(-1)
+            e1, e0 = rel(s1, want), rel(s0, want)
+            msg += f' vs fp64 (max / L2): split {e1:.2e} / {rel2(s1, want):.2e}, fp32 kernel {e0:.2e} / {rel2(s0, want):.2e}'
+            bad += 0 if e1 < 5e-6 else 1
+        else:
+            e = rel(s1, s0)
+            msg += f' vs fp32 kernel: {e:.2e} / {rel2(s1, s0):.2e}'
+            bad += 0 if e < 5e-6 else 1
+        flops = 2.0 * Co * Ci * H * W * B
+        t = {}
+        for on in (0, 1, 0, 1):
+            _lib.wgrad_split(on)
+            t[on] = min(t.get(on, 1e9), timeit(lambda: _lib.wgrad_slabs(g, x, _lib.CONV_1X1, H, W), n=10))
+        gb = (g.numel() + x.numel()) * 4 / 1e9
+        msg += (f' | split {t[1] * 1e3:8.1f} us {flops / t[1] / 1e9:6.1f} TF/s {gb / t[1]:5.2f} TB/s, fp32 kernel {t[0] * 1e3:8.1f} us '
+                f'{flops / t[0] / 1e9:6.1f} TF/s')
+        print(msg, flush=True)
     # grouped form (samples share a slab): plain gradient of small images
     for B, Co, Ci, H, W in [(8, 128, 128, 32, 32), (32, 512, 512, 32, 32)]:
         g = torch.randn(B, Co, H, W, device=DEV)

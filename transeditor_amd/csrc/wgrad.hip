@@ -917,6 +917,8 @@ extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W
     int64_t mn = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH) * (int64_t)B;
     // the sample-pair form of csrc/wgrad6.hip (Co == Ci == 32) runs one block per PAIR of samples and chunk
     if (te_wgrad_split_bf16(-1) == 1 && te_wgrad_split_supported(kind, Co, Ci, H, W) == 2 && B % 2 == 0) mn = B / 2;
+    // the split 1x1 kernel (wgrad6p_kernel, round 6) has 128 x 128 channel blocks
+    if (kind == TE_CONV_1X1 && te_wgrad_split_bf16(-1) == 1 && te_wgrad_split_supported(kind, Co, Ci, H, W) == 1) mn = (int64_t)(Co / 128) * (Ci / 128) * B;
     // blocks per CU the split aims at: the 8-wave 3x3 / T2 blocks own a CU (two 68 KB operand images), so ONE round of them
     // does the same work as two with half the slab bytes for the reducer (same-box A/B, round 3: +0.8 % / +1.2 % on the
     // kernels, half the te_wgrad_reduce traffic of the narrow layers); the light 1x1 blocks share a CU and want two
@@ -936,7 +938,8 @@ extern "C" int te_wgrad_slab_count(int kind, int B, int Co, int Ci, int H, int W
 extern "C" int te_wgrad_group_plan(int kind, int B, int Co, int Ci, int H, int W, int* NB_out, int* S_out) {
     if (B <= 0 || Co <= 0 || Ci <= 0 || H <= 0 || W <= 0 || !NB_out || !S_out) return TE_ERR_SHAPE;
     const int tiles = n_cell_tiles(kind, H, W);
-    const int64_t mn1 = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH);
+    int64_t mn1 = te::cdiv((int64_t)Co * Ci, (pick_nwp(Co, Ci) * 32) * QCH);
+    if (kind == TE_CONV_1X1 && te_wgrad_split_bf16(-1) == 1 && te_wgrad_split_supported(kind, Co, Ci, H, W) == 1) mn1 = (int64_t)(Co / 128) * (Ci / 128);
     const int64_t per_sample = std::max<int64_t>((int64_t)Co * (kind == TE_CONV_T2 ? (2 * H + 1) * (2 * W + 1) : H * W), (int64_t)Ci * H * W) * 4;
     int NB = 1;
     // whole channel blocks only: the 16-byte staging path masks a channel tail through the END of the sample's buffer range, and

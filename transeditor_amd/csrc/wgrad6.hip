@@ -839,6 +839,170 @@ __global__ __launch_bounds__(WT, 1) void wgrad6tw_kernel(const Wg6Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- 1x1 kind (round 6)
+// TE_CONV_1X1 (the weight gradient of the discriminator's ResBlock skip convolutions, model_spatial_query.py:173-181 / :780-798):
+//     slab[b][s][co][ci] = sum over the cells of chunk s of sample b   g[b, co, cell] * x[b, ci, cell]
+// One tap: six piece products per 16 cells and 32 x 32 channels, so every staged element is used for 1/9 of the MFMAs it feeds in the
+// 3x3 kinds, and the staging decides the shape: block tile 128 x 128 channels, 4 waves (one per SIMD, as the other kernels of this
+// file), wave (wco, wci) owns 64 x 64 = 2 x 2 sub-tiles (64 accumulator registers): 24 MFMAs per step of 16 cells, fed by 6 + 6
+// operand reads, while the wave splits one g unit and one x unit (64 channels x 8 cells each = 4 packed pairs x 3 split steps: 24
+// slots, one behind every MFMA).  Both tensors are plain H x W planes: no components, no ring - g and x rows are
+// [piece 3][k half 2][channel 64] images (6 KB) per 64-channel group, double-buffered (48 KB of LDS in all).  Same step order, chunk
+// mapping, prefetch distance (the loads of step y + 2 at the head of step y) and slab layout as wgrad6t_kernel; the fp32 kernel
+// (wgrad_mfma_kernel<TE_CONV_1X1>) ran these launches at 70 - 77 TFLOP/s, the HBM floor (both tensors read once) is a third of its time.
+constexpr int PI = 3 * 2 * TC;                // elements of one 64-channel row image: 384 (6 KB)
+
+__global__ __launch_bounds__(WT, 1) void wgrad6p_kernel(const Wg6Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem_raw);          // [side: g, x][buffer 2][group 2][PI]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wid >> 1, wci = wid & 1;                  // multiplying: the wave's 64 x 64 quarter of the block tile
+    const int grp = wid >> 1, q = wid & 1;                    // staging: channel group `grp` of g AND of x, cells 8 q .. 8 q + 7 of the step; lane = channel
+
+    const Wg6Chunk ck = wg6_chunk(p.S, p.NB * (p.W / 16));
+    const int s_chunk = ck.s, bgrp = ck.bgrp, b = bgrp * p.NB;
+    const int co0 = blockIdx.y * 2 * TC, ci0 = blockIdx.z * 2 * TC;
+    const size_t plane = (size_t)p.H * p.W;
+    const float* gblk = p.g + ((size_t)b * p.Co + co0) * plane;
+    const float* xblk = p.x + ((size_t)b * p.Ci + ci0) * plane;
+    const unsigned ch_lane = (unsigned)((grp * TC + lane) * plane * 4);        // bytes (host-checked < 2 GiB)
+
+    f32x16 acc[2][2];                                         // [co sub-tile][ci sub-tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // rows past the end are clamped to the last row (their registers are never used)
+    auto load8 = [&](float (&r8)[8], const float* blk, int C, int bb, int cx, int row) {
+        const char* src = reinterpret_cast<const char*>(blk + (size_t)bb * C * plane + (size_t)min(row, p.H - 1) * p.W + 16 * cx + 8 * q);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 16 * k + ch_lane);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r8[4 * k + e] = v[e];
+        }
+    };
+    // split of one packed pair in three steps (wgrad6t_kernel: unit_step); units 0..3: the g unit, 4..7: the x unit
+    unsigned pg[3][4], px[3][4];
+    float v0 = 0.f, v1 = 0.f, f0 = 0.f, f1 = 0.f;
+    auto unit_step = [&](const float (&rg)[8], const float (&rx)[8], int u, int step) {
+        unsigned& d0 = u < 4 ? pg[0][u] : px[0][u - 4];
+        unsigned& d1 = u < 4 ? pg[1][u] : px[1][u - 4];
+        unsigned& d2 = u < 4 ? pg[2][u] : px[2][u - 4];
+        if (step == 0) {
+            if (u < 4) { v0 = rg[2 * u]; v1 = rg[2 * u + 1]; }
+            else { v0 = rx[2 * (u - 4)]; v1 = rx[2 * (u - 4) + 1]; }
+            const f32x2 t = {v0, v1};
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d0 = h;
+            f0 = __builtin_bit_cast(float, h << 16);
+            f1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
+        } else if (step == 1) {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+            d1 = m;
+            f0 = __builtin_bit_cast(float, m << 16);
+            f1 = __builtin_bit_cast(float, m & 0xFFFF0000u);
+        } else {
+            v0 -= f0; v1 -= f1;
+            const f32x2 t = {v0, v1};
+            d2 = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+        }
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(f0), "+v"(f1));
+    };
+    const int w_elem = grp * PI + q * TC + lane;              // + side * 4 PI + buffer * 2 PI + piece * 2 TC
+    auto write_g = [&](int buf, int pc) {
+        u32x4 v; v[0] = pg[pc][0]; v[1] = pg[pc][1]; v[2] = pg[pc][2]; v[3] = pg[pc][3];
+        lds[buf * 2 * PI + pc * 2 * TC + w_elem] = v;
+    };
+    auto write_x = [&](int buf, int pc) {
+        u32x4 v; v[0] = px[pc][0]; v[1] = px[pc][1]; v[2] = px[pc][2]; v[3] = px[pc][3];
+        lds[4 * PI + buf * 2 * PI + pc * 2 * TC + w_elem] = v;
+    };
+    // the staging program: slots 0..23 = 8 units x 3 steps; the writes of a side in the slot of its last step
+    auto stage_slot = [&](const float (&rg)[8], const float (&rx)[8], int k, int buf) {
+        if (k < 24) unit_step(rg, rx, k / 3, k % 3);
+        if (k == 11) { write_g(buf, 0); write_g(buf, 1); write_g(buf, 2); }
+        if (k == 23) { write_x(buf, 0); write_x(buf, 1); write_x(buf, 2); }
+    };
+
+    const int tiles_x = p.W / 16;
+    const int sps = tiles_x * p.H, n_steps = sps * p.NB;
+    const int a_elem = wco * PI + half * TC + l31;                            // + sub-tile * 32 + buffer * 2 PI + piece * 2 TC
+    const int b_elem = 4 * PI + wci * PI + half * TC + l31;
+
+    float rg[8], rx[8], ng[8], nx[8];
+    for (int sg = 0; sg < ck.nseg; ++sg) {
+    int t, t_end;
+    wg6_segment(ck, sg, p.S, p.H, n_steps, t, t_end);
+    while (t < t_end) {
+        const int bb = t / sps, rem = t - bb * sps, cx = rem / p.H, ya = rem - cx * p.H;
+        const int n = min(p.H - ya, t_end - t), yb = ya + n;
+        t += n;
+        // ---- head of a sweep: row ya into buffer ya & 1, registers of the next step
+        {
+            float g0[8], x0[8];
+            load8(g0, gblk, p.Co, bb, cx, ya);
+            load8(x0, xblk, p.Ci, bb, cx, ya);
+            load8(rg, gblk, p.Co, bb, cx, ya + 1);
+            load8(rx, xblk, p.Ci, bb, cx, ya + 1);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) stage_slot(g0, x0, k, ya & 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { asm volatile("" :: "v"(rg[i])); asm volatile("" :: "v"(rx[i])); }       // (wait for the first step's registers here)
+        }
+        w6g_barrier();
+        for (int y = ya; y < yb; ++y) {
+            load8(ng, gblk, p.Co, bb, cx, y + 2);             // registers of the step after next
+            load8(nx, xblk, p.Ci, bb, cx, y + 2);
+            const int cur = (y & 1) * 2 * PI, nxt = (y + 1) & 1;
+            bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    av[i][pc] = __builtin_bit_cast(bf16x8, lds[cur + a_elem + i * 32 + pc * 2 * TC]);
+                    bv[i][pc] = __builtin_bit_cast(bf16x8, lds[cur + b_elem + i * 32 + pc * 2 * TC]);
+                }
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};        // small terms first: mm, hl, lh, hm, mh, hh
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int qq = 0; qq < 6; ++qq) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA[qq]], bv[j][PB[qq]], acc[i][j], 0, 0, 0);
+                        stage_slot(rg, rx, (i * 2 + j) * 6 + qq, nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { rg[i] = ng[i]; rx[i] = nx[i]; }
+            w6g_barrier();
+        }
+    }
+    }
+
+    float* sl = p.slabs + ((size_t)bgrp * p.S + s_chunk) * p.Co * p.Ci;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wci * TC + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * TC + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                sl[(size_t)co * p.Ci + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // on by default; TE_SPLIT_WGRAD=0 (or TE_SPLIT_BF16=0, the switch of all split kernels) keeps the fp32 kernel - A/B measurements
 std::atomic<int> g_wg6_on{[] {
     const char* e = getenv("TE_SPLIT_WGRAD");
@@ -849,6 +1013,8 @@ std::atomic<int> g_wg6_on{[] {
 
 // TE_SPLIT_WGRAD_T2=0: the transposed kind alone stays on the fp32 kernel (A/B measurements)
 std::atomic<int> g_wg6t_on{[] { const char* e = getenv("TE_SPLIT_WGRAD_T2"); return (e && atoi(e) == 0) ? 0 : 1; }()};
+// TE_SPLIT_WGRAD_1X1=0: the 1x1 kind alone stays on the fp32 kernel (A/B measurements)
+std::atomic<int> g_wg6p_on{[] { const char* e = getenv("TE_SPLIT_WGRAD_1X1"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 
 }  // namespace
 
@@ -885,6 +1051,8 @@ extern "C" int te_wgrad_split_supported(int kind, int Co, int Ci, int H, int W) 
         if (!(W >= 16 && W % 16 == 0)) return 0;
         return (Co % 32 == 0 && Ci % 32 == 0 && Co + Ci >= 96) ? 1 : 0;      // (32 x 32: a quarter of the tile - stays on the fp32 kernel)
     }
+    if (kind == TE_CONV_1X1)                                                  // round 6: wgrad6p_kernel, 128 x 128 channels per block
+        return (W >= 16 && W % 16 == 0 && Co % (2 * TC) == 0 && Ci % (2 * TC) == 0) ? 1 : 0;
     return 0;
 }
 
@@ -896,6 +1064,14 @@ int te_wgrad6_launch(float* slabs, const float* g, const float* x, int kind, int
     Wg6Args a{};
     a.slabs = slabs; a.g = g; a.x = x; a.B = B; a.Co = Co; a.Ci = Ci; a.H = H; a.W = W; a.S = S; a.NB = NB; a.tiles_x = W / 32;
     dim3 grid((unsigned)(B / NB * S), (unsigned)te::cdiv(Co, TC), (unsigned)te::cdiv(Ci, TC));
+    if (kind == TE_CONV_1X1) {
+        if (!g_wg6p_on.load(std::memory_order_relaxed)) return 0;
+        if ((int64_t)NB * std::max(Co, Ci) * H * W * 4 >= (int64_t)OOBW) return 0;           // 32-bit byte offsets inside a sample group
+        static std::atomic<uint64_t> attr_done_p1{0};
+        te::allow_big_lds(attr_done_p1, (const void*)wgrad6p_kernel, 160 * 1024);
+        wgrad6p_kernel<<<dim3(grid.x, (unsigned)(Co / (2 * TC)), (unsigned)(Ci / (2 * TC))), WT, (size_t)8 * PI * 16, s>>>(a);
+        return 1;
+    }
     if (kind == TE_CONV_T2) {
         if (!g_wg6t_on.load(std::memory_order_relaxed)) return 0;
         // 32-bit byte offsets inside a sample group: lane * plane * 4 over the 64 channels of a tile, for the (2H+1) x (2W+1) tensor and
