@@ -575,29 +575,32 @@ __global__ __launch_bounds__(WT, 2) void t2s6q_kernel(const T2Args p) {
 //     out[m][2i + 0][2W] = sum_k s_k ( w[m][k][0][2] in[k][i][W-1] + w[m][k][2][2] in[k][i-1][W-1] )      i = 0 .. H (the corner: i = H)
 //     out[m][2i + 1][2W] = sum_k s_k   w[m][k][1][2] in[k][i][W-1]
 // (model_spatial_query.py:310-321: conv_transpose2d(stride 2, pad 0); taps as packed: t = 3 ky + kx).  Block = 64 output channels x 64 (32)
-// line cells of one sample, 1 024 threads = four groups that each take 8 of a chunk's 32 input channels and meet through LDS at the end;
-// thread = 4 channels x 4 (2) cells, per input channel 48 (24) multiply-adds from three 16-byte weight reads (broadcast over the 16
-// lanes that share the channels) and one 20 (12)-byte line read; the next chunk's global loads are in flight during the multiply-adds
-// (the first version without that prefetch and with 16-channel chunks: 82 - 87 us per launch, latency-bound).  Weights from the plain fp32 copy behind the split layout
-// (TE_PACK_T6FWD / T6SWAP: Wp[tap][Kp][Mp]), plain fp32 arithmetic, fixed summation order.
-constexpr int EM = 64, EKC = 32, EKS = 4, ET = 256 * EKS;          // (EKS: groups of 256 threads that share a chunk's input channels)
+// line cells of one sample, 8 waves: a wave owns a 32 x 32 (channel x cell) tile - even and odd outputs, 2 x 16 accumulator registers -
+// and a share of every 32-channel chunk's channel PAIRS; per pair three v_mfma_f32_32x32x2_f32 (near, odd, far: bit for bit an fp32 FMA
+// chain) fed by five 4-byte LDS reads; the wave groups meet through LDS at the end in a fixed order; the next chunk's global loads are in
+// flight during the multiply-adds.  (First versions on the vector ALU: scalar FMAs 54 - 92 us, v_pk_fma_f32 37 - 70 us per launch at the
+// two large shapes - packed fp32 issues at half rate here -; with loads inside branches 82 - 130 us, latency-bound.)  Weights from the plain
+// fp32 copy behind the split layout (TE_PACK_T6FWD / T6SWAP: Wp[tap][Kp][Mp]), plain fp32 arithmetic, fixed summation order.
+constexpr int EM = 64, EKC = 32, ET = 512;
 struct T2EdgeArgs {
     float* out; const float* in; const float* wp; const float* isc; const float* osc; const float* bias; int act;
     const float* colbuf;     // optional [B][K][H]: the style-scaled last input column as left by t2s6_kernel (NULL: gathered from `in`)
     int B, K, M, H, W, Kp, Mp, Ho, Wo, row_tiles, line_tiles, mtiles;
 };
 
-// CT = line cells per thread (4: tile of 64 cells, lines of >= 64 cells; 2: tile of 32 cells)
+// CT: line tile of 16 CT cells (4: lines of >= 64 cells; 2: 32-cell tiles)
 template <bool ISC, int CT>
 __global__ __launch_bounds__(ET) void t2_edge_kernel(const T2EdgeArgs p) {
     constexpr int EC = 16 * CT, XS = EC + 4, NXV = EKC * (EC + 2), NW = 3 * EKC * (EM / 4);      // line tile, LDS row stride, staged values
     constexpr int RW = (NW + ET - 1) / ET, RX = (NXV + ET - 1) / ET;                              // 16-byte weight / 4-byte line loads per thread and chunk
-    constexpr int NACC = 4 * CT * 2;
-    constexpr int SMEM = (3 * EKC * EM + EKC * XS) > 256 * NACC ? (3 * EKC * EM + EKC * XS) : 256 * NACC;
+    constexpr int NT = 2 * (EC / 32), KG = 8 / NT;             // 32 x 32 (channel x cell) wave tiles of the block; wave groups that share a chunk's channels
+    constexpr int SMEM = 3 * EKC * EM + EKC * XS;              // (>= NT * 64 * 32: the partial tiles of one wave group)
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* ws = smem;                           // [tap: even-near, even-far, odd][k][m]
     float* xs = smem + 3 * EKC * EM;            // [k][cell c0 - 1 .. c0 + EC] (+ pad)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw = wid % NT, kg = wid / NT, wm = tw & 1, wc = tw >> 1;      // the wave's tile: channels m0 + 32 wm .., cells c0 + 32 wc ..; its channel group
     int bx = blockIdx.x;
     const int lt = bx % p.line_tiles; bx /= p.line_tiles;
     const int mt = bx % p.mtiles, b = bx / p.mtiles;
@@ -610,18 +613,12 @@ __global__ __launch_bounds__(ET) void t2_edge_kernel(const T2EdgeArgs p) {
     const size_t xbase = compact ? 0 : (col ? (size_t)(p.W - 1) : (size_t)(p.H - 1) * p.W);
     const size_t obase = col ? (size_t)(2 * p.W) : (size_t)(2 * p.H) * p.Wo;
     const int tap_near = col ? 2 : 6, tap_far = 8, tap_odd = col ? 5 : 7;  // even outputs: (ky, kx) = (0, 2) | (2, 0) and (2, 2); odd: (1, 2) | (2, 1)
-    const int kh = tid >> 8, t8 = tid & 255, mg = t8 >> 4, cg = t8 & 15;
     const size_t iplane = compact ? (size_t)p.H : (size_t)p.H * p.W, oplane = (size_t)p.Ho * p.Wo;       // (iplane: channel stride of the line source)
     const float* inb = (compact ? p.colbuf : p.in) + (size_t)b * p.K * iplane + xbase;
     const float* iscb = ISC ? p.isc + (size_t)b * p.K : nullptr;
-    // accumulators as channel PAIRS (m, m + 1): one v_pk_fma_f32 per pair and cell (the weight pair is an aligned half of the 16-byte
-    // read, the line value is broadcast) - 24 (12) packed instructions per input channel instead of 48 (24) scalar ones; the scalar
-    // form measured 54 - 92 us per launch at 160 - 192 blocks, bound by instruction issue
-    f32x2 ae[2][CT], ao[2][CT];
+    f32x16 ae, ao;                              // even / odd outputs of the wave's 32 channels x 32 cells
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) { ae[m][c] = f32x2{0.f, 0.f}; ao[m][c] = f32x2{0.f, 0.f}; }
+    for (int r = 0; r < 16; ++r) { ae[r] = 0.f; ao[r] = 0.f; }
 
     // per-thread staging geometry (the same for every chunk): weight items e = tid + 512 r -> (tap, k, 4 channels); line items -> (k, cell).
     // Every load is UNCONDITIONAL (clamped address; what does not exist becomes zero when the chunk is written to LDS) and the style scale
@@ -659,6 +656,10 @@ __global__ __launch_bounds__(ET) void t2_edge_kernel(const T2EdgeArgs p) {
             sv[r] = (ISC && !compact) ? iscb[k] : 1.f;
         }
     };
+    // operands of v_mfma_f32_32x32x2_f32 for channel pair j of the chunk: A[m][kk] = weight of channel 2 j + kk (lane = m + 32 kk),
+    // B[kk][n] = line value of cell n (+ 1 for the near tap: xs index 0 is cell c0 - 1)
+    const float* wa = ws + half * EM + wm * 32 + l31;           // + (tap * EKC + 2 j) * EM
+    const float* xb = xs + half * XS + wc * 32 + l31;           // + 2 j * XS (+ 1)
     fetch(0);
     for (int kc = 0; kc < p.K; kc += EKC) {
         __syncthreads();                  // the previous chunk's reads are done
@@ -671,79 +672,47 @@ __global__ __launch_bounds__(ET) void t2_edge_kernel(const T2EdgeArgs p) {
             if (xl[r] >= 0) xs[xl[r]] = (xok[r] && kc + xk[r] < p.K) ? xv[r] * sv[r] : 0.f;
         __syncthreads();
         if (kc + EKC < p.K) fetch(kc + EKC);          // in flight during the multiply-adds below
-#pragma unroll 4
-        for (int kk = 0; kk < EKC / EKS; ++kk) {
-            const int k = kh * (EKC / EKS) + kk;
-            const float* xr = &xs[k * XS + CT * cg];              // cells c - 1 .. c + CT - 1 of this thread's first cell c = c0 + CT cg
-            float x[CT + 1];
-            if (CT == 4) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xr);
-                x[0] = x4[0]; x[1] = x4[1]; x[2] = x4[2]; x[3] = x4[3]; x[CT] = xr[4];
-            } else {
 #pragma unroll
-                for (int c = 0; c <= CT; ++c) x[c] = xr[c];
-            }
-            const f32x4 wn = *reinterpret_cast<const f32x4*>(&ws[(0 * EKC + k) * EM + 4 * mg]);
-            const f32x4 wf = *reinterpret_cast<const f32x4*>(&ws[(1 * EKC + k) * EM + 4 * mg]);
-            const f32x4 wo = *reinterpret_cast<const f32x4*>(&ws[(2 * EKC + k) * EM + 4 * mg]);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f32x2 wn2 = {wn[2 * m], wn[2 * m + 1]}, wf2 = {wf[2 * m], wf[2 * m + 1]}, wo2 = {wo[2 * m], wo[2 * m + 1]};
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const f32x2 xa = {x[c + 1], x[c + 1]}, xb = {x[c], x[c]};
-                    ae[m][c] = __builtin_elementwise_fma(wn2, xa, ae[m][c]);
-                    ae[m][c] = __builtin_elementwise_fma(wf2, xb, ae[m][c]);
-                    ao[m][c] = __builtin_elementwise_fma(wo2, xa, ao[m][c]);
-                }
-            }
+        for (int jj = 0; jj < EKC / 2 / KG; ++jj) {
+            const int j = kg + KG * jj;                // this wave group's channel pairs of the chunk
+            const float an = wa[(0 * EKC + 2 * j) * EM], af = wa[(1 * EKC + 2 * j) * EM], aod = wa[(2 * EKC + 2 * j) * EM];
+            const float bn = xb[2 * j * XS + 1], bf = xb[2 * j * XS];
+            ae = __builtin_amdgcn_mfma_f32_32x32x2f32(an, bn, ae, 0, 0, 0);
+            ao = __builtin_amdgcn_mfma_f32_32x32x2f32(aod, bn, ao, 0, 0, 0);
+            ae = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, ae, 0, 0, 0);
         }
     }
-    // the channel groups meet in group 0, one after the other (fixed order: ((g0 + g1) + g2) + g3), then the direct kernel's epilogue:
+    // the wave groups meet in group 0, one after the other (fixed order: ((g0 + g1) + g2) + g3), then the direct kernel's epilogue:
     // demodulation scale, bias, leaky ReLU
-    float* red = smem;                    // NACC partial sums per thread of one group
+    float* red = smem + tw * (64 * 32);         // 32 partial sums per lane of this tile
 #pragma unroll
-    for (int g = 1; g < EKS; ++g) {
+    for (int g = 1; g < KG; ++g) {
         __syncthreads();
-        if (kh == g) {
+        if (kg == g) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    *reinterpret_cast<f32x2*>(&red[(((m * CT + c) * 2 + 0) * 256 + t8) * 2]) = ae[m][c];
-                    *reinterpret_cast<f32x2*>(&red[(((m * CT + c) * 2 + 1) * 256 + t8) * 2]) = ao[m][c];
-                }
+            for (int r = 0; r < 16; ++r) { red[r * 64 + lane] = ae[r]; red[(16 + r) * 64 + lane] = ao[r]; }
         }
         __syncthreads();
-        if (kh == 0) {
+        if (kg == 0) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    ae[m][c] += *reinterpret_cast<const f32x2*>(&red[(((m * CT + c) * 2 + 0) * 256 + t8) * 2]);
-                    ao[m][c] += *reinterpret_cast<const f32x2*>(&red[(((m * CT + c) * 2 + 1) * 256 + t8) * 2]);
-                }
+            for (int r = 0; r < 16; ++r) { ae[r] += red[r * 64 + lane]; ao[r] += red[(16 + r) * 64 + lane]; }
         }
     }
-    if (kh != 0) return;
+    if (kg != 0) return;
     const float gain = p.act == 3 ? 1.4142135623730951f : 1.f;
+    const int o = 2 * (c0 + wc * 32 + l31);     // the lane's cell: outputs o (even) and o + 1 (odd)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int mm = m0 + 4 * mg + m;
+    for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const float sc = p.osc ? p.osc[(size_t)b * p.M + mm] : 1.f, bi = p.bias ? p.bias[mm] : 0.f;
         float* orow = p.out + ((size_t)b * p.M + mm) * oplane + obase;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int o = 2 * (c0 + CT * cg + c);
-            float ve = ae[m >> 1][c][m & 1] * sc + bi;
-            float vo = ao[m >> 1][c][m & 1] * sc + bi;
-            if (p.act >= 3) {
-                ve = (ve > 0.f ? ve : ve * 0.2f) * gain;
-                vo = (vo > 0.f ? vo : vo * 0.2f) * gain;
-            }
-            if (o < NOUT) orow[(size_t)o * so] = ve;
-            if (o + 1 < NOUT) orow[(size_t)(o + 1) * so] = vo;
+        float ve = ae[r] * sc + bi, vo = ao[r] * sc + bi;
+        if (p.act >= 3) {
+            ve = (ve > 0.f ? ve : ve * 0.2f) * gain;
+            vo = (vo > 0.f ? vo : vo * 0.2f) * gain;
         }
+        if (o < NOUT) orow[(size_t)o * so] = ve;
+        if (o + 1 < NOUT) orow[(size_t)(o + 1) * so] = vo;
     }
 }
 
