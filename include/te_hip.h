@@ -282,7 +282,7 @@ int te_wgrad_pair_form(int kind, int Co, int Ci, int H, int W);
 /* Round 5: the 3x3 correlation on the bf16 matrix pipe (csrc/wgrad6.hip: pair form, every fp32 operand split into three bf16 pieces,
  * six exact piece products per multiply-add, fp32 accumulation - fp32-equivalent slabs, same layout, same reducers).
  * te_wgrad_split_supported: 1 where it applies (Co % 64 == 0, Ci % 64 == 0; kind TE_CONV_3X3: W % 32 == 0; kind TE_CONV_T2 - direct
- * form, nine taps x six products - W % 16 == 0).
+ * form, nine taps x six products - W % 16 == 0; round 6: kind TE_CONV_1X1 with Co % 128 == 0, Ci % 128 == 0, W % 16 == 0).
  * te_wgrad_split_bf16(0 | 1): process-wide switch (environment TE_SPLIT_WGRAD at load time), returns the previous value; any other
  * argument only queries.  With the switch on, te_wgrad_f32 / te_wgrad_group_f32 take the kernel where it applies and the fp32
  * kernel elsewhere. */
