@@ -378,6 +378,7 @@ __global__ __launch_bounds__(WT, 2) void s2s6_kernel(const S2Args p) {
 //     M0: 54 MFMAs + the fetch of stage s + 1       SA: weight DMA only
 //     M1: 54 MFMAs + the staging arithmetic         SB: weight DMA + res -> T_g(s + 1)
 // Same products in the same order per output element as s2s6_kernel: bit-identical results (tests/test_gpu_s2s6.py).
+// (FOUR images per staged half tile - 256 output channels, 4 x 32 accumulator registers - does not fit: 256 VGPRs with 192 spilled.)
 template <bool ISC>
 __global__ __launch_bounds__(WT, 2) void s2s6q_kernel(const S2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
