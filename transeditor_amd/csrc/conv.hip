@@ -1259,8 +1259,9 @@ extern "C" int te_conv_res_f32(float* out, float* ws, const float* in, const flo
     a.out = out; a.ws = ws; a.in = in; a.wp = wp; a.isc = isc; a.osc = osc; a.bias = bias; a.res = res; a.mref = mask_ref; a.mgain = mask_gain; a.act = act;
     a.B = B; a.K = K; a.M = M; a.Kp = roundup(K, KPAD); a.Mp = roundup(M, MPAD); a.H = H; a.W = W;
     if (kind == TE_CONV_T2S6) {
-        // body cells on the bf16 pipe; the last output row and column (cells i = H, j = W) as two thin regions of the fp32 kernel,
-        // from the plain copy of the weights behind the split layout (TE_PACK_T6FWD / TE_PACK_T6SWAP).  The thin launch is a few dozen
+        // body cells on the bf16 pipe; the last output row and column (cells i = H, j = W) from the plain copy of the weights behind the
+        // split layout (TE_PACK_T6FWD / TE_PACK_T6SWAP): since round 6 by t2_edge_kernel (below); under TE_T2_EDGE=0 as two thin regions of
+        // the fp32 kernel, the round-5 path this comment describes.  The thin launch is a few dozen
         // blocks that each walk the whole channel loop (130 - 150 us of latency for < 1 GFLOP: 28 % of a 128-channel launch,
         // tools/block_overhead_probe.py); it writes other output pixels than the body, so it runs on a SIDE stream of this host thread,
         // forked from and joined back into the caller's stream with events (also legal inside a stream capture), concurrently with

@@ -7,8 +7,9 @@
 // (mod 2) - 4 + 2 + 2 + 1 = 9 tap products per input pixel, no zero insertion - into FOUR accumulator tiles (one per phase); a tap with
 // ky = 2 (kx = 2) reads the input one row up (one column left).  This kernel covers the BODY cells [0, H) x [0, W), i.e. output rows
 // 0 .. 2H - 1 and columns 0 .. 2W - 1; the last output row and column (cells i = H / j = W, which only see taps with ky = 2 / kx = 2)
-// are two thin regions of the fp32 kernel, launched behind it from the fp32 copy of the weights that the packed buffer carries along
-// (TE_PACK_T6FWD / TE_PACK_T6SWAP = split fragment-order layout of s2s6.hip + TE_PACK_FWD / TE_PACK_SWAP layout; conv.hip).
+// come from t2_edge_kernel below (round 6; until then two thin regions of the fp32 kernel), launched behind it from the fp32 copy of
+// the weights that the packed buffer carries along (TE_PACK_T6FWD / TE_PACK_T6SWAP = split fragment-order layout of s2s6.hip +
+// TE_PACK_FWD / TE_PACK_SWAP layout; conv.hip).
 //
 // Structure = s2s6.hip (ping-pong form, read wino6.hip's header): block 512 threads, cell tile 64 output channels x 8 rows x 16 columns,
 // two half tiles of 4 cell rows (5 input rows x 17 columns each with the halo), wave (wm, wrl) of a group = 32 channels x cell rows
